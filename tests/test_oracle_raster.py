@@ -1,0 +1,254 @@
+"""Pins the CPU oracle (oracle/raster_oracle.c) -- the reference holds no tests for this path
+(SURVEY.md section 4), so the oracle is pinned by hand-derived known answers, structural invariants and
+finite differences of its own fp64 build."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import raster_oracle as ro
+from scenes import camera, random_gaussians
+
+
+def _fwd(s, **kw):
+    args = dict(shs=s.get("shs"), sh_degree=s.get("sh_degree", 3), scales=s["scales"], rotations=s["rotations"])
+    args.update(kw)
+    return ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], s["W"], s["H"],
+                      s["tanfovx"], s["tanfovy"], s["bg"], **args)
+
+
+def _single(z=2.0, s=0.05, o=0.6, W=17, H=17, color=(0.2, 0.5, 0.9)):
+    cam = camera(W, H)
+    return dict(means3D=np.array([[0, 0, z]], np.float32), scales=np.full((1, 3), s, np.float32),
+                rotations=np.array([[1, 0, 0, 0]], np.float32), opacities=np.array([[o]], np.float32),
+                colors_precomp=np.array([color], np.float32), bg=np.array([0.1, 0.2, 0.3], np.float32), **cam)
+
+
+def test_get_higher_msb():
+    # rasterizer_impl.cu:35-50; SURVEY appendix A: 9 for 256 tiles, 11 for 2040, 13 for 8160
+    assert ro.get_higher_msb(256) == 9
+    assert ro.get_higher_msb(2040) == 11
+    assert ro.get_higher_msb(8160) == 13
+    assert ro.get_higher_msb(1) == 1
+
+
+def test_single_isotropic_gaussian_on_pixel_centre():
+    s = _single()
+    st = _fwd(s, shs=None, colors_precomp=s["colors_precomp"])
+    W = H = 17
+    focal = W / (2 * s["tanfovx"])
+    a = np.float32((focal / 2.0) ** 2 * 0.05 ** 2 + 0.3)
+    # lambda = mid + sqrt(max(0.1, mid^2 - det)) with mid^2 == det for an isotropic splat (forward.cu:229-232)
+    radius = math.ceil(3 * math.sqrt(a + math.sqrt(0.1)))
+    assert st.radii[0] == radius
+    np.testing.assert_allclose(st.means2D[0], [8.0, 8.0], atol=1e-5)   # ndc2Pix(0, 17) = 8
+    np.testing.assert_allclose(st.conic_opacity[0], [1 / a, 0, 1 / a, 0.6], rtol=1e-5, atol=1e-7)
+    assert st.depths[0] == np.float32(2.0)
+    # rect: (8 +- r) over 16px tiles on a 2x2 grid
+    rmin = max(0, int((8 - radius) / 16)); rmax = min(2, int((8 + radius + 15) / 16))
+    assert st.tiles_touched[0] == (rmax - rmin) ** 2 == st.num_rendered
+    alpha = min(0.99, 0.6)
+    col = np.array([0.2, 0.5, 0.9]) * alpha + (1 - alpha) * s["bg"]
+    np.testing.assert_allclose(st.out_color[:, 8, 8], col, rtol=1e-6)
+    np.testing.assert_allclose(st.out_depth[0, 8, 8], 2.0 * alpha, rtol=1e-6)
+    np.testing.assert_allclose(st.final_T[8 * 17 + 8], 1 - alpha, rtol=1e-6)
+    # one pixel off centre: power = -0.5/a
+    G = math.exp(-0.5 / a)
+    np.testing.assert_allclose(st.out_color[0, 8, 9], 0.2 * 0.6 * G + (1 - 0.6 * G) * 0.1, rtol=1e-5)
+
+
+def test_two_overlapping_gaussians_both_depth_orders():
+    cam = camera(17, 17)
+    for order in ((2.0, 3.0), (3.0, 2.0)):
+        means = np.array([[0, 0, order[0]], [0, 0, order[1]]], np.float32)
+        c = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]], np.float32)
+        o = np.array([[0.5], [0.8]], np.float32)
+        st = ro.forward(means, o, cam["viewmatrix"], cam["projmatrix"], cam["campos"], 17, 17, cam["tanfovx"],
+                        cam["tanfovy"], np.zeros(3, np.float32), colors_precomp=c,
+                        scales=np.full((2, 3), 0.05, np.float32), rotations=np.array([[1, 0, 0, 0]] * 2, np.float32))
+        first, second = (0, 1) if order[0] < order[1] else (1, 0)
+        a1, a2 = o[first, 0], o[second, 0]
+        exp = c[first] * a1 + (1 - a1) * a2 * c[second]
+        np.testing.assert_allclose(st.out_color[:, 8, 8], exp, rtol=1e-6)
+        # front-most first in the centre tile's list
+        t = 0
+        lst = st.point_list[st.ranges[t, 0]:st.ranges[t, 1]]
+        assert list(lst) == [first, second]
+        assert st.n_contrib[8 * 17 + 8] == 2
+
+
+def test_near_plane_cull_at_0p2():
+    s = _single(z=0.2)
+    st = _fwd(s, shs=None, colors_precomp=s["colors_precomp"])
+    assert st.radii[0] == 0 and st.num_rendered == 0        # p_view.z <= 0.2 culled (auxiliary.h:154)
+    np.testing.assert_allclose(st.out_color[:, 8, 8], s["bg"])
+    s = _single(z=float(np.nextafter(np.float32(0.2), np.float32(1))))
+    st = _fwd(s, shs=None, colors_precomp=s["colors_precomp"])
+    assert st.radii[0] > 0
+
+
+def test_saturation_stops_before_blending_the_stopping_gaussian():
+    # T*(1-alpha) < 1e-4 => done, and the stopping Gaussian is NOT blended (forward.cu:349-354)
+    cam = camera(17, 17)
+    n = 3
+    means = np.array([[0, 0, 2.0 + i] for i in range(n)], np.float32)
+    o = np.full((n, 1), 1.0, np.float32)  # alpha = 0.99 each: T = 1e-2, 1e-4 (not < 1e-4?) ...
+    c = np.eye(3, dtype=np.float32)
+    st = ro.forward(means, o, cam["viewmatrix"], cam["projmatrix"], cam["campos"], 17, 17, cam["tanfovx"],
+                    cam["tanfovy"], np.zeros(3, np.float32), colors_precomp=c,
+                    scales=np.full((n, 3), 0.05, np.float32), rotations=np.array([[1, 0, 0, 0]] * n, np.float32))
+    a = np.float32(0.99)
+    T1 = np.float32(1) * (np.float32(1) - a)
+    T2 = T1 * (np.float32(1) - a)
+    nc = st.n_contrib[8 * 17 + 8]
+    if T2 < np.float32(0.0001):
+        assert nc == 1
+        np.testing.assert_allclose(st.out_color[:, 8, 8], [0.99, 0, 0], rtol=1e-6)
+    else:
+        assert nc == 2
+        np.testing.assert_allclose(st.out_color[:, 8, 8], [0.99, 0.99 * T1, 0], rtol=1e-6)
+    assert st.final_T[8 * 17 + 8] >= np.float32(0.0001)
+
+
+def test_border_straddling_rect_uses_truncation():
+    # mean left of the image: (p.x - r)/16 is negative and truncates toward zero, then clamps (auxiliary.h:46-56)
+    cam = camera(64, 48)
+    x = -1.02 * cam["tanfovx"] * 2.0
+    s = dict(means3D=np.array([[x, 0, 2.0]], np.float32), scales=np.full((1, 3), 0.1, np.float32),
+             rotations=np.array([[1, 0, 0, 0]], np.float32), opacities=np.array([[0.9]], np.float32),
+             bg=np.zeros(3, np.float32), **cam)
+    st = _fwd(s, shs=None, colors_precomp=np.ones((1, 3), np.float32))
+    px, py = st.means2D[0]
+    r = st.radii[0]
+    assert px < 0 and r > 0
+    exp_min = min(4, max(0, int((px - r) / 16)))
+    exp_max = min(4, max(0, int((px + r + 15) / 16)))
+    ymin = min(3, max(0, int((py - r) / 16))); ymax = min(3, max(0, int((py + r + 15) / 16)))
+    assert st.tiles_touched[0] == (exp_max - exp_min) * (ymax - ymin)
+    assert st.tiles_touched[0] > 0
+
+
+def test_clamped_sh_colour_flags():
+    s = _single()
+    shs = np.zeros((1, 16, 3), np.float32)
+    shs[0, 0] = [-5.0, 0.0, 5.0]  # 0.282*(-5)+0.5 < 0 -> clamped
+    st = _fwd(s, shs=shs, sh_degree=0)
+    assert list(st.clamped[0]) == [1, 0, 0]
+    assert st.rgb[0, 0] == 0.0
+    np.testing.assert_allclose(st.rgb[0, 1:], [0.5, 0.28209479177387814 * 5 + 0.5], rtol=1e-6)
+
+
+@pytest.mark.parametrize("seed,P,W,H", [(0, 500, 128, 96), (1, 1500, 100, 50), (2, 64, 33, 17)])
+def test_structural_invariants(seed, P, W, H):
+    s = random_gaussians(P, seed=seed, W=W, H=H)
+    st = _fwd(s)
+    R = st.num_rendered
+    assert int(st.tiles_touched.sum()) == R == int(st.point_offsets[-1])
+    # keys sorted by (tile, depth bits); ties by ascending Gaussian index (stable sort of emission order)
+    tiles = (st.point_list_keys >> np.uint64(32)).astype(np.int64)
+    dbits = (st.point_list_keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    order = np.lexsort((st.point_list.astype(np.int64), dbits, tiles))
+    assert np.array_equal(order, np.arange(R))
+    assert np.array_equal(dbits, st.depths.view(np.uint32)[st.point_list].astype(np.int64))
+    # ranges partition [0, R) in tile order; empty tiles are (0, 0)
+    pos = 0
+    for t in range(st.ranges.shape[0]):
+        a, b = st.ranges[t]
+        if a == b == 0 and not (tiles == t).any():
+            continue
+        assert a == pos and b > a
+        assert (tiles[a:b] == t).all()
+        pos = b
+    assert pos == R
+    # n_contrib <= length of the tile's range
+    gx = (W + 15) // 16
+    nc = st.n_contrib.reshape(H, W)
+    for py in range(0, H, 7):
+        for px in range(0, W, 5):
+            t = (py // 16) * gx + px // 16
+            assert nc[py, px] <= st.ranges[t, 1] - st.ranges[t, 0]
+    # sum of blend weights + T_final == 1 per pixel
+    st1 = _fwd(dict(s, bg=np.zeros(3, np.float32)), shs=None, colors_precomp=np.ones((P, 3), np.float32))
+    np.testing.assert_allclose(st1.out_color[0].reshape(-1) + st1.final_T, 1.0, atol=2e-5)
+    assert (st.radii[s["means3D"][:, 2] <= 0.2] == 0).all()
+
+
+def test_empty_input():
+    cam = camera(32, 32)
+    st = ro.forward(np.zeros((0, 3), np.float32), np.zeros((0, 1), np.float32), cam["viewmatrix"], cam["projmatrix"],
+                    cam["campos"], 32, 32, cam["tanfovx"], cam["tanfovy"], np.ones(3, np.float32),
+                    shs=np.zeros((0, 16, 3), np.float32), colors_precomp=np.zeros((0, 3), np.float32),
+                    scales=np.zeros((0, 3), np.float32), rotations=np.zeros((0, 4), np.float32))
+    assert st.num_rendered == 0 and (st.out_color == 0).all()   # P==0 short-circuits to zeros
+
+
+def _loss64(s, wc, wd, **over):
+    d = dict(s)
+    d.update(over)
+    st = ro.forward(d["means3D"], d["opacities"], d["viewmatrix"], d["projmatrix"], d["campos"], d["W"], d["H"],
+                    d["tanfovx"], d["tanfovy"], d["bg"], shs=d["shs"], sh_degree=3, scales=d["scales"],
+                    rotations=d["rotations"], fp64=True)
+    return float((st.out_color * wc).sum() + (st.out_depth * wd).sum()), st
+
+
+def test_backward_matches_finite_differences_fp64():
+    """Analytic backward (backward.cu restated) vs central differences of the fp64 forward, away from the
+    reference's deliberate non-derivatives (0.99 cap: backward.cu:571; frustum clamp: :175-176)."""
+    W, H, P = 40, 24, 24
+    s = random_gaussians(P, seed=5, W=W, H=H, zrange=(2.0, 5.0), scale=(-2.6, -1.8))
+    s["means3D"][:, 0] *= 0.7
+    s["means3D"][:, 1] *= 0.7
+    s["means3D"][:, 2] = np.abs(s["means3D"][:, 2]) + 1.5
+    s["opacities"] = np.clip(s["opacities"], 0.05, 0.85)
+    s = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype == np.float32 else v) for k, v in s.items()}
+    rng = np.random.default_rng(0)
+    wc = rng.normal(size=(3, H, W))
+    wd = rng.normal(size=(1, H, W)) * 0.3
+    L0, st = _loss64(s, wc, wd)
+    g = ro.backward(st, wc, wd)
+    checks = [("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+              ("opacities", "dL_dopacity"), ("shs", "dL_dsh")]
+    eps = 1e-6
+    for name, gname in checks:
+        x = s[name]
+        ga = g[gname].reshape(x.shape)
+        flat_idx = rng.choice(x.size, size=min(40, x.size), replace=False)
+        bad = 0
+        for fi in flat_idx:
+            idx = np.unravel_index(fi, x.shape)
+            xp = x.copy(); xp[idx] += eps
+            xm = x.copy(); xm[idx] -= eps
+            fd = (_loss64(s, wc, wd, **{name: xp})[0] - _loss64(s, wc, wd, **{name: xm})[0]) / (2 * eps)
+            if not np.isclose(fd, ga[idx], rtol=2e-4, atol=1e-6):
+                bad += 1
+        # a perturbation may cross one of the hard thresholds (1/255, power>0, T<1e-4, ceil radius): allow a few
+        assert bad <= 2, (name, bad)
+
+
+def test_viewspace_gradient_is_ndc_scaled():
+    # dL_dmean2D is scaled by 0.5*W / 0.5*H (backward.cu:485-486,578-579)
+    s = random_gaussians(200, seed=3, W=64, H=48)
+    st = _fwd(s)
+    g = ro.backward(st, np.ones((3, 48, 64), np.float32))
+    assert np.abs(g["dL_dmeans2D"][:, 2]).max() == 0
+    assert np.abs(g["dL_dmeans2D"][:, :2]).max() > 0
+    assert np.abs(g["dL_dconic"][:, 2]).max() == 0   # component z of the float4 is never written (:582-584)
+    invisible = st.radii == 0
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dsh"):
+        assert np.abs(g[k][invisible]).max() == 0
+
+
+def test_knn_matches_brute_force():
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(3000, 3)).astype(np.float32)
+    got = ro.knn_mean_dist2(pts)
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    np.fill_diagonal(d2, np.inf)
+    exp = np.sort(d2, axis=1)[:, :3].mean(1)
+    np.testing.assert_allclose(got, exp, rtol=1e-5)
+
+
+def test_mark_visible():
+    s = random_gaussians(300, seed=4)
+    vis = ro.mark_visible(s["means3D"], s["viewmatrix"], s["projmatrix"])
+    assert np.array_equal(vis, s["means3D"][:, 2] > 0.2)
