@@ -1,0 +1,107 @@
+"""ctypes binding of libmom4d.so (the C ABI declared in include/mom4d.h).
+
+The product path FAILS LOUDLY when the HIP library is missing: there is no CPU or
+torch fallback behind these calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmom4d.so")
+_lib = None
+
+MOM_OK, MOM_EINVAL, MOM_ELAUNCH, MOM_ECAPACITY = 0, -1, -2, -3
+_ERR = {MOM_EINVAL: "invalid argument", MOM_ELAUNCH: "HIP launch/runtime failure", MOM_ECAPACITY: "scratch too small"}
+
+
+class MomError(RuntimeError):
+    pass
+
+
+class MomRasterArgs(C.Structure):
+    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
+                ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
+                ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
+                ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("scale_modifier", C.c_float),
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int)]
+
+
+class MomRasterGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D",
+                                          "dL_dsh", "dL_dscales", "dL_drotations")]
+
+
+class MomRasterLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in ("geom_rec", "geom_cov3D", "geom_clamped", "geom_gacc", "img_ranges",
+                                          "img_n_contrib", "img_final_T", "img_tile_counts", "bin_keys",
+                                          "bin_point_list")]
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into lib/libmom4d.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise MomError("building libmom4d.so failed:\n" + r.stdout[-4000:])
+    if verbose:
+        print(r.stdout)
+    return LIB_PATH
+
+
+def _sig(lib):
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    lib.mom_version.restype = C.c_char_p
+    lib.mom_raster_geom_bytes.restype = sz
+    lib.mom_raster_geom_bytes.argtypes = [i32]
+    lib.mom_raster_image_bytes.restype = sz
+    lib.mom_raster_image_bytes.argtypes = [i32, i32]
+    lib.mom_raster_binning_bytes.restype = sz
+    lib.mom_raster_binning_bytes.argtypes = [i32, i32, i32, sz]
+    lib.mom_raster_layout.argtypes = [i32, i32, i32, sz, C.POINTER(MomRasterLayout)]
+    lib.mom_raster_forward_geometry.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, vp, vp, vp]
+    lib.mom_raster_forward_render.argtypes = [C.POINTER(MomRasterArgs), vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.mom_raster_backward.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, sz, vp, vp, vp, C.POINTER(MomRasterGrads), vp]
+    lib.mom_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
+    for name in EXPORTS:
+        getattr(lib, name)  # raises AttributeError if the library lacks a declared symbol
+    return lib
+
+
+# every symbol include/mom4d.h declares (tests/test_abi.py checks this list against the header)
+EXPORTS = [
+    "mom_version", "mom_raster_geom_bytes", "mom_raster_image_bytes", "mom_raster_binning_bytes", "mom_raster_layout",
+    "mom_raster_forward_geometry", "mom_raster_forward_render", "mom_raster_backward", "mom_mark_visible",
+    "mom_selftest_wave_sum",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MomError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+        _lib = _sig(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != MOM_OK:
+        raise MomError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None / empty tensor -> NULL, like the reference's empty tensors)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,128 @@
+// Internal definitions shared by the HIP translation units of libmom4d.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/mom4d.h"
+
+#define MOM_WAVE 64
+#define MOM_ALIGN 256
+
+// ---- private scratch layouts -------------------------------------------------
+// geom (per Gaussian):
+//   rec[P][3] float4 : {x, y, depth, tiles_touched bits} {conic.x, conic.y, conic.z, opacity} {r, g, b, radius bits}
+//   cov3D[P][6] float, clamped[P] uchar4, gacc[P][12] float (backward accumulators)
+// image: hdr[64] u32, tile_counts[tiles] u32, tile_cursor[tiles] u32, ranges[tiles] uint2, n_contrib[H*W] u32,
+//        final_T[H*W] f32
+// binning: keys[cap] u64, point_list[cap] u32   (sized once the instance count is known)
+struct GeomView {
+    float4* rec;
+    float* cov3D;
+    uchar4* clamped;
+    float* gacc;
+};
+struct ImageView {
+    uint32_t* hdr;  // [0] = num_rendered, [1] = status bits
+    uint32_t* tile_counts;
+    uint32_t* tile_cursor;
+    uint2* ranges;
+    uint32_t* n_contrib;
+    float* final_T;
+};
+struct BinView {
+    uint64_t* keys;
+    uint32_t* point_list;
+};
+
+static inline size_t mom_align_up(size_t x) { return (x + MOM_ALIGN - 1) & ~(size_t)(MOM_ALIGN - 1); }
+
+static inline size_t geom_view(char* base, int P, GeomView* v)
+{
+    size_t off = 0;
+    size_t o_rec = off; off = mom_align_up(off + (size_t)P * 48);
+    size_t o_cov = off; off = mom_align_up(off + (size_t)P * 24);
+    size_t o_cl = off; off = mom_align_up(off + (size_t)P * 4);
+    size_t o_ga = off; off = mom_align_up(off + (size_t)P * 48);
+    if (v) {
+        v->rec = (float4*)(base + o_rec);
+        v->cov3D = (float*)(base + o_cov);
+        v->clamped = (uchar4*)(base + o_cl);
+        v->gacc = (float*)(base + o_ga);
+    }
+    return off + MOM_ALIGN;
+}
+static inline size_t image_view(char* base, int W, int H, ImageView* v)
+{
+    const size_t tiles = (size_t)((W + MOM_TILE - 1) / MOM_TILE) * ((H + MOM_TILE - 1) / MOM_TILE);
+    const size_t N = (size_t)W * H;
+    size_t off = 0;
+    size_t o_h = off; off = mom_align_up(off + 64 * 4);
+    size_t o_c = off; off = mom_align_up(off + tiles * 4);
+    size_t o_u = off; off = mom_align_up(off + tiles * 4);
+    size_t o_r = off; off = mom_align_up(off + tiles * 8);
+    size_t o_n = off; off = mom_align_up(off + N * 4);
+    size_t o_t = off; off = mom_align_up(off + N * 4);
+    if (v) {
+        v->hdr = (uint32_t*)(base + o_h);
+        v->tile_counts = (uint32_t*)(base + o_c);
+        v->tile_cursor = (uint32_t*)(base + o_u);
+        v->ranges = (uint2*)(base + o_r);
+        v->n_contrib = (uint32_t*)(base + o_n);
+        v->final_T = (float*)(base + o_t);
+    }
+    return off + MOM_ALIGN;
+}
+static inline size_t bin_view(char* base, size_t cap, BinView* v)
+{
+    size_t off = 0;
+    size_t o_k = off; off = mom_align_up(off + cap * 8);
+    size_t o_p = off; off = mom_align_up(off + cap * 4);
+    if (v) {
+        v->keys = (uint64_t*)(base + o_k);
+        v->point_list = (uint32_t*)(base + o_p);
+    }
+    return off + MOM_ALIGN;
+}
+static inline char* mom_align_ptr(void* p)
+{
+    return (char*)(((uintptr_t)p + MOM_ALIGN - 1) & ~(uintptr_t)(MOM_ALIGN - 1));
+}
+
+#define MOM_CHECK_LAUNCH(a, s)                                         \
+    do {                                                               \
+        hipError_t e__ = hipGetLastError();                            \
+        if (e__ != hipSuccess) return MOM_ELAUNCH;                     \
+        if ((a)->debug) {                                              \
+            e__ = hipStreamSynchronize((hipStream_t)(s));              \
+            if (e__ != hipSuccess) return MOM_ELAUNCH;                 \
+        }                                                              \
+    } while (0)
+
+#ifdef __HIPCC__
+// ---- device helpers ----------------------------------------------------------
+// Tile rectangle of a splat: truncating casts then clamp (reference auxiliary.h:46-56).
+__device__ __forceinline__ void mom_get_rect(float px, float py, int max_radius, int gx, int gy, int& x0, int& y0,
+                                             int& x1, int& y1)
+{
+    x0 = min(gx, max(0, (int)((px - max_radius) / MOM_TILE)));
+    y0 = min(gy, max(0, (int)((py - max_radius) / MOM_TILE)));
+    x1 = min(gx, max(0, (int)((px + max_radius + MOM_TILE - 1) / MOM_TILE)));
+    y1 = min(gy, max(0, (int)((py + max_radius + MOM_TILE - 1) / MOM_TILE)));
+}
+
+// exp(x) for x <= 0 on the transcendental unit: v_exp_f32(x*log2e) with the
+// rounding error of the product fed back (about 1.5 ulp; both render passes use
+// this one function so they take identical alpha branches).
+__device__ __forceinline__ float mom_exp(float x)
+{
+    const float L2E = 1.4426950408889634f;
+    const float L2E_LO = 1.9259629911266175e-8f;  // log2(e) - (float)log2(e)
+    float t = x * L2E;
+    float e = __builtin_fmaf(x, L2E, -t);
+    e = __builtin_fmaf(x, L2E_LO, e);
+    float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r * 0.6931471805599453f, e, r);
+}
+
+__device__ __forceinline__ int mom_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#endif

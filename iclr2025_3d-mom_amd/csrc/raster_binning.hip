@@ -1,0 +1,282 @@
+// Tile binning + per-tile depth sort for the rasterizer, gfx950.
+//
+// Replaces InclusiveSum + duplicateWithKeys + DeviceRadixSort::SortPairs +
+// identifyTileRanges (reference rasterizer_impl.cu:70-138,278-318).  The
+// reference sorts all (tile<<32 | depth_bits) keys globally with a stable LSD
+// radix sort over instances emitted in ascending Gaussian index, i.e. its
+// point_list is ordered by (tile, depth_bits, gaussian_idx) -- a TOTAL order.
+// Any algorithm that realises that total order yields the same bits, so this
+// file does an MSD split instead:
+//   1. tile_hist    : per-workgroup LDS histogram of the instances per tile
+//                     (wave-cooperative for large splats), flushed with one
+//                     global atomic per non-empty (workgroup, tile);
+//   2. tile_scan    : one workgroup scans the <=36k tile counters -> ranges,
+//                     bucket cursors and the instance count;
+//   3. tile_scatter : same enumeration, one returning global atomic per
+//                     non-empty (workgroup, tile) reserves a slice of the tile's
+//                     bucket, LDS atomics rank inside the slice; writes the
+//                     64-bit key (depth_bits<<32 | idx) -- order inside a bucket
+//                     is arbitrary here;
+//   4. tile_sort    : one workgroup per tile sorts its bucket by the 64-bit key
+//                     in LDS (bitonic network, all compare-exchanges ascending,
+//                     so no padding is ever materialised) and writes point_list.
+// Instances never travel through HBM more than: 8 B write, 8 B read, 4 B write.
+#include "mom_common.h"
+
+namespace {
+
+constexpr int kSmallRect = 8;          // splats touching <= 8 tiles are enumerated by their own lane
+constexpr int kSortLdsCap = 8192;      // 64 KiB of 64-bit keys per workgroup
+constexpr int kMaxLdsTiles = 16384;    // 64 KiB LDS histogram
+
+// Calls f(tile, src_lane, src_payload) once for every (Gaussian, tile) instance of this wave's 64
+// Gaussians.  Lanes own small rectangles; large ones are walked by the whole wave (the owner's payload
+// is broadcast with v_readlane before the divergent loop).
+template <class F>
+__device__ __forceinline__ void for_each_instance(int x0, int y0, int x1, int y1, int gx, uint32_t payload, F f)
+{
+    const int lane = mom_lane();
+    const int w = x1 - x0;
+    const int cnt = w * (y1 - y0);
+    if (cnt <= kSmallRect) {
+        for (int i = 0; i < cnt; i++) f((y0 + i / w) * gx + x0 + i % w, lane, payload);
+    }
+    unsigned long long big = __ballot(cnt > kSmallRect);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bx0 = __builtin_amdgcn_readlane(x0, src);
+        const int by0 = __builtin_amdgcn_readlane(y0, src);
+        const int bw = __builtin_amdgcn_readlane(w, src);
+        const int bcnt = __builtin_amdgcn_readlane(cnt, src);
+        const uint32_t bpay = (uint32_t)__builtin_amdgcn_readlane((int)payload, src);
+        for (int i = lane; i < bcnt; i += MOM_WAVE) f((by0 + i / bw) * gx + bx0 + i % bw, src, bpay);
+    }
+}
+
+__device__ __forceinline__ void load_rect(const float4* __restrict__ rec, int g, int P, int gx, int gy, int& x0, int& y0,
+                                          int& x1, int& y1, uint32_t& depth_bits)
+{
+    x0 = y0 = x1 = y1 = 0;
+    depth_bits = 0;
+    if (g < P) {
+        const float4 r0 = rec[3 * (size_t)g];
+        const int radius = __float_as_int(rec[3 * (size_t)g + 2].w);
+        if (radius > 0) {
+            mom_get_rect(r0.x, r0.y, radius, gx, gy, x0, y0, x1, y1);
+            depth_bits = __float_as_uint(r0.z);
+        }
+    }
+}
+
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int gx, int gy, const float4* __restrict__ rec,
+                                                       uint32_t* __restrict__ tile_counts)
+{
+    extern __shared__ uint32_t s_cnt[];
+    const int tiles = gx * gy;
+    if (LDS_HIST) {
+        for (int t = threadIdx.x; t < tiles; t += 256) s_cnt[t] = 0;
+        __syncthreads();
+    }
+    for (int c = 0; c < chunks; c++) {
+        const int g = (blockIdx.x * chunks + c) * 256 + threadIdx.x;
+        int x0, y0, x1, y1;
+        uint32_t db;
+        load_rect(rec, g, P, gx, gy, x0, y0, x1, y1, db);
+        for_each_instance(x0, y0, x1, y1, gx, 0u, [&](int tile, int, uint32_t) {
+            if (LDS_HIST)
+                atomicAdd(&s_cnt[tile], 1u);
+            else
+                atomicAdd(&tile_counts[tile], 1u);
+        });
+    }
+    if (LDS_HIST) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < tiles; t += 256) {
+            const uint32_t n = s_cnt[t];
+            if (n) atomicAdd(&tile_counts[t], n);
+        }
+    }
+}
+
+// One workgroup (1024 threads): exclusive scan of the tile counters.
+__global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32_t* __restrict__ tile_counts,
+                                                        uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
+                                                        uint32_t* __restrict__ hdr, uint32_t* __restrict__ num_rendered_dev)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < tiles; base += 1024) {
+        const int t = base + threadIdx.x;
+        const uint32_t n = t < tiles ? tile_counts[t] : 0u;
+        uint32_t incl = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += s_wave[w];
+        const uint32_t carry = s_carry;
+        const uint32_t start = carry + woff + incl - n;
+        if (t < tiles) {
+            tile_cursor[t] = start;
+            ranges[t] = n ? make_uint2(start, start + n) : make_uint2(0u, 0u);  // empty tiles stay (0,0)
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = start + n;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        hdr[0] = s_carry;
+        *num_rendered_dev = s_carry;
+    }
+}
+
+template <bool LDS_HIST>
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, int gx, int gy, const float4* __restrict__ rec,
+                                                          uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
+                                                          uint32_t capacity, uint32_t* __restrict__ hdr)
+{
+    extern __shared__ uint32_t s_cnt[];
+    const int tiles = gx * gy;
+    bool overflow = false;
+    if (LDS_HIST) {
+        for (int t = threadIdx.x; t < tiles; t += 256) s_cnt[t] = 0;
+        __syncthreads();
+        for (int c = 0; c < chunks; c++) {
+            const int g = (blockIdx.x * chunks + c) * 256 + threadIdx.x;
+            int x0, y0, x1, y1;
+            uint32_t db;
+            load_rect(rec, g, P, gx, gy, x0, y0, x1, y1, db);
+            for_each_instance(x0, y0, x1, y1, gx, 0u, [&](int tile, int, uint32_t) { atomicAdd(&s_cnt[tile], 1u); });
+        }
+        __syncthreads();
+        // reserve this workgroup's slice of every non-empty bucket
+        for (int t = threadIdx.x; t < tiles; t += 256) {
+            const uint32_t n = s_cnt[t];
+            if (n) s_cnt[t] = atomicAdd(&tile_cursor[t], n);
+        }
+        __syncthreads();
+    }
+    for (int c = 0; c < chunks; c++) {
+        const int g = (blockIdx.x * chunks + c) * 256 + threadIdx.x;
+        const int wave_g0 = g - mom_lane();
+        int x0, y0, x1, y1;
+        uint32_t db;
+        load_rect(rec, g, P, gx, gy, x0, y0, x1, y1, db);
+        for_each_instance(x0, y0, x1, y1, gx, db, [&](int tile, int src, uint32_t sdb) {
+            const uint32_t pos = LDS_HIST ? atomicAdd(&s_cnt[tile], 1u) : atomicAdd(&tile_cursor[tile], 1u);
+            if (pos < capacity)
+                keys[pos] = ((uint64_t)sdb << 32) | (uint32_t)(wave_g0 + src);
+            else
+                overflow = true;
+        });
+    }
+    if (overflow) atomicOr(&hdr[1], 1u);
+}
+
+// ---- per-tile sort ------------------------------------------------------------
+// Bitonic network in the "flip then disperse" form: every compare-exchange puts
+// the smaller key at the lower index, so virtual +inf padding above n never moves
+// and is simply skipped.
+template <class KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int nthreads, int tid)
+{
+    int m = 1;
+    while (m < n) m <<= 1;
+    for (int kk = 2; kk <= m; kk <<= 1) {
+        const int half = kk >> 1;
+        for (int i = tid; i < (m >> 1); i += nthreads) {
+            const int blk = i / half, off = i - blk * half;
+            const int a = blk * kk + off, b = blk * kk + kk - 1 - off;
+            if (b < n) {
+                const uint64_t ka = k[a], kb = k[b];
+                if (ka > kb) { k[a] = kb; k[b] = ka; }
+            }
+        }
+        __syncthreads();
+        for (int j = kk >> 2; j >= 1; j >>= 1) {
+            for (int i = tid; i < (m >> 1); i += nthreads) {
+                const int a = ((i / j) * 2 * j) + (i % j), b = a + j;
+                if (b < n) {
+                    const uint64_t ka = k[a], kb = k[b];
+                    if (ka > kb) { k[a] = kb; k[b] = ka; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ point_list, uint32_t capacity)
+{
+    __shared__ uint64_t s_keys[kSortLdsCap];
+    const uint2 r = ranges[blockIdx.x];
+    uint32_t end = r.y < capacity ? r.y : capacity;
+    if (r.x >= end) return;
+    const int n = (int)(end - r.x);
+    uint64_t* gk = keys + r.x;
+    if (n <= kSortLdsCap) {
+        for (int i = threadIdx.x; i < n; i += 256) s_keys[i] = gk[i];
+        __syncthreads();
+        if (n > 1) bitonic_sort(s_keys, n, 256, threadIdx.x);
+        for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)s_keys[i];
+    } else {
+        // oversized bucket: same network directly on the (L2-resident) global bucket
+        __syncthreads();
+        bitonic_sort(gk, n, 256, threadIdx.x);
+        __threadfence_block();
+        for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)gk[i];
+    }
+}
+
+}  // namespace
+
+int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const ImageView& im, uint32_t* num_rendered_dev,
+                             hipStream_t s)
+{
+    const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
+    const int tiles = gx * gy;
+    if (hipMemsetAsync(im.hdr, 0, 64 * 4, s) != hipSuccess) return MOM_ELAUNCH;
+    if (hipMemsetAsync(im.tile_counts, 0, (size_t)tiles * 4, s) != hipSuccess) return MOM_ELAUNCH;
+    int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
+    if (chunks < 1) chunks = 1;
+    const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
+    if (tiles <= kMaxLdsTiles)
+        hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy, g.rec,
+                           im.tile_counts);
+    else
+        hipLaunchKernelGGL(tile_hist_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, g.rec, im.tile_counts);
+    if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tiles, im.tile_counts, im.tile_cursor, im.ranges, im.hdr,
+                       num_rendered_dev);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
+                            hipStream_t s)
+{
+    const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
+    const int tiles = gx * gy;
+    int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
+    if (chunks < 1) chunks = 1;
+    const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
+    const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+    if (tiles <= kMaxLdsTiles)
+        hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy,
+                           g.rec, im.tile_cursor, b.keys, cap, im.hdr);
+    else
+        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, g.rec,
+                           im.tile_cursor, b.keys, cap, im.hdr);
+    if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles), dim3(256), 0, s, im.ranges, b.keys, b.point_list, cap);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

@@ -1,0 +1,216 @@
+// Per-Gaussian projection for the tile rasterizer (forward), gfx950.
+//
+// Replaces preprocessCUDA<3> + computeCov3D + computeCov2D + computeColorFromSH
+// (reference forward.cu:20-256, auxiliary.h:41-164).  THIS FILE IS COMPILED WITH
+// -ffp-contract=off: radii, tile rectangles and the depth sort keys must be
+// bit-identical to an IEEE evaluation of the reference's expressions in source
+// order (fp64 ndc2Pix, truncating casts, un-normalised quaternion), and they are.
+#include "mom_common.h"
+
+namespace {
+
+struct M3 {  // column-major 3x3, m[c][r]; products summed left to right like glm (type_mat3x3.inl:486-519)
+    float m[3][3];
+};
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B)
+{
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+    return R;
+}
+__device__ __forceinline__ M3 transpose(const M3& A)
+{
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            R.m[c][r] = A.m[r][c];
+    return R;
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+__constant__ float kSH_C0 = 0.28209479177387814f;
+__constant__ float kSH_C1 = 0.4886025119029199f;
+__constant__ float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                                0.5462742152960396f};
+__constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+struct PreArgs {
+    int P, D, M, W, H, gx, gy;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *view, *proj, *cam;  // device pointers, [16] [16] [3]
+    float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
+};
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __restrict__ radii, float4* __restrict__ rec,
+                                                            float* __restrict__ cov3Ds, uchar4* __restrict__ clamped)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    const float* __restrict__ view = a.view;
+    const float* __restrict__ proj = a.proj;
+    const float* __restrict__ cam = a.cam;
+
+    int radius = 0;
+    uint32_t tiles = 0;
+    float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
+    uchar4 cl = {0, 0, 0, 0};
+
+    const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
+    // near cull: keep iff p_view.z > 0.2
+    const float vx = view[0] * px + view[4] * py + view[8] * pz + view[12];
+    const float vy = view[1] * px + view[5] * py + view[9] * pz + view[13];
+    const float vz = view[2] * px + view[6] * py + view[10] * pz + view[14];
+    do {
+        if (vz <= 0.2f) break;
+        const float hx = proj[0] * px + proj[4] * py + proj[8] * pz + proj[12];
+        const float hy = proj[1] * px + proj[5] * py + proj[9] * pz + proj[13];
+        const float hw = proj[3] * px + proj[7] * py + proj[11] * pz + proj[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float projx = hx * p_w, projy = hy * p_w;
+
+        float c3[6];
+        if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * idx + i];
+        } else {
+            const float mod = a.scale_modifier;
+            M3 S = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
+            S.m[0][0] = mod * a.scales[3 * idx];
+            S.m[1][1] = mod * a.scales[3 * idx + 1];
+            S.m[2][2] = mod * a.scales[3 * idx + 2];
+            const float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
+                        z = a.rotations[4 * idx + 3];
+            M3 Rm = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                      {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                      {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
+            M3 Mm = mul(S, Rm);
+            M3 Sg = mul(transpose(Mm), Mm);
+            c3[0] = Sg.m[0][0]; c3[1] = Sg.m[0][1]; c3[2] = Sg.m[0][2];
+            c3[3] = Sg.m[1][1]; c3[4] = Sg.m[1][2]; c3[5] = Sg.m[2][2];
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov3Ds[6 * idx + i] = c3[i];
+        }
+
+        // EWA 2D covariance
+        float tx = vx, ty = vy;
+        const float tz = vz;
+        const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+        const float txtz = tx / tz, tytz = ty / tz;
+        tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        M3 J = {{{a.focal_x / tz, 0.0f, -(a.focal_x * tx) / (tz * tz)},
+                 {0.0f, a.focal_y / tz, -(a.focal_y * ty) / (tz * tz)},
+                 {0.f, 0.f, 0.f}}};
+        M3 Wm = {{{view[0], view[4], view[8]}, {view[1], view[5], view[9]}, {view[2], view[6], view[10]}}};
+        M3 T = mul(Wm, J);
+        M3 Vrk = {{{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}}};
+        M3 cov = mul(mul(transpose(T), transpose(Vrk)), T);
+        const float cxx = cov.m[0][0] + 0.3f, cxy = cov.m[0][1], cyy = cov.m[1][1] + 0.3f;
+
+        const float det = cxx * cyy - cxy * cxy;
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float conx = cyy * det_inv, cony = -cxy * det_inv, conz = cxx * det_inv;
+
+        const float mid = 0.5f * (cxx + cyy);
+        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        const float pix = ndc2pix(projx, a.W), piy = ndc2pix(projy, a.H);
+        int x0, y0, x1, y1;
+        mom_get_rect(pix, piy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+        const uint32_t cnt = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
+        if (cnt == 0) break;
+
+        float cr, cg, cb;
+        if (a.colors_precomp == nullptr) {
+            float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            dx = dx / len; dy = dy / len; dz = dz / len;
+            const float* sh = a.shs + (size_t)idx * a.M * 3;
+            float res[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float v = kSH_C0 * sh[c];
+                if (a.D > 0) {
+                    const float x = dx, y = dy, z = dz;
+                    v = v - kSH_C1 * y * sh[3 + c] + kSH_C1 * z * sh[6 + c] - kSH_C1 * x * sh[9 + c];
+                    if (a.D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        v = v + kSH_C2[0] * xy * sh[12 + c] + kSH_C2[1] * yz * sh[15 + c] +
+                            kSH_C2[2] * (2.0f * zz - xx - yy) * sh[18 + c] + kSH_C2[3] * xz * sh[21 + c] +
+                            kSH_C2[4] * (xx - yy) * sh[24 + c];
+                        if (a.D > 2) {
+                            v = v + kSH_C3[0] * y * (3.0f * xx - yy) * sh[27 + c] + kSH_C3[1] * xy * z * sh[30 + c] +
+                                kSH_C3[2] * y * (4.0f * zz - xx - yy) * sh[33 + c] +
+                                kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + c] +
+                                kSH_C3[4] * x * (4.0f * zz - xx - yy) * sh[39 + c] + kSH_C3[5] * z * (xx - yy) * sh[42 + c] +
+                                kSH_C3[6] * x * (xx - 3.0f * yy) * sh[45 + c];
+                        }
+                    }
+                }
+                v += 0.5f;
+                res[c] = v;
+            }
+            cl.x = res[0] < 0; cl.y = res[1] < 0; cl.z = res[2] < 0;
+            cr = fmaxf(res[0], 0.0f); cg = fmaxf(res[1], 0.0f); cb = fmaxf(res[2], 0.0f);
+        } else {
+            cr = a.colors_precomp[3 * idx]; cg = a.colors_precomp[3 * idx + 1]; cb = a.colors_precomp[3 * idx + 2];
+        }
+        radius = (int)my_radius;
+        tiles = cnt;
+        r0 = make_float4(pix, piy, vz, __uint_as_float(tiles));
+        r1 = make_float4(conx, cony, conz, a.opacities[idx]);
+        r2 = make_float4(cr, cg, cb, __int_as_float(radius));
+    } while (0);
+
+    radii[idx] = radius;
+    rec[3 * (size_t)idx + 0] = r0;
+    rec[3 * (size_t)idx + 1] = r1;
+    rec[3 * (size_t)idx + 2] = r2;
+    clamped[idx] = cl;
+}
+
+__global__ void mark_visible_kernel(int P, const float* __restrict__ means, const float* __restrict__ view,
+                                    uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float vz = view[2] * means[3 * idx] + view[6] * means[3 * idx + 1] + view[10] * means[3 * idx + 2] + view[14];
+    present[idx] = vz <= 0.2f ? 0 : 1;
+}
+
+}  // namespace
+
+// host launcher (called from raster_api.hip)
+int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, hipStream_t s)
+{
+    PreArgs p;
+    p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
+    p.gx = (a->W + MOM_TILE - 1) / MOM_TILE;
+    p.gy = (a->H + MOM_TILE - 1) / MOM_TILE;
+    p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
+    p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
+    p.scale_modifier = a->scale_modifier; p.tan_fovx = a->tan_fovx; p.tan_fovy = a->tan_fovy;
+    // rasterizer_impl.cu:223-224
+    p.focal_y = a->H / (2.0f * a->tan_fovy);
+    p.focal_x = a->W / (2.0f * a->tan_fovx);
+    p.view = a->viewmatrix; p.proj = a->projmatrix; p.cam = a->campos;
+    const int blocks = (a->P + 255) / 256;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, s, p, radii, g.rec, g.cov3D, g.clamped);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+int mom_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

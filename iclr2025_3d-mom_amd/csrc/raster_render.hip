@@ -1,0 +1,275 @@
+// Tile compositing, forward and backward, gfx950.
+//
+// Replaces renderCUDA<3> forward (reference forward.cu:261-379) and backward
+// (backward.cu:415-590).  One 256-thread workgroup (4 wave64) per 16x16 tile,
+// one pixel per lane; a wave owns a 16x4 pixel strip.  Splat records (48 B:
+// xy+depth | conic+opacity | rgb) are gathered once per workgroup into LDS in
+// chunks of 256 and then read back as LDS broadcasts.
+//
+// Backward: instead of the reference's 10 global float atomics per (pixel,
+// splat) pair, each wave reduces its 64 pixels' contributions in registers
+// (DPP row operations) and issues ONE 40-byte atomic instruction per (wave,
+// splat) into the per-Gaussian accumulator record gacc[P][12].
+#include "mom_common.h"
+
+namespace {
+
+__device__ __forceinline__ int remap_tile(int b, int nt)
+{
+    // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous band of tiles so
+    // that neighbouring tiles (which share splats) share an L2.  Bijective for any nt.  Speed only.
+    const int xcd = b & 7, slot = b >> 3, q = nt >> 3, r = nt & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int o = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+    return v + __int_as_float(o);
+}
+// Sum over the 64 lanes; the total is returned in every lane (via v_readlane of lane 63).
+__device__ __forceinline__ float wave_sum(float v)
+{
+#if MOM_USE_DPP
+    v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x124, 0xF>(v);  // row_ror:4
+    v = dpp_add<0x128, 0xF>(v);  // row_ror:8   -> every lane holds its 16-lane row sum
+    v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> row 3 holds the wave sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+#else
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+#endif
+}
+
+__global__ void __launch_bounds__(256)
+render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt,
+                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
+                  uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
+                  uint32_t capacity)
+{
+    __shared__ float4 s_rec[256 * 3];
+    const int tile = remap_tile(blockIdx.x, nt);
+    const int tx = tile % gx, ty = tile / gx;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    bool done = !inside;
+
+    uint2 range = ranges[tile];
+    if (range.y > capacity) range.y = capacity;
+    if (range.x > range.y) range.x = range.y;
+    int toDo = (int)(range.y - range.x);
+    const int rounds = (toDo + 255) / 256;
+
+    float T = 1.0f;
+    uint32_t contributor = 0, last_contributor = 0;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+
+    for (int i = 0; i < rounds; i++, toDo -= 256) {
+        if (__syncthreads_count(done) == 256) break;
+        const int progress = i * 256 + threadIdx.x;
+        if (range.x + progress < range.y) {
+            const size_t id = point_list[range.x + progress];
+            s_rec[threadIdx.x * 3 + 0] = rec[3 * id + 0];
+            s_rec[threadIdx.x * 3 + 1] = rec[3 * id + 1];
+            s_rec[threadIdx.x * 3 + 2] = rec[3 * id + 2];
+        }
+        __syncthreads();
+        const int nb = min(256, toDo);
+        for (int j = 0; !done && j < nb; j++) {
+            contributor++;
+            const float4 r0 = s_rec[j * 3 + 0];
+            const float4 r1 = s_rec[j * 3 + 1];
+            const float dx = r0.x - pxf, dy = r0.y - pyf;
+            const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, r1.w * mom_exp(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1.f - alpha);
+            if (test_T < 0.0001f) {
+                done = true;
+                continue;
+            }
+            const float4 r2 = s_rec[j * 3 + 2];
+            const float w = alpha * T;
+            C0 += r2.x * w;
+            C1 += r2.y * w;
+            C2 += r2.z * w;
+            D += r0.z * w;
+            T = test_T;
+            last_contributor = contributor;
+        }
+    }
+    if (inside) {
+        const int pix = py * W + px;
+        final_T[pix] = T;
+        n_contrib[pix] = last_contributor;
+        const size_t HW = (size_t)H * W;
+        out_color[pix] = C0 + T * bg[0];
+        out_color[HW + pix] = C1 + T * bg[1];
+        out_color[2 * HW + pix] = C2 + T * bg[2];
+        out_depth[pix] = D;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt,
+                  const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
+                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
+                  const float* __restrict__ dL_dpixel_depths, float* __restrict__ gacc, uint32_t capacity)
+{
+    __shared__ float4 s_rec[256 * 3];
+    __shared__ uint32_t s_id[256];
+    const int tile = remap_tile(blockIdx.x, nt);
+    const int tx = tile % gx, ty = tile / gx;
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const int lane = threadIdx.x & 63;
+
+    uint2 range = ranges[tile];
+    if (range.y > capacity) range.y = capacity;
+    if (range.x > range.y) range.x = range.y;
+    int toDo = (int)(range.y - range.x);
+    const int rounds = (toDo + 255) / 256;
+
+    const int pix = inside ? py * W + px : 0;
+    const size_t HW = (size_t)H * W;
+    const float T_final = inside ? final_Ts[pix] : 0.f;
+    float T = T_final;
+    uint32_t contributor = (uint32_t)toDo;
+    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
+
+    float accum0 = 0.f, accum1 = 0.f, accum2 = 0.f, accum_d = 0.f;
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dpd = 0.f;
+    if (inside) {
+        dp0 = dL_dpixels[pix];
+        dp1 = dL_dpixels[HW + pix];
+        dp2 = dL_dpixels[2 * HW + pix];
+        dpd = dL_dpixel_depths ? dL_dpixel_depths[pix] : 0.f;
+    }
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+
+    for (int i = 0; i < rounds; i++, toDo -= 256) {
+        __syncthreads();
+        const int progress = i * 256 + threadIdx.x;
+        if (range.x + progress < range.y) {
+            const uint32_t id = point_list[range.y - progress - 1];
+            s_id[threadIdx.x] = id;
+            s_rec[threadIdx.x * 3 + 0] = rec[3 * (size_t)id + 0];
+            s_rec[threadIdx.x * 3 + 1] = rec[3 * (size_t)id + 1];
+            s_rec[threadIdx.x * 3 + 2] = rec[3 * (size_t)id + 2];
+        }
+        __syncthreads();
+        const int nb = min(256, toDo);
+        for (int j = 0; j < nb; j++) {
+            contributor--;
+            const float4 r0 = s_rec[j * 3 + 0];
+            const float4 r1 = s_rec[j * 3 + 1];
+            const float dx = r0.x - pxf, dy = r0.y - pyf;
+            const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+            const float G = mom_exp(power);
+            const float alpha = fminf(0.99f, r1.w * G);
+            const bool valid = inside && ((int)contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (!__any(valid)) continue;  // wave-uniform skip
+
+            float g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f,
+                  g_d = 0.f;
+            if (valid) {
+                const float4 r2 = s_rec[j * 3 + 2];
+                T = T / (1.f - alpha);
+                const float w = alpha * T;
+                float dL_dalpha = 0.f;
+                accum0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
+                lc0 = r2.x;
+                dL_dalpha += (r2.x - accum0) * dp0;
+                accum1 = last_alpha * lc1 + (1.f - last_alpha) * accum1;
+                lc1 = r2.y;
+                dL_dalpha += (r2.y - accum1) * dp1;
+                accum2 = last_alpha * lc2 + (1.f - last_alpha) * accum2;
+                lc2 = r2.z;
+                dL_dalpha += (r2.z - accum2) * dp2;
+                g_c0 = w * dp0;
+                g_c1 = w * dp1;
+                g_c2 = w * dp2;
+                accum_d = last_alpha * last_depth + (1.f - last_alpha) * accum_d;
+                last_depth = r0.z;
+                dL_dalpha += (r0.z - accum_d) * dpd;
+                g_d = w * dpd;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                // no derivative for the 0.99 cap, exactly as the reference (backward.cu:571)
+                const float dL_dG = r1.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
+                const float dG_ddely = -gdy * r1.z - gdx * r1.y;
+                g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                g_my = dL_dG * dG_ddely * ddely_dy;
+                g_cx = -0.5f * gdx * dx * dL_dG;
+                g_cy = -0.5f * gdx * dy * dL_dG;
+                g_cw = -0.5f * gdy * dy * dL_dG;
+                g_op = G * dL_dalpha;
+            }
+            const float s0 = wave_sum(g_mx), s1 = wave_sum(g_my), s2 = wave_sum(g_cx), s3 = wave_sum(g_cy), s4 = wave_sum(g_cw),
+                        s5 = wave_sum(g_op), s6 = wave_sum(g_c0), s7 = wave_sum(g_c1), s8 = wave_sum(g_c2), s9 = wave_sum(g_d);
+            float v = s0;
+            v = lane == 1 ? s1 : v;
+            v = lane == 2 ? s2 : v;
+            v = lane == 3 ? s3 : v;
+            v = lane == 4 ? s4 : v;
+            v = lane == 5 ? s5 : v;
+            v = lane == 6 ? s6 : v;
+            v = lane == 7 ? s7 : v;
+            v = lane == 8 ? s8 : v;
+            v = lane == 9 ? s9 : v;
+            if (lane < 10) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
+        }
+    }
+}
+
+}  // namespace
+
+int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
+                          float* out_color, float* out_depth, hipStream_t s)
+{
+    const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
+    const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, gx * gy,
+                       g.rec, a->background, im.final_T, im.n_contrib, out_color, out_depth, cap);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
+                          const float* dL_dpix, const float* dL_ddepth, hipStream_t s)
+{
+    const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
+    const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+    if (hipMemsetAsync(g.gacc, 0, (size_t)a->P * 48, s) != hipSuccess) return MOM_ELAUNCH;
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, gx * gy,
+                       g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+// wave_sum self test: out[w] = sum of in[64*w .. 64*w+63]
+namespace {
+__global__ void wave_sum_test_kernel(const float* in, float* out)
+{
+    const float t = wave_sum(in[blockIdx.x * 64 + threadIdx.x]);
+    if (threadIdx.x == 17) out[blockIdx.x] = t;
+}
+}  // namespace
+extern "C" int mom_selftest_wave_sum(const float* in, float* out, int waves, mom_stream_t s)
+{
+    hipLaunchKernelGGL(wave_sum_test_kernel, dim3(waves), dim3(64), 0, (hipStream_t)s, in, out);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

@@ -1,0 +1,174 @@
+"""Stand-in for the reference's pybind module `diff_gaussian_rasterization._C`
+(submodules/depth-diff-gaussian-rasterization/ext.cpp:14-18, rasterize_points.h:18-68):
+same three functions, same argument order, same return tuples -- backed by libmom4d.so.
+
+Differences a caller can observe, all documented in INTEGRATION.md:
+* the byte buffers' internal layout is private to libmom4d;
+* `num_rendered` is the instance CAPACITY of the binning buffer; it equals the true
+  instance count in the default "exact" mode (one host sync per forward, like the
+  reference's cudaMemcpy at rasterizer_impl.cu:282) and is an upper bound in "async" mode.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _native as N
+
+_state = {"mode": "exact", "cap_hint": 0, "last_R": None, "status": None}
+
+
+def set_sync_mode(mode: str, capacity_hint: int = 0) -> None:
+    """'exact': read the instance count back (blocking) and size the binning buffer exactly.
+    'async': never block; size the buffer from `capacity_hint` / 1.5x the last observed count and raise at the
+    next call if the previous one overflowed."""
+    assert mode in ("exact", "async")
+    _state["mode"] = mode
+    if capacity_hint:
+        _state["cap_hint"] = int(capacity_hint)
+
+
+def last_num_rendered():
+    """Instance count of the most recent forward (async mode: synchronises nothing, may lag by one call)."""
+    r = _state["last_R"]
+    return None if r is None else int(r[0])
+
+
+def _args(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+          tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug):
+    a = N.MomRasterArgs()
+    a.P = means3D.shape[0]
+    a.D = int(degree)
+    a.M = int(sh.shape[1]) if sh.numel() != 0 else 0
+    a.W, a.H = int(W), int(H)
+    keep = []
+
+    def dev(t):
+        if t is None or t.numel() == 0:
+            return None
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.contiguous().float()
+        keep.append(t)
+        return t.data_ptr()
+
+    a.background = dev(bg)
+    a.means3D = dev(means3D)
+    a.shs = dev(sh)
+    a.colors_precomp = dev(colors)
+    a.opacities = dev(opacity)
+    a.scales = dev(scales)
+    a.rotations = dev(rotations)
+    a.cov3D_precomp = dev(cov3D_precomp)
+    a.viewmatrix = dev(viewmatrix)
+    a.projmatrix = dev(projmatrix)
+    a.campos = dev(campos)
+    a.scale_modifier = float(scale_modifier)
+    a.tan_fovx, a.tan_fovy = float(tan_fovx), float(tan_fovy)
+    a.prefiltered, a.debug = int(bool(prefiltered)), int(bool(debug))
+    return a, keep
+
+
+def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+                        debug):
+    """RasterizeGaussiansCUDA (rasterize_points.cu:35-117)."""
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:57-59
+    if not means3D.is_cuda:
+        raise RuntimeError("libmom4d has no CPU path: means3D must live on the GPU")
+    lib = N.lib()
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    out_color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    geom = torch.empty((lib.mom_raster_geom_bytes(P),), dtype=torch.uint8, device=dev)
+    img = torch.empty((lib.mom_raster_image_bytes(W, H),), dtype=torch.uint8, device=dev)
+    if P == 0:  # rasterize_points.cu:82
+        out_color.zero_()
+        out_depth.zero_()
+        return 0, out_color, out_depth, radii, geom, torch.empty((0,), dtype=torch.uint8, device=dev), img
+    a, keep = _args(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                    projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug)
+    stream = N.current_stream()
+    nr_dev = torch.empty((2,), dtype=torch.int32, device=dev)
+    nr_host = torch.empty((1,), dtype=torch.int32).pin_memory()
+    N.check(lib.mom_raster_forward_geometry(C.byref(a), geom.data_ptr(), img.data_ptr(), radii.data_ptr(),
+                                            nr_dev.data_ptr(), nr_host.data_ptr(), stream), "mom_raster_forward_geometry")
+    if _state["mode"] == "exact":
+        torch.cuda.current_stream().synchronize()
+        cap = int(nr_host[0])
+    else:
+        prev = _state["last_R"]
+        if _state["status"] is not None and prev is not None:
+            # the previous call has long finished (the training loop syncs on loss.item()); check it now
+            if int(_state["status"][0]) & 1:
+                raise RuntimeError("libmom4d: binning capacity overflowed in the previous async forward "
+                                   f"(count {int(prev[0])}); raise capacity_hint or use exact mode")
+            _state["cap_hint"] = max(_state["cap_hint"], int(int(prev[0]) * 1.5) + 4096)
+        cap = max(_state["cap_hint"], 4096)
+    _state["last_R"] = nr_host
+    binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, cap),), dtype=torch.uint8, device=dev)
+    status_host = None
+    N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
+                                          out_color.data_ptr(), out_depth.data_ptr(), nr_dev[1:].data_ptr(), stream),
+            "mom_raster_forward_render")
+    if _state["mode"] == "async":
+        status_host = torch.empty((1,), dtype=torch.int32).pin_memory()
+        status_host.copy_(nr_dev[1:], non_blocking=True)
+    _state["status"] = status_host
+    del keep
+    return cap, out_color, out_depth, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                 projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA (rasterize_points.cu:119-202)."""
+    lib = N.lib()
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = dL_dout_color.shape[1], dL_dout_color.shape[2]
+    M = int(sh.shape[1]) if sh.numel() != 0 else 0
+    opt = dict(dtype=torch.float32, device=dev)
+    g2d = torch.empty((P, 3), **opt)
+    gcol = torch.empty((P, 3), **opt)
+    gop = torch.empty((P, 1), **opt)
+    g3d = torch.empty((P, 3), **opt)
+    gcov = torch.empty((P, 6), **opt)
+    have_sr = scales.numel() != 0
+    gsh = torch.empty((P, M, 3), **opt) if (M and colors.numel() == 0) else torch.zeros((P, M, 3), **opt)
+    gsc = torch.empty((P, 3), **opt) if have_sr else torch.zeros((P, 3), **opt)
+    grot = torch.empty((P, 4), **opt) if have_sr else torch.zeros((P, 4), **opt)
+    if P == 0:
+        return g2d, gcol, gop, g3d, gcov, gsh, gsc, grot
+    # opacity is not an input of the reference's backward; the forward kept it inside the geometry records
+    a, keep = _args(bg, means3D, colors, means3D.new_ones((1,)), scales, rotations, scale_modifier, cov3D_precomp,
+                    viewmatrix, projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, False, debug)
+    g = N.MomRasterGrads()
+    g.dL_dmeans2D, g.dL_dcolors, g.dL_dopacity = g2d.data_ptr(), gcol.data_ptr(), gop.data_ptr()
+    g.dL_dmeans3D, g.dL_dcov3D = g3d.data_ptr(), gcov.data_ptr()
+    g.dL_dsh = gsh.data_ptr() if gsh.numel() else None
+    g.dL_dscales, g.dL_drotations = gsc.data_ptr(), grot.data_ptr()
+    dcol = dL_dout_color.contiguous().float()
+    ddep = None if dL_dout_depth is None else dL_dout_depth.contiguous().float()
+    N.check(lib.mom_raster_backward(C.byref(a), radii.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(), int(R),
+                                    imageBuffer.data_ptr(), dcol.data_ptr(), None if ddep is None else ddep.data_ptr(),
+                                    C.byref(g), N.current_stream()), "mom_raster_backward")
+    del keep
+    return g2d, gcol, gop, g3d, gcov, gsh, gsc, grot
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible (rasterize_points.cu:204-223)."""
+    lib = N.lib()
+    P = means3D.shape[0]
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P:
+        m = means3D.contiguous().float()
+        v = viewmatrix.contiguous().float()
+        p = projmatrix.contiguous().float()
+        N.check(lib.mom_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), present.data_ptr(), N.current_stream()),
+                "mom_mark_visible")
+    return present

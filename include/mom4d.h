@@ -1,0 +1,155 @@
+/*
+ * mom4d.h -- C ABI of libmom4d.so, the MI355X (gfx950) hot path of the 4D Gaussian
+ * Splatting train/render loop of cvsp-lab/ICLR2025_3D-MOM.
+ *
+ * Every entry point takes plain device pointers and sizes plus a hipStream_t
+ * (passed as void*), is stream-ordered on that stream, never allocates, never
+ * synchronises the host unless its comment says so, and returns 0 on success
+ * or a negative MOM_E* code (it never throws across the ABI).
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   CudaRasterizer::Rasterizer::forward / backward / markVisible
+ *       submodules/depth-diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:19-87
+ *       (implementation rasterizer_impl.cu:141-153,198-444)
+ *   RasterizeGaussiansCUDA / RasterizeGaussiansBackwardCUDA / markVisible (torch glue)
+ *       submodules/depth-diff-gaussian-rasterization/rasterize_points.h:18-68
+ *   distCUDA2 / SimpleKNN::knn
+ *       submodules/simple-knn/spatial.h, simple_knn.h  (simple_knn.cu:185-221)
+ * and, one level up (torch ops the reference issues from Python):
+ *   deform_network.forward           scene/deformation.py:190-223 + scene/hexplane.py:160-183
+ *   torch.optim.Adam.step            scene/gaussian_model.py:209, train_4DGS.py:295-297
+ *   l1_loss / ssim                   utils/loss_utils.py:23-24,52-92
+ *   compute_regulation               scene/gaussian_model.py:730-769
+ *   boolean-mask row compaction      scene/gaussian_model.py:424-459
+ */
+#ifndef MOM4D_H_INCLUDED
+#define MOM4D_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOM_OK 0
+#define MOM_EINVAL (-1)   /* bad argument (shape, null pointer, unsupported channel count) */
+#define MOM_ELAUNCH (-2)  /* a HIP launch / runtime call failed (hipGetLastError) */
+#define MOM_ECAPACITY (-3)/* scratch buffer too small */
+
+#define MOM_TILE 16       /* config.h:14-16 BLOCK_X == BLOCK_Y == 16 */
+
+typedef void* mom_stream_t; /* hipStream_t */
+
+/* Arguments of one rasterizer call; the field meanings are those of
+ * CudaRasterizer::Rasterizer::forward (rasterizer.h:29-55).  Null pointers stand
+ * for "absent" exactly as empty tensors do in the reference (forward.cu:205,241).
+ * Matrices are the transposed (column-major) 4x4s the reference passes. */
+typedef struct MomRasterArgs {
+    int P;                 /* number of Gaussians */
+    int D;                 /* active SH degree (0..3) */
+    int M;                 /* SH coefficients per Gaussian in `shs` (0 if absent) */
+    int W, H;              /* image size in pixels */
+    const float* background;     /* [3] */
+    const float* means3D;        /* [P,3] */
+    const float* shs;            /* [P,M,3] or null */
+    const float* colors_precomp; /* [P,3] or null */
+    const float* opacities;      /* [P] (already activated) */
+    const float* scales;         /* [P,3] or null */
+    const float* rotations;      /* [P,4] (r,x,y,z), used as given, or null */
+    const float* cov3D_precomp;  /* [P,6] or null */
+    const float* viewmatrix;     /* [16] */
+    const float* projmatrix;     /* [16] */
+    const float* campos;         /* [3] */
+    float scale_modifier;
+    float tan_fovx, tan_fovy;
+    int prefiltered;
+    int debug;             /* !=0: hipStreamSynchronize + error check after every kernel (CHECK_CUDA, auxiliary.h:166-173) */
+} MomRasterArgs;
+
+/* Scratch sizing (bytes).  The three buffers play the roles of the reference's
+ * geomBuffer / binningBuffer / imgBuffer (rasterize_points.cu:72-78) and are
+ * handed back to the backward pass unchanged.  Their internal layout is
+ * private; mom_raster_layout exposes it for tests. */
+size_t mom_raster_geom_bytes(int P);
+size_t mom_raster_image_bytes(int W, int H);
+size_t mom_raster_binning_bytes(int P, int W, int H, size_t capacity /* max instances */);
+
+/* Forward, stage 1: per-Gaussian projection (preprocessCUDA, forward.cu:156-256),
+ * per-tile instance histogram and its scan.  Writes radii[P] (int32), the tile
+ * ranges and *num_rendered_dev (uint32, device).  If num_rendered_host is not
+ * null it must be host memory (pinned recommended) and receives the same value by
+ * an async copy on `stream` (the caller synchronises if it wants to read it; this
+ * replaces the blocking cudaMemcpy at rasterizer_impl.cu:282). */
+int mom_raster_forward_geometry(const MomRasterArgs* a, void* geom, void* image, int* radii,
+                                uint32_t* num_rendered_dev, uint32_t* num_rendered_host, mom_stream_t stream);
+
+/* Forward, stage 2: scatter instances into their tiles, per-tile depth sort
+ * (result identical to the reference's global sort of (tile<<32|depth) keys:
+ * rasterizer_impl.cu:70-111,301-318) and alpha compositing (renderCUDA,
+ * forward.cu:261-379).  `capacity` is the instance capacity the binning buffer
+ * was sized for; if the true count exceeds it nothing beyond capacity is written,
+ * bit 0 of *status_dev is set and the image is incomplete.
+ * out_color [3,H,W], out_depth [1,H,W]. */
+int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning, size_t capacity, void* image,
+                              float* out_color, float* out_depth, uint32_t* status_dev, mom_stream_t stream);
+
+/* Gradients of one backward call (RasterizeGaussiansBackwardCUDA,
+ * rasterize_points.cu:154-163,202).  All are fully written by the call (zeros
+ * for Gaussians with radius 0), so they need no prior memset. */
+typedef struct MomRasterGrads {
+    float* dL_dmeans2D;   /* [P,3] (x,y in NDC-scaled pixels; z = 0) */
+    float* dL_dcolors;    /* [P,3] */
+    float* dL_dopacity;   /* [P,1] */
+    float* dL_dmeans3D;   /* [P,3] */
+    float* dL_dcov3D;     /* [P,6] */
+    float* dL_dsh;        /* [P,M,3] or null when M == 0 */
+    float* dL_dscales;    /* [P,3] or null when scales absent */
+    float* dL_drotations; /* [P,4] or null when rotations absent */
+} MomRasterGrads;
+
+/* Backward (Rasterizer::backward, rasterizer_impl.cu:343-444): render backward
+ * (backward.cu:415-590), cov2D backward (:144-274), preprocess backward (:346-412).
+ * dL_dout_color [3,H,W]; dL_dout_depth [1,H,W] or null (treated as zeros).
+ * `capacity` is the value given to mom_raster_forward_render.  dL_dscales /
+ * dL_drotations are written only when scales/rotations are present. */
+int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, void* binning, size_t capacity,
+                        void* image, const float* dL_dout_color, const float* dL_dout_depth,
+                        const MomRasterGrads* g, mom_stream_t stream);
+
+/* checkFrustum (rasterizer_impl.cu:54-66): present[i] = p_view.z > 0.2 */
+int mom_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, mom_stream_t stream);
+
+/* Layout of the private scratch buffers, for tests: byte offsets of the named
+ * arrays.  geom: rec[P][12] float = {x, y, depth, tiles_touched(bits) | conic.x,
+ * conic.y, conic.z, opacity | r, g, b, radius(bits)}; cov3D[P][6]; clamped[P][4] u8.
+ * image: ranges[tiles][2] u32, n_contrib[H*W] u32, final_T[H*W] f32, tile_counts[tiles] u32
+ * (the per-tile histogram, bucket cursors and a small header also live here so that the
+ * binning buffer can be sized AFTER the instance count is known).
+ * binning: keys[capacity] u64 (depth_bits<<32|idx, bucketed by tile),
+ * point_list[capacity] u32. */
+typedef struct MomRasterLayout {
+    size_t geom_rec, geom_cov3D, geom_clamped, geom_gacc;
+    size_t img_ranges, img_n_contrib, img_final_T, img_tile_counts;
+    size_t bin_keys, bin_point_list;
+} MomRasterLayout;
+int mom_raster_layout(int P, int W, int H, size_t capacity, MomRasterLayout* out);
+
+/* distCUDA2 (simple-knn/spatial.cu:15-25): mean squared distance to the 3 nearest
+ * neighbours.  scratch must hold mom_knn_scratch_bytes(P).  Synchronises the
+ * stream once internally (the reference does two blocking copies, simple_knn.cu:197,200). */
+size_t mom_knn_scratch_bytes(int P);
+int mom_knn_mean_dist2(int P, const float* points /* [P,3] */, float* mean_dist2 /* [P] */, void* scratch,
+                       mom_stream_t stream);
+
+const char* mom_version(void);
+
+/* Self test of the wave64 DPP reduction used by the render backward:
+ * out[w] = sum(in[64w .. 64w+63]). */
+int mom_selftest_wave_sum(const float* in, float* out, int waves, mom_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOM4D_H_INCLUDED */

@@ -1,0 +1,208 @@
+"""GPU parity: libmom4d (HIP, through the reference-shaped `_C` boundary) vs the CPU oracle on identical
+Gaussians.  Bar (BASELINE.json north_star): integer tile/sort indices bit-exact; images within 1e-4 per-pixel L1."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from scenes import camera, random_gaussians
+
+pytestmark = pytest.mark.gpu
+
+IMG_L1_TOL = 1e-4      # mean per-pixel L1 (north_star)
+IMG_MAX_TOL = 2e-2     # a 1-ulp exp difference may flip one of the hard thresholds (1/255, T<1e-4) on a few pixels
+GRAD_REL_TOL = 2e-3    # float-atomic / reduction-order differences
+
+
+def _oracle(s, **kw):
+    args = dict(shs=s.get("shs"), sh_degree=3, scales=s["scales"], rotations=s["rotations"])
+    args.update(kw)
+    return ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], s["W"], s["H"],
+                      s["tanfovx"], s["tanfovy"], s["bg"], **args)
+
+
+def _cmp_forward(fw, st, P):
+    assert fw["R"] == st.num_rendered
+    np.testing.assert_array_equal(fw["radii"], st.radii)
+    vis = st.radii > 0
+    np.testing.assert_array_equal(fw["tiles_touched"], st.tiles_touched)
+    # depth keys, pixel centres and conics come out of a contraction-free fp32 pipeline: bit-exact
+    np.testing.assert_array_equal(fw["depths"][vis].view(np.uint32), st.depths[vis].view(np.uint32))
+    np.testing.assert_array_equal(fw["means2D"][vis].view(np.uint32), st.means2D[vis].view(np.uint32))
+    np.testing.assert_array_equal(fw["conic_opacity"][vis].view(np.uint32), st.conic_opacity[vis].view(np.uint32))
+    np.testing.assert_array_equal(fw["ranges"], st.ranges)
+    np.testing.assert_array_equal(fw["point_list"], st.point_list)      # the whole sort, bit for bit
+    np.testing.assert_array_equal(fw["clamped"][vis], st.clamped[vis])
+    np.testing.assert_allclose(fw["rgb"][vis], st.rgb[vis], rtol=1e-6, atol=1e-7)
+    dc = np.abs(fw["color"] - st.out_color)
+    assert dc.mean() <= IMG_L1_TOL and dc.max() <= IMG_MAX_TOL, (dc.mean(), dc.max())
+    dd = np.abs(fw["depth"] - st.out_depth)
+    assert dd.mean() <= IMG_L1_TOL * max(1.0, float(st.depths.max())), dd.mean()
+    same = (fw["n_contrib"] == st.n_contrib).mean()
+    assert same >= 0.999, same
+    assert np.abs(fw["final_T"] - st.final_T).mean() <= 1e-5
+
+
+def _relerr(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-20))
+
+
+def test_wave_sum_selftest():
+    from hip_helpers import N
+    x = torch.randn(64 * 37, device="cuda")
+    out = torch.zeros(37, device="cuda")
+    N.check(N.lib().mom_selftest_wave_sum(x.data_ptr(), out.data_ptr(), 37, N.current_stream()), "selftest")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), x.view(37, 64).double().sum(1).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed,P,W,H,kw", [
+    (0, 2000, 128, 96, {}),
+    (1, 5000, 256, 256, {}),                       # BASELINE configs[0] geometry: 5k Gaussians, 256x256
+    (2, 700, 100, 50, dict(scale=(-3.0, -0.5))),   # ragged image, large splats (wave-cooperative enumeration)
+    (3, 64, 33, 17, {}),
+    (4, 20000, 320, 180, dict(scale=(-5.0, -3.0))),
+])
+def test_forward_parity(seed, P, W, H, kw):
+    from hip_helpers import hip_forward
+    s = random_gaussians(P, seed=seed, W=W, H=H, **kw)
+    _cmp_forward(hip_forward(s), _oracle(s), P)
+
+
+def test_forward_parity_lower_sh_degree_and_scale_modifier():
+    from hip_helpers import hip_forward
+    s = random_gaussians(1500, seed=7, W=96, H=80)
+    for deg in (0, 1, 2):
+        fw = hip_forward(s, sh_degree=deg, scale_modifier=0.7)
+        st = _oracle(s, sh_degree=deg, scale_modifier=0.7)
+        _cmp_forward(fw, st, 1500)
+
+
+def test_forward_parity_precomputed_colors_and_cov3d():
+    from hip_helpers import hip_forward
+    s = random_gaussians(1200, seed=8, W=80, H=64)
+    rng = np.random.default_rng(0)
+    cols = rng.uniform(0, 1, (1200, 3)).astype(np.float32)
+    st0 = _oracle(s)
+    fw = hip_forward(s, colors_precomp=cols)
+    st = _oracle(s, shs=None, colors_precomp=cols)
+    _cmp_forward(fw, st, 1200)
+    fw = hip_forward(s, cov3D_precomp=st0.cov3D)
+    st = _oracle(s, scales=None, rotations=None, cov3D_precomp=st0.cov3D)
+    _cmp_forward(fw, st, 1200)
+
+
+def test_oversized_tile_bucket_uses_global_sort_path():
+    # > 8192 instances in one tile: exercises the global-memory bitonic path; equal depths exercise the idx tiebreak
+    from hip_helpers import hip_forward
+    P = 9000
+    s = random_gaussians(P, seed=9, W=32, H=32, scale=(-5.5, -4.5))
+    s["means3D"][:, 0] *= 0.05
+    s["means3D"][:, 1] *= 0.05
+    s["means3D"][100:, 2] = np.abs(s["means3D"][100:, 2]) + 0.5
+    s["means3D"][2000:2500, 2] = 3.0     # exact depth ties
+    s["opacities"][:] = 0.02
+    fw, st = hip_forward(s), _oracle(s)
+    assert (st.ranges[:, 1] - st.ranges[:, 0]).max() > 8192
+    _cmp_forward(fw, st, P)
+
+
+def test_empty_and_all_culled():
+    from hip_helpers import hip_forward
+    s = random_gaussians(10, seed=1, W=48, H=32)
+    s0 = {k: (v[:0] if isinstance(v, np.ndarray) and v.shape[:1] == (10,) else v) for k, v in s.items()}
+    fw = hip_forward(s0)
+    assert fw["R"] == 0 and (fw["color"] == 0).all() and (fw["depth"] == 0).all()
+    s["means3D"][:, 2] = -1.0
+    fw = hip_forward(s)
+    assert fw["R"] == 0 and (fw["radii"] == 0).all()
+    np.testing.assert_allclose(fw["color"], np.broadcast_to(s["bg"][:, None, None], (3, 32, 48)))
+
+
+@pytest.mark.parametrize("seed,P,W,H,kw", [
+    (10, 1500, 128, 96, {}),
+    (11, 400, 70, 45, dict(scale=(-3.0, -1.0))),
+    (12, 5000, 256, 256, dict(scale=(-5.0, -3.0))),
+])
+def test_backward_parity(seed, P, W, H, kw):
+    from hip_helpers import hip_forward, hip_backward
+    s = random_gaussians(P, seed=seed, W=W, H=H, **kw)
+    rng = np.random.default_rng(seed)
+    dcol = rng.normal(size=(3, H, W)).astype(np.float32)
+    ddep = (rng.normal(size=(1, H, W)) * 0.2).astype(np.float32)
+    fw = hip_forward(s)
+    st = _oracle(s)
+    g = hip_backward(fw, dcol, ddep)
+    go = ro.backward(st, dcol, ddep)
+    for name in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+                 "dL_drotations"):
+        a, b = g[name], go[name].reshape(g[name].shape)
+        assert _relerr(a, b) <= GRAD_REL_TOL, (name, _relerr(a, b))
+        inv = st.radii == 0
+        assert np.abs(a[inv]).max(initial=0.0) == 0.0, name
+
+
+def test_dropin_autograd_matches_oracle():
+    """Through GaussianRasterizer.forward + loss.backward(), the way gaussian_renderer.render() drives it."""
+    from hip_helpers import DGR, t
+    P, W, H = 800, 96, 64
+    s = random_gaussians(P, seed=21, W=W, H=H)
+    rs = DGR.GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"],
+                                           bg=t(s["bg"]), scale_modifier=1.0, viewmatrix=t(s["viewmatrix"]),
+                                           projmatrix=t(s["projmatrix"]), sh_degree=3, campos=t(s["campos"]),
+                                           prefiltered=False, debug=False)
+    rast = DGR.GaussianRasterizer(rs)
+    means3D = t(s["means3D"]).requires_grad_(True)
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    opac = t(s["opacities"]).requires_grad_(True)
+    shs = t(s["shs"]).requires_grad_(True)
+    scales = t(s["scales"]).requires_grad_(True)
+    rots = t(s["rotations"]).requires_grad_(True)
+    img, radii, depth = rast(means3D=means3D, means2D=means2D, shs=shs, opacities=opac, scales=scales, rotations=rots)
+    wgt = torch.linspace(0.5, 1.5, 3 * H * W, device="cuda").view(3, H, W)
+    (img * wgt).sum().backward()
+    st = _oracle(s)
+    go = ro.backward(st, wgt.cpu().numpy())
+    assert _relerr(means3D.grad.cpu().numpy(), go["dL_dmeans3D"]) <= GRAD_REL_TOL
+    assert _relerr(means2D.grad.cpu().numpy(), go["dL_dmeans2D"]) <= GRAD_REL_TOL
+    assert _relerr(opac.grad.cpu().numpy(), go["dL_dopacity"]) <= GRAD_REL_TOL
+    assert _relerr(shs.grad.cpu().numpy(), go["dL_dsh"]) <= GRAD_REL_TOL
+    assert _relerr(scales.grad.cpu().numpy(), go["dL_dscales"]) <= GRAD_REL_TOL
+    assert _relerr(rots.grad.cpu().numpy(), go["dL_drotations"]) <= GRAD_REL_TOL
+    np.testing.assert_array_equal(radii.cpu().numpy(), st.radii)
+    with pytest.raises(Exception):
+        rast(means3D=means3D, means2D=means2D, opacities=opac, scales=scales, rotations=rots)  # neither shs nor colours
+    vis = rast.markVisible(means3D.detach())
+    np.testing.assert_array_equal(vis.cpu().numpy(), s["means3D"][:, 2] > 0.2)
+
+
+def test_full_size_properties_config2():
+    """BASELINE configs[1] size (200k Gaussians, 960x540): size-independent properties instead of the oracle."""
+    from hip_helpers import hip_forward
+    P, W, H = 200_000, 960, 540
+    s = random_gaussians(P, seed=33, W=W, H=H, scale=(-6.0, -4.5))
+    fw = hip_forward(s)
+    R = fw["R"]
+    assert int(fw["tiles_touched"].sum()) == R == int(fw["tile_counts"].sum())
+    pl, rg = fw["point_list"], fw["ranges"]
+    dbits = fw["depths"].view(np.uint32)
+    pos = 0
+    for tile in range(rg.shape[0]):
+        a, b = rg[tile]
+        if a == b:
+            continue
+        assert a == pos
+        key = (dbits[pl[a:b]].astype(np.uint64) << np.uint64(32)) | pl[a:b].astype(np.uint64)
+        assert (np.diff(key.astype(np.int64)) > 0).all()      # strictly sorted by (depth bits, idx)
+        pos = b
+    assert pos == R
+    # weights + T == 1 with unit colours / zero background
+    s1 = dict(s, bg=np.zeros(3, np.float32))
+    fw1 = hip_forward(s1, colors_precomp=np.ones((P, 3), np.float32))
+    np.testing.assert_allclose(fw1["color"][0].reshape(-1) + fw1["final_T"], 1.0, atol=3e-5)
+    # idempotence: same inputs, same bits
+    fw2 = hip_forward(s)
+    np.testing.assert_array_equal(fw2["point_list"], pl)
+    np.testing.assert_array_equal(fw2["color"], fw["color"])
