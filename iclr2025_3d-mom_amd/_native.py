@@ -41,6 +41,22 @@ class MomRasterLayout(C.Structure):
                                           "bin_point_list")]
 
 
+class MomHexPlane(C.Structure):
+    _fields_ = [("levels", C.c_int), ("channels", C.c_int), ("res", (C.c_int * 4) * 4),
+                ("planes", (C.c_void_p * 6) * 4), ("grads", (C.c_void_p * 6) * 4), ("aabb", C.c_float * 6)]
+
+
+class MomAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_size_t), ("lr", C.c_float), ("bias_correction1", C.c_float),
+                ("bias_correction2_sqrt", C.c_float)]
+
+
+class MomRegPlane(C.Structure):
+    _fields_ = [("plane", C.c_void_p), ("grad", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("w_smooth", C.c_float),
+                ("w_l1", C.c_float), ("grad_scale", C.c_float)]
+
+
 def build(verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into lib/libmom4d.so (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
@@ -67,6 +83,14 @@ def _sig(lib):
     lib.mom_raster_backward.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, sz, vp, vp, vp, C.POINTER(MomRasterGrads), vp]
     lib.mom_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
+    lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp]
+    lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
+    lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_float, C.c_float, C.c_float, vp]
+    lib.mom_l1_loss.argtypes = [sz, vp, vp, vp, vp, vp]
+    lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
+    lib.mom_knn_scratch_bytes.restype = sz
+    lib.mom_knn_scratch_bytes.argtypes = [i32]
+    lib.mom_knn_mean_dist2.argtypes = [i32, vp, vp, vp, vp]
     for name in EXPORTS:
         getattr(lib, name)  # raises AttributeError if the library lacks a declared symbol
     return lib
@@ -76,7 +100,8 @@ def _sig(lib):
 EXPORTS = [
     "mom_version", "mom_raster_geom_bytes", "mom_raster_image_bytes", "mom_raster_binning_bytes", "mom_raster_layout",
     "mom_raster_forward_geometry", "mom_raster_forward_render", "mom_raster_backward", "mom_mark_visible",
-    "mom_selftest_wave_sum",
+    "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_adam_step", "mom_l1_loss",
+    "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
 ]
 
 

@@ -1,0 +1,231 @@
+// HexPlane feature field, forward and backward, gfx950.
+//
+// Replaces HexPlaneField.forward -> interpolate_ms_features -> 6 x F.grid_sample(bilinear,
+// align_corners=True, padding_mode='border') per level + product over planes + concat over
+// levels (reference scene/hexplane.py:19-46,73-106,160-183) and the 12 scatter-add backward
+// kernels autograd runs for them.
+//
+// Layout: every plane is stored CHANNEL-LAST, [H][W][32] floats, so one texel is one 128-byte
+// line.  32 lanes (half a wave64) own one (Gaussian, level): lane c owns channel c, so every
+// texel fetch of a half-wave is one coalesced 128-B line and every gradient scatter is one
+// 128-B row of float atomics (the shape that runs at the full atomic rate).  The six plane
+// samples and their product stay in registers; features leave as one 128-B row per half-wave.
+//
+// Arithmetic follows ATen's grid_sampler_2d (unnormalise with align_corners, clip to the
+// border, nw/ne/sw/se weights, accumulation order nw,ne,sw,se) so that results agree with the
+// reference's torch ops to rounding.
+#include "mom_common.h"
+
+namespace {
+
+struct PlaneSample {
+    int i00, i01, i10, i11;      // texel indices (row-major over [H][W]), -1 when out of bounds
+    float w00, w01, w10, w11;    // nw, ne, sw, se
+    float gx_mul, gy_mul;        // d(ix)/d(coord) incl. border-clip mask
+    float ix, iy;
+    int ixn, iyn;
+};
+
+__device__ __forceinline__ float unnorm_clip(float c, int size, float& gmul)
+{
+    // align_corners=True: ((c+1)/2)*(size-1); border: clip to [0, size-1] with zero gradient when clipped
+    float v = ((c + 1.f) / 2.f) * (float)(size - 1);
+    gmul = (float)(size - 1) / 2.f;
+    if (v <= 0.f) {
+        v = 0.f;
+        gmul = 0.f;
+    } else {
+        const float mx = (float)(size - 1);
+        if (v >= mx) {
+            v = mx;
+            gmul = 0.f;
+        }
+    }
+    return v;
+}
+
+__device__ __forceinline__ PlaneSample make_sample(float cx, float cy, int Wd, int Hd)
+{
+    PlaneSample s;
+    s.ix = unnorm_clip(cx, Wd, s.gx_mul);
+    s.iy = unnorm_clip(cy, Hd, s.gy_mul);
+    const float fx = floorf(s.ix), fy = floorf(s.iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    s.ixn = x0;
+    s.iyn = y0;
+    s.w00 = ((float)x1 - s.ix) * ((float)y1 - s.iy);
+    s.w01 = (s.ix - (float)x0) * ((float)y1 - s.iy);
+    s.w10 = ((float)x1 - s.ix) * (s.iy - (float)y0);
+    s.w11 = (s.ix - (float)x0) * (s.iy - (float)y0);
+    const bool x0in = x0 >= 0 && x0 < Wd, x1in = x1 >= 0 && x1 < Wd, y0in = y0 >= 0 && y0 < Hd, y1in = y1 >= 0 && y1 < Hd;
+    s.i00 = (x0in && y0in) ? y0 * Wd + x0 : -1;
+    s.i01 = (x1in && y0in) ? y0 * Wd + x1 : -1;
+    s.i10 = (x0in && y1in) ? y1 * Wd + x0 : -1;
+    s.i11 = (x1in && y1in) ? y1 * Wd + x1 : -1;
+    return s;
+}
+
+struct HexArgs {
+    int P, levels;
+    int res[4][4];
+    const float* planes[4][6];
+    float* grads[4][6];
+    float a0[3], a1[3];  // aabb rows exactly as the reference stores them (row 0 = xyz_max, row 1 = xyz_min)
+    float time;
+    const float* times;  // optional per-point timestamps [P]; null -> `time` for every point
+};
+
+__constant__ int kCombA[6] = {0, 0, 0, 1, 1, 2};
+__constant__ int kCombB[6] = {1, 2, 3, 2, 3, 3};
+
+__device__ __forceinline__ void norm_coords(const HexArgs& a, const float* __restrict__ xyz, int g, float c[4])
+{
+#pragma unroll
+    for (int k = 0; k < 3; k++) c[k] = (xyz[3 * g + k] - a.a0[k]) * (2.0f / (a.a1[k] - a.a0[k])) - 1.0f;
+    c[3] = a.times ? a.times[g] : a.time;
+}
+
+// grid: one half-wave per (Gaussian, level); blockDim 256 = 8 half-waves
+__global__ void __launch_bounds__(256) hexplane_fwd_kernel(HexArgs a, const float* __restrict__ xyz, float* __restrict__ feat)
+{
+    const int ch = threadIdx.x & 31;
+    const long long unit = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int g = (int)(unit / a.levels), lvl = (int)(unit % a.levels);
+    if (g >= a.P) return;
+    float c[4];
+    norm_coords(a, xyz, g, c);
+    float prod = 1.f;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        const int ca = kCombA[p], cb = kCombB[p];
+        const int Wd = a.res[lvl][ca], Hd = a.res[lvl][cb];
+        const PlaneSample s = make_sample(c[ca], c[cb], Wd, Hd);
+        const float* __restrict__ pl = a.planes[lvl][p];
+        float v = 0.f;
+        if (s.i00 >= 0) v += pl[(size_t)s.i00 * 32 + ch] * s.w00;
+        if (s.i01 >= 0) v += pl[(size_t)s.i01 * 32 + ch] * s.w01;
+        if (s.i10 >= 0) v += pl[(size_t)s.i10 * 32 + ch] * s.w10;
+        if (s.i11 >= 0) v += pl[(size_t)s.i11 * 32 + ch] * s.w11;
+        prod = prod * v;
+    }
+    feat[(size_t)g * (a.levels * 32) + lvl * 32 + ch] = prod;
+}
+
+__device__ __forceinline__ float half_wave_sum(float v)
+{
+    // sum over the 32 lanes of this half-wave (xor butterflies never cross bit 5)
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+hexplane_bwd_kernel(HexArgs a, const float* __restrict__ xyz, const float* __restrict__ dfeat, float* __restrict__ dxyz)
+{
+    const int ch = threadIdx.x & 31;
+    const long long unit = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int g = (int)(unit / a.levels), lvl = (int)(unit % a.levels);
+    if (g >= a.P) return;
+    float c[4];
+    norm_coords(a, xyz, g, c);
+    PlaneSample s[6];
+    float v[6], t00[6], t01[6], t10[6], t11[6];
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        const int ca = kCombA[p], cb = kCombB[p];
+        s[p] = make_sample(c[ca], c[cb], a.res[lvl][ca], a.res[lvl][cb]);
+        const float* __restrict__ pl = a.planes[lvl][p];
+        t00[p] = s[p].i00 >= 0 ? pl[(size_t)s[p].i00 * 32 + ch] : 0.f;
+        t01[p] = s[p].i01 >= 0 ? pl[(size_t)s[p].i01 * 32 + ch] : 0.f;
+        t10[p] = s[p].i10 >= 0 ? pl[(size_t)s[p].i10 * 32 + ch] : 0.f;
+        t11[p] = s[p].i11 >= 0 ? pl[(size_t)s[p].i11 * 32 + ch] : 0.f;
+        float acc = 0.f;
+        acc += t00[p] * s[p].w00;
+        acc += t01[p] * s[p].w01;
+        acc += t10[p] * s[p].w10;
+        acc += t11[p] * s[p].w11;
+        v[p] = acc;
+    }
+    const float go = dfeat[(size_t)g * (a.levels * 32) + lvl * 32 + ch];
+    // prefix / suffix products -> product excluding plane p
+    float pre[7], suf[7];
+    pre[0] = 1.f;
+#pragma unroll
+    for (int p = 0; p < 6; p++) pre[p + 1] = pre[p] * v[p];
+    suf[6] = 1.f;
+#pragma unroll
+    for (int p = 5; p >= 0; p--) suf[p] = suf[p + 1] * v[p];
+    float gc[3] = {0.f, 0.f, 0.f};  // dL/d(normalised x,y,z), this channel's share
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        const float gv = go * pre[p] * suf[p + 1];
+        float* __restrict__ gp = a.grads[lvl][p];
+        if (s[p].i00 >= 0) atomicAdd(&gp[(size_t)s[p].i00 * 32 + ch], gv * s[p].w00);
+        if (s[p].i01 >= 0) atomicAdd(&gp[(size_t)s[p].i01 * 32 + ch], gv * s[p].w01);
+        if (s[p].i10 >= 0) atomicAdd(&gp[(size_t)s[p].i10 * 32 + ch], gv * s[p].w10);
+        if (s[p].i11 >= 0) atomicAdd(&gp[(size_t)s[p].i11 * 32 + ch], gv * s[p].w11);
+        // grid gradient (ATen grid_sampler_2d backward): with x1 = x0+1, y1 = y0+1
+        const float x0 = (float)s[p].ixn, y0 = (float)s[p].iyn, x1 = x0 + 1.f, y1 = y0 + 1.f;
+        float gix = 0.f, giy = 0.f;
+        gix -= t00[p] * (y1 - s[p].iy) * gv;
+        giy -= t00[p] * (x1 - s[p].ix) * gv;
+        gix += t01[p] * (y1 - s[p].iy) * gv;
+        giy -= t01[p] * (s[p].ix - x0) * gv;
+        gix -= t10[p] * (s[p].iy - y0) * gv;
+        giy += t10[p] * (x1 - s[p].ix) * gv;
+        gix += t11[p] * (s[p].iy - y0) * gv;
+        giy += t11[p] * (s[p].ix - x0) * gv;
+        const int ca = kCombA[p], cb = kCombB[p];
+        if (ca < 3) gc[ca] += gix * s[p].gx_mul;
+        if (cb < 3) gc[cb] += giy * s[p].gy_mul;
+    }
+    if (dxyz) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float tot = half_wave_sum(gc[k]) * (2.0f / (a.a1[k] - a.a0[k]));
+            if (ch == 0) atomicAdd(&dxyz[3 * g + k], tot);  // two levels add into the same slot
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time, float* feat,
+                                    mom_stream_t stream)
+{
+    if (!hp || hp->channels != 32 || hp->levels < 1 || hp->levels > 4 || P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!xyz || !feat) return MOM_EINVAL;
+    HexArgs a;
+    a.P = P; a.levels = hp->levels; a.time = time; a.times = times;
+    for (int l = 0; l < 4; l++)
+        for (int k = 0; k < 4; k++) a.res[l][k] = hp->res[l][k];
+    for (int l = 0; l < 4; l++)
+        for (int p = 0; p < 6; p++) { a.planes[l][p] = hp->planes[l][p]; a.grads[l][p] = nullptr; }
+    for (int k = 0; k < 3; k++) { a.a0[k] = hp->aabb[k]; a.a1[k] = hp->aabb[3 + k]; }
+    const long long units = (long long)P * hp->levels;
+    hipLaunchKernelGGL(hexplane_fwd_kernel, dim3((unsigned)((units + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a, xyz, feat);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
+                                     const float* dfeat, float* dxyz, mom_stream_t stream)
+{
+    if (!hp || hp->channels != 32 || hp->levels < 1 || hp->levels > 4 || P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!xyz || !dfeat) return MOM_EINVAL;
+    HexArgs a;
+    a.P = P; a.levels = hp->levels; a.time = time; a.times = times;
+    for (int l = 0; l < 4; l++)
+        for (int k = 0; k < 4; k++) a.res[l][k] = hp->res[l][k];
+    for (int l = 0; l < 4; l++)
+        for (int p = 0; p < 6; p++) {
+            a.planes[l][p] = hp->planes[l][p];
+            a.grads[l][p] = hp->grads[l][p];
+            if (l < hp->levels && (!a.planes[l][p] || !a.grads[l][p])) return MOM_EINVAL;
+        }
+    for (int k = 0; k < 3; k++) { a.a0[k] = hp->aabb[k]; a.a1[k] = hp->aabb[3 + k]; }
+    const long long units = (long long)P * hp->levels;
+    hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)((units + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a, xyz, dfeat, dxyz);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

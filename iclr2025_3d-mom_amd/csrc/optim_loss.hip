@@ -1,0 +1,188 @@
+// Fused multi-tensor Adam, L1 loss (+PSNR sums, +gradient) and the HexPlane regularisers, gfx950.
+//
+// Replaces torch.optim.Adam.step over 8 parameter groups (reference scene/gaussian_model.py:209,
+// train_4DGS.py:295-297: ~44 tensors -> one launch), l1_loss + psnr (utils/loss_utils.py:23-24,
+// utils/image_utils.py:17-38: one pass that also emits dL/dimage) and compute_regulation
+// (scene/gaussian_model.py:730-769, scene/regulation.py:22-28: one launch for 12 planes, value and
+// gradient).  All are streaming passes: 16-byte accesses where the layout allows, grid-stride,
+// one atomic per workgroup for reductions.
+#include "mom_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- Adam
+struct AdamArgs {
+    MomAdamTensor t[MOM_ADAM_MAX_TENSORS];
+    unsigned block_start[MOM_ADAM_MAX_TENSORS + 1];
+    int count;
+    float beta1, beta2, eps;
+};
+constexpr int kAdamPerBlock = 256 * 8;
+
+__global__ void __launch_bounds__(256) adam_kernel(AdamArgs a)
+{
+    // find the tensor this workgroup works on (count <= 64: linear scan on the scalar unit)
+    int ti = 0;
+    while (ti + 1 < a.count && blockIdx.x >= a.block_start[ti + 1]) ti++;
+    const MomAdamTensor T = a.t[ti];
+    const size_t base = (size_t)(blockIdx.x - a.block_start[ti]) * kAdamPerBlock;
+    const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
+    const float step_size = T.lr / T.bias_correction1;
+    const float inv_bc2_sqrt = 1.f / T.bias_correction2_sqrt;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const size_t i = base + (size_t)k * 256 + threadIdx.x;
+        if (i < T.n) {
+            const float g = T.grad[i];
+            float m = T.exp_avg[i], v = T.exp_avg_sq[i];
+            m = m + (g - m) * w1;                       // exp_avg.lerp_(grad, 1-beta1)
+            v = v * a.beta2 + w2 * g * g;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1-beta2)
+            const float denom = sqrtf(v) * inv_bc2_sqrt + a.eps;
+            T.param[i] = T.param[i] - step_size * (m / denom);
+            T.exp_avg[i] = m;
+            T.exp_avg_sq[i] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- L1 (+ squared error sums + gradient)
+__device__ __forceinline__ float block_sum(float v, float* s)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += s[w];
+    __syncthreads();
+    return t;  // valid in thread 0
+}
+
+__global__ void __launch_bounds__(256)
+l1_kernel(size_t n, const float* __restrict__ img, const float* __restrict__ gt, float* __restrict__ dimg, float inv_n,
+          float* __restrict__ sums /* [0]=sum|d| [1]=sum d^2 */)
+{
+    __shared__ float s[4];
+    float a1 = 0.f, a2 = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = img[i] - gt[i];
+        a1 += fabsf(d);
+        a2 += d * d;
+        if (dimg) dimg[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);  // sign(d)/n, torch.abs' subgradient
+    }
+    const float t1 = block_sum(a1, s);
+    const float t2 = block_sum(a2, s);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sums[0], t1);
+        atomicAdd(&sums[1], t2);
+    }
+}
+
+// ---------------------------------------------------------------- plane regularisers
+// One workgroup strip per (plane, column block): second difference along H for every (w, c), plus the
+// |1 - p| term for space-time planes.  Planes are channel-last [H][W][32]: element (h, w, c) at (h*W + w)*32 + c,
+// so a fixed h is one contiguous row of W*32 floats and all accesses are coalesced.
+struct RegArgs {
+    MomRegPlane p[MOM_REG_MAX_PLANES];
+    unsigned block_start[MOM_REG_MAX_PLANES + 1];
+    int count;
+};
+
+__global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __restrict__ out /* [0] = value */)
+{
+    __shared__ float s[4];
+    int pi = 0;
+    while (pi + 1 < a.count && blockIdx.x >= a.block_start[pi + 1]) pi++;
+    const MomRegPlane P = a.p[pi];
+    const int row = P.W * 32;  // floats per h
+    const int col = (blockIdx.x - a.block_start[pi]) * 256 + threadIdx.x;
+    float val = 0.f;
+    if (col < row) {
+        const float* __restrict__ t = P.plane;
+        float* __restrict__ g = P.grad;
+        const int H = P.H;
+        // smoothness: mean over (c, H-2, W) of (t[h+2] - 2 t[h+1] + t[h])^2, weight ws
+        const float cs = (H > 2 && P.w_smooth != 0.f) ? P.w_smooth / ((float)(H - 2) * (float)row) : 0.f;
+        const float cl = P.w_l1 != 0.f ? P.w_l1 / ((float)H * (float)row) : 0.f;
+        float sm2 = 0.f, sm1 = 0.f;  // second differences s_{h-2}, s_{h-1}
+        float t0 = t[col], t1 = H > 1 ? t[(size_t)row + col] : 0.f;
+        for (int h = 0; h < H; h++) {
+            const float t2 = (h + 2 < H) ? t[(size_t)(h + 2) * row + col] : 0.f;
+            const float sh = (h + 2 < H) ? (t2 - 2.f * t1 + t0) : 0.f;  // s_h
+            val += cs * sh * sh;
+            // d/dt[h] sum s^2 = 2 (s_{h-2} - 2 s_{h-1} + s_h)
+            float gr = 2.f * cs * (sm2 - 2.f * sm1 + sh);
+            if (cl != 0.f) {
+                const float d = 1.f - t0;
+                val += cl * fabsf(d);
+                gr += d > 0.f ? -cl : (d < 0.f ? cl : 0.f);
+            }
+            if (g) g[(size_t)h * row + col] += gr * P.grad_scale;
+            sm2 = sm1;
+            sm1 = sh;
+            t0 = t1;
+            t1 = t2;
+        }
+    }
+    const float tot = block_sum(val, s);
+    if (threadIdx.x == 0 && tot != 0.f) atomicAdd(out, tot);
+}
+
+}  // namespace
+
+extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, float beta1, float beta2, float eps, mom_stream_t stream)
+{
+    if (count < 0 || (count > 0 && !tensors)) return MOM_EINVAL;
+    int done = 0;
+    while (done < count) {
+        AdamArgs a;
+        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+        int n = count - done;
+        if (n > MOM_ADAM_MAX_TENSORS) n = MOM_ADAM_MAX_TENSORS;
+        unsigned blocks = 0;
+        for (int i = 0; i < n; i++) {
+            a.t[i] = tensors[done + i];
+            if (a.t[i].n && (!a.t[i].param || !a.t[i].grad || !a.t[i].exp_avg || !a.t[i].exp_avg_sq)) return MOM_EINVAL;
+            a.block_start[i] = blocks;
+            blocks += (unsigned)((a.t[i].n + kAdamPerBlock - 1) / kAdamPerBlock);
+        }
+        a.block_start[n] = blocks;
+        a.count = n;
+        if (blocks) {
+            hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+            if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+        }
+        done += n;
+    }
+    return MOM_OK;
+}
+
+extern "C" int mom_l1_loss(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream)
+{
+    if (!img || !gt || !sums2) return MOM_EINVAL;
+    if (hipMemsetAsync(sums2, 0, 8, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
+    if (n == 0) return MOM_OK;
+    size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, img, gt, dimg, 1.0f / (float)n, sums2);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+extern "C" int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom_stream_t stream)
+{
+    if (count < 0 || count > MOM_REG_MAX_PLANES || !value || (count && !planes)) return MOM_EINVAL;
+    if (hipMemsetAsync(value, 0, 4, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
+    RegArgs a;
+    unsigned blocks = 0;
+    for (int i = 0; i < count; i++) {
+        a.p[i] = planes[i];
+        if (!a.p[i].plane || a.p[i].H < 1 || a.p[i].W < 1) return MOM_EINVAL;
+        a.block_start[i] = blocks;
+        blocks += (unsigned)((a.p[i].W * 32 + 255) / 256);
+    }
+    a.block_start[count] = blocks;
+    a.count = count;
+    if (blocks) hipLaunchKernelGGL(plane_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, value);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

@@ -1,0 +1,79 @@
+"""render(): one camera, one frame (reference gaussian_renderer/__init__.py:22-178) -- same signature, same
+returned dict, same maths; the deformation field and the rasterizer underneath are libmom4d HIP kernels, the
+camera matrices are staged on the device once per camera instead of every call, and the timestamp travels as
+a scalar instead of a [P,1] tensor."""
+import math
+
+import torch
+
+from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from ..utils.sh_utils import eval_sh
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, stage="fine",
+           cam_type=None, delta_scale=None):
+    """Background tensor (bg_color) must be on the GPU."""
+    means3D = pc.get_xyz
+    dev = means3D.device
+    # gradient holder for the 2D means (read back by the densification statistics, train_4DGS.py:227-229)
+    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    if cam_type != "PanopticSports":
+        if hasattr(viewpoint_camera, "device_tensors"):
+            view, proj, campos, _ = viewpoint_camera.device_tensors(dev)
+        else:
+            view, proj, campos = (viewpoint_camera.world_view_transform.to(dev), viewpoint_camera.full_proj_transform.to(dev),
+                                  viewpoint_camera.camera_center.to(dev))
+        raster_settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+            tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5), bg=bg_color,
+            scale_modifier=scaling_modifier, viewmatrix=view, projmatrix=proj, sh_degree=pc.active_sh_degree, campos=campos,
+            prefiltered=False, debug=pipe.debug)
+        time = float(viewpoint_camera.time)
+    else:
+        raster_settings = viewpoint_camera['camera']
+        time = float(viewpoint_camera['time'])
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means2D = screenspace_points
+    opacity = pc._opacity
+    shs = pc.get_features
+    scales = rotations = cov3D_precomp = None
+    if pipe.compute_cov3D_python:
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc._scaling, pc._rotation
+
+    if stage == "coarse":
+        means3D_final, scales_final, rotations_final, opacity_final, shs_final = means3D, scales, rotations, opacity, shs
+    else:
+        # fine stage: HexPlane + MLP residual on top of frame_num * scene_flow (:101-103)
+        means3D_final, scales_final, rotations_final, opacity_final, shs_final = pc._deformation(
+            means3D, scales, rotations, opacity, shs, time, pc.get_flow, viewpoint_camera.frame_num, delta_scale)
+    flow_loss = 0
+
+    scales_final = pc.scaling_activation(scales_final)
+    rotations_final = pc.rotation_activation(rotations_final)
+    opacity = pc.opacity_activation(opacity_final)
+
+    colors_precomp = None
+    if override_color is None:
+        if pipe.convert_SHs_python:
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - campos.repeat(pc.get_features.shape[0], 1)
+            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp / dir_pp.norm(dim=1, keepdim=True))
+            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+            shs_final = None
+    else:
+        colors_precomp = override_color
+        shs_final = None
+
+    rendered_image, radii, depth = rasterizer(means3D=means3D_final, means2D=means2D, shs=shs_final,
+                                              colors_precomp=colors_precomp, opacities=opacity, scales=scales_final,
+                                              rotations=rotations_final, cov3D_precomp=cov3D_precomp)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth, "flow_loss": flow_loss}

@@ -1,0 +1,235 @@
+"""torch-facing wrappers (autograd Functions, optimizer) around the libmom4d C ABI.
+
+Every op here runs on the GPU through hand-written HIP; given CPU tensors they raise (no fallback).
+CPU-only tests of the host logic swap `BACKEND` for the oracle's torch restatement explicitly."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+
+
+def _need_cuda(t, what):
+    if not t.is_cuda:
+        raise N.MomError(f"{what}: libmom4d has no CPU path (got a {t.device} tensor)")
+
+
+# --------------------------------------------------------------------------- HexPlane
+def plane_storage(p):
+    """Channel-last [H,W,C] storage view of a logical [1,C,H,W] plane parameter (or None if it is not
+    laid out that way)."""
+    if p.dim() == 4 and p.shape[0] == 1:
+        v = p[0].permute(1, 2, 0)
+        if v.is_contiguous():
+            return v
+    return None
+
+
+def make_plane(C_, H, W, device=None):
+    """A [1,C,H,W] tensor whose memory is channel-last ([H][W][C]) -- the layout libmom4d's kernels read."""
+    return torch.empty(1, H, W, C_, device=device).permute(0, 3, 1, 2)
+
+
+def _hexplane_desc(planes_by_level, aabb, grads_by_level=None):
+    d = N.MomHexPlane()
+    d.levels = len(planes_by_level)
+    d.channels = planes_by_level[0][0].shape[1]
+    keep = []
+    for l, planes in enumerate(planes_by_level):
+        # resolutions: plane (a,b) has W = res[a], H = res[b]
+        res = [0, 0, 0, 0]
+        for p, (a, b) in enumerate(((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))):
+            st = plane_storage(planes[p])
+            if st is None:
+                raise N.MomError("HexPlane planes must be channel-last (use ops.make_plane)")
+            res[a], res[b] = st.shape[1], st.shape[0]
+            d.planes[l][p] = st.data_ptr()
+            keep.append(st)
+            if grads_by_level is not None:
+                gs = plane_storage(grads_by_level[l][p])
+                d.grads[l][p] = gs.data_ptr()
+                keep.append(gs)
+        for k in range(4):
+            d.res[l][k] = res[k]
+    a = aabb.detach().float().cpu().reshape(-1).tolist()
+    for k in range(6):
+        d.aabb[k] = a[k]
+    return d, keep
+
+
+class HexPlaneFunction(torch.autograd.Function):
+    """features[P, L*32] = HexPlaneField(xyz, t) (reference scene/hexplane.py:160-183)."""
+
+    @staticmethod
+    def forward(ctx, xyz, time, aabb, n_levels, *planes):
+        _need_cuda(xyz, "hexplane")
+        lv = [list(planes[6 * l:6 * l + 6]) for l in range(n_levels)]
+        d, keep = _hexplane_desc(lv, aabb)
+        xyz_c = xyz.detach().contiguous().float()
+        P = xyz_c.shape[0]
+        feat = torch.empty((P, n_levels * 32), dtype=torch.float32, device=xyz.device)
+        # one timestamp per camera (a python float) or per-point timestamps (a tensor, as the reference passes)
+        times = time.detach().reshape(-1).contiguous().float() if torch.is_tensor(time) else None
+        tval = 0.0 if times is not None else float(time)
+        N.check(N.lib().mom_hexplane_forward(C.byref(d), P, xyz_c.data_ptr(), None if times is None else times.data_ptr(),
+                                             tval, feat.data_ptr(), N.current_stream()), "mom_hexplane_forward")
+        ctx.save_for_backward(xyz_c, aabb, *planes)
+        ctx.times, ctx.time, ctx.n_levels = times, tval, n_levels
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        xyz_c, aabb, *planes = ctx.saved_tensors
+        n_levels = ctx.n_levels
+        lv = [list(planes[6 * l:6 * l + 6]) for l in range(n_levels)]
+        grads = [[torch.zeros_like(p) for p in level] for level in lv]   # preserves the channel-last strides
+        d, keep = _hexplane_desc(lv, aabb, grads)
+        P = xyz_c.shape[0]
+        dxyz = torch.zeros_like(xyz_c) if ctx.needs_input_grad[0] else None
+        dfeat = dfeat.contiguous()
+        N.check(N.lib().mom_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(),
+                                              None if ctx.times is None else ctx.times.data_ptr(), ctx.time, dfeat.data_ptr(),
+                                              None if dxyz is None else dxyz.data_ptr(), N.current_stream()),
+                "mom_hexplane_backward")
+        flat = [g for level in grads for g in level]
+        return (dxyz, None, None, None, *flat)
+
+
+def hexplane_features(xyz, time, aabb, planes_by_level):
+    flat = [p for level in planes_by_level for p in level]
+    return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), *flat)
+
+
+# --------------------------------------------------------------------------- L1 + PSNR
+class L1LossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt):
+        _need_cuda(img, "l1_loss")
+        a = img.detach().contiguous().float()
+        b = gt.detach().contiguous().float()
+        dimg = torch.empty_like(a)
+        sums = torch.empty(2, dtype=torch.float32, device=a.device)
+        N.check(N.lib().mom_l1_loss(a.numel(), a.data_ptr(), b.data_ptr(), dimg.data_ptr(), sums.data_ptr(),
+                                    N.current_stream()), "mom_l1_loss")
+        ctx.save_for_backward(dimg)
+        ctx.mark_non_differentiable(sums)
+        return sums[0] / a.numel(), sums
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (dimg,) = ctx.saved_tensors
+        return dimg * g, None
+
+
+def l1_loss_with_sums(img, gt):
+    """(mean |img-gt|, [sum|d|, sum d^2]) in one pass; the second output feeds psnr without re-reading the images."""
+    return L1LossFunction.apply(img, gt)
+
+
+# --------------------------------------------------------------------------- plane regularisers
+class PlaneRegFunction(torch.autograd.Function):
+    """value = sum_p  w_smooth[p] * smooth2(plane_p) + w_l1[p] * mean|1 - plane_p|."""
+
+    @staticmethod
+    def forward(ctx, w_smooth, w_l1, *planes):
+        _need_cuda(planes[0], "plane_regulation")
+        arr = (N.MomRegPlane * len(planes))()
+        for i, p in enumerate(planes):
+            st = plane_storage(p)
+            arr[i].plane, arr[i].grad = st.data_ptr(), None
+            arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+            arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), 0.0
+        val = torch.empty(1, dtype=torch.float32, device=planes[0].device)
+        N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), N.current_stream()), "mom_plane_regulation")
+        ctx.save_for_backward(*planes)
+        ctx.w = (list(w_smooth), list(w_l1))
+        return val[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        planes = ctx.saved_tensors
+        w_smooth, w_l1 = ctx.w
+        grads = [torch.zeros_like(p) for p in planes]
+        arr = (N.MomRegPlane * len(planes))()
+        gs = float(g)  # the loss weight is a python scalar in the reference loop (train_4DGS.py:217-218)
+        for i, p in enumerate(planes):
+            st, gt_ = plane_storage(p), plane_storage(grads[i])
+            arr[i].plane, arr[i].grad = st.data_ptr(), gt_.data_ptr()
+            arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+            arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), gs
+        val = torch.empty(1, dtype=torch.float32, device=planes[0].device)
+        N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), N.current_stream()), "mom_plane_regulation")
+        return (None, None, *grads)
+
+
+def plane_regulation(planes, w_smooth, w_l1):
+    return PlaneRegFunction.apply(w_smooth, w_l1, *planes)
+
+
+# --------------------------------------------------------------------------- Adam
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False) whose step() is ONE HIP launch over all
+    parameters with a gradient.  State layout ('step', 'exp_avg', 'exp_avg_sq') and param_groups are those of
+    torch.optim.Adam, so the reference's optimizer-state surgery (scene/gaussian_model.py:409-482) and
+    state_dict()/load_state_dict() work unchanged."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        by_cfg = {}
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _need_cuda(p, "FusedAdam")
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                step = float(st["step"])
+                g = p.grad
+                if g.stride() != p.stride() or not p.is_non_overlapping_and_dense():
+                    raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
+                t = N.MomAdamTensor()
+                t.param, t.grad = p.data_ptr(), g.data_ptr()
+                t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+                t.n = p.numel()
+                t.lr = float(group["lr"])
+                t.bias_correction1 = 1.0 - b1 ** step
+                t.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
+                by_cfg.setdefault((b1, b2, group["eps"]), []).append(t)
+        for (b1, b2, eps), ts in by_cfg.items():
+            arr = (N.MomAdamTensor * len(ts))(*ts)
+            N.check(N.lib().mom_adam_step(arr, len(ts), b1, b2, eps, N.current_stream()), "mom_adam_step")
+        return loss
+
+
+# --------------------------------------------------------------------------- backend switch
+class _HipBackend:
+    """The product path.  Tests of pure host logic on a GPU-less machine may install the oracle's torch
+    restatement here EXPLICITLY (oracle.torch_ref.TorchBackend); nothing falls back to it by itself."""
+    name = "hip"
+    hexplane_features = staticmethod(hexplane_features)
+    l1_loss_with_sums = staticmethod(l1_loss_with_sums)
+    plane_regulation = staticmethod(plane_regulation)
+    Adam = FusedAdam
+
+
+BACKEND = _HipBackend
+
+
+def set_backend(b):
+    global BACKEND
+    BACKEND = b

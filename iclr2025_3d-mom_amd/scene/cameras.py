@@ -1,0 +1,48 @@
+"""Camera / MiniCam with the reference's attributes (reference scene/cameras.py:17-83)."""
+import numpy as np
+import torch
+from torch import nn
+
+from ..utils.graphics_utils import getProjectionMatrix, getWorld2View2
+
+
+class Camera(nn.Module):
+    def __init__(self, colmap_id, R, T, FoVx, FoVy, image, gt_alpha_mask, image_name, uid, trans=np.array([0.0, 0.0, 0.0]),
+                 scale=1.0, data_device="cuda", time=0, mask=None, frame_num=0, depth=None):
+        super().__init__()
+        self.uid, self.colmap_id, self.R, self.T = uid, colmap_id, R, T
+        self.FoVx, self.FoVy, self.image_name, self.time = FoVx, FoVy, image_name, time
+        try:
+            self.data_device = torch.device(data_device)
+        except Exception as e:
+            print(e)
+            print(f"[Warning] Custom device {data_device} failed, fallback to default cuda device")
+            self.data_device = torch.device("cuda")
+        self.original_image = image.clamp(0.0, 1.0)[:3, :, :]      # stays on the host like the reference (:39-40)
+        self.image_width, self.image_height = self.original_image.shape[2], self.original_image.shape[1]
+        if gt_alpha_mask is not None:
+            self.original_image = self.original_image * gt_alpha_mask
+        self.depth, self.mask, self.frame_num = depth, mask, frame_num
+        self.zfar, self.znear, self.trans, self.scale = 100.0, 0.01, trans, scale
+        self.world_view_transform = torch.tensor(getWorld2View2(R, T, trans, scale)).transpose(0, 1)
+        self.projection_matrix = getProjectionMatrix(znear=self.znear, zfar=self.zfar, fovX=FoVx, fovY=FoVy).transpose(0, 1)
+        self.full_proj_transform = (self.world_view_transform.unsqueeze(0).bmm(self.projection_matrix.unsqueeze(0))).squeeze(0)
+        self.camera_center = self.world_view_transform.inverse()[3, :3]
+        self._dev_cache = None
+
+    def device_tensors(self, device):
+        """(view, full_proj, camera_center[, gt image]) staged on `device` once -- the reference re-uploads the three
+        matrices and the ground-truth image every iteration (gaussian_renderer/__init__.py:49-52, train_4DGS.py:194)."""
+        if self._dev_cache is None or self._dev_cache[0].device != torch.device(device):
+            self._dev_cache = (self.world_view_transform.to(device), self.full_proj_transform.to(device),
+                               self.camera_center.to(device), self.original_image.to(device))
+        return self._dev_cache
+
+
+class MiniCam:
+    def __init__(self, width, height, fovy, fovx, znear, zfar, world_view_transform, full_proj_transform, time):
+        self.image_width, self.image_height, self.FoVy, self.FoVx = width, height, fovy, fovx
+        self.znear, self.zfar = znear, zfar
+        self.world_view_transform, self.full_proj_transform = world_view_transform, full_proj_transform
+        self.camera_center = torch.inverse(self.world_view_transform)[3][:3]
+        self.time = time

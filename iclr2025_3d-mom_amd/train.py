@@ -1,0 +1,98 @@
+"""The per-iteration body of the reference's scene_reconstruction (train_4DGS.py:119-301), in the same order:
+LR update -> SH-degree bump -> camera draw -> render -> loss -> backward -> densification statistics ->
+densify / prune / opacity reset -> Adam step.  Host syncs the reference pays every iteration (loss.item(),
+isnan, the num_rendered read-back, H2D of matrices and ground truth) are optional here."""
+from random import randint
+
+import torch
+
+from .gaussian_renderer import render
+from .utils.loss_utils import l1_loss, psnr_from_last_l1, ssim
+
+
+class Trainer:
+    def __init__(self, scene, gaussians, opt, hyper, pipe, stage="fine", delta_scale=1, white_background=False,
+                 sync_every_step=True):
+        self.scene, self.g, self.opt, self.hyper, self.pipe, self.stage = scene, gaussians, opt, hyper, pipe, stage
+        self.delta_scale = delta_scale
+        dev = gaussians._xyz.device
+        self.background = torch.tensor([1, 1, 1] if white_background else [0, 0, 0], dtype=torch.float32, device=dev)
+        gaussians.training_setup(opt)
+        self.cams = list(scene.getTrainCameras() if stage == "coarse" else scene.getTrainCameras_2())
+        self.stack = list(self.cams)
+        self.sync_every_step = sync_every_step
+        self.ema_loss, self.ema_psnr = 0.0, 0.0
+        self.last = {}
+
+    def _draw(self):
+        cams = []
+        while len(cams) < self.opt.batch_size:
+            cams.append(self.stack.pop(randint(0, len(self.stack) - 1)))
+            if not self.stack:
+                self.stack = list(self.cams)
+        return cams
+
+    def step(self, iteration, cams=None):
+        g, opt, hyper = self.g, self.opt, self.hyper
+        g.update_learning_rate(iteration)
+        if iteration % 1000 == 0:
+            g.oneupSHdegree()
+        cams = cams or self._draw()
+        images, gts, radii_l, vis_l, vsp_l = [], [], [], [], []
+        for cam in cams:
+            pkg = render(cam, g, self.pipe, self.background, stage=self.stage, cam_type=self.scene.dataset_type,
+                         delta_scale=self.delta_scale)
+            images.append(pkg["render"].unsqueeze(0))
+            gts.append(cam.device_tensors(self.background.device)[3].unsqueeze(0))
+            radii_l.append(pkg["radii"].unsqueeze(0))
+            vis_l.append(pkg["visibility_filter"].unsqueeze(0))
+            vsp_l.append(pkg["viewspace_points"])
+        radii = torch.cat(radii_l, 0).max(dim=0).values
+        visibility = torch.cat(vis_l).any(dim=0)
+        image = torch.cat(images, 0)
+        gt = torch.cat(gts, 0)
+
+        Ll1 = l1_loss(image, gt[:, :3, :, :])
+        loss = Ll1
+        if self.stage == "fine" and hyper.time_smoothness_weight != 0:
+            loss = loss + g.compute_regulation(hyper.time_smoothness_weight, hyper.l1_time_planes, hyper.plane_tv_weight)
+        if opt.lambda_dssim != 0:
+            loss = loss + opt.lambda_dssim * (1.0 - ssim(image, gt))
+        loss.backward()
+
+        vsp_grad = torch.zeros_like(vsp_l[0])
+        for v in vsp_l:
+            vsp_grad = vsp_grad + v.grad
+
+        with torch.no_grad():
+            if self.sync_every_step:
+                # the reference pays these syncs every iteration (train_4DGS.py:224,234-235)
+                if torch.isnan(loss).any():
+                    raise FloatingPointError("loss is nan")
+                self.ema_loss = 0.4 * loss.item() + 0.6 * self.ema_loss
+                self.ema_psnr = 0.4 * float(psnr_from_last_l1()) + 0.6 * self.ema_psnr
+            self.last = {"loss": loss.detach(), "l1": Ll1.detach(), "points": g._xyz.shape[0]}
+
+            if iteration < opt.densify_until_iter:
+                g.max_radii2D[visibility] = torch.max(g.max_radii2D[visibility], radii[visibility].float())
+                g.add_densification_stats(vsp_grad, visibility)
+                if self.stage == "coarse":
+                    op_thr, de_thr = opt.opacity_threshold_coarse, opt.densify_grad_threshold_coarse
+                else:
+                    f = iteration / opt.densify_until_iter
+                    op_thr = opt.opacity_threshold_fine_init - f * (opt.opacity_threshold_fine_init - opt.opacity_threshold_fine_after)
+                    de_thr = opt.densify_grad_threshold_fine_init - f * (opt.densify_grad_threshold_fine_init - opt.densify_grad_threshold_after)
+                n = g.get_xyz.shape[0]
+                size_thr = 20 if iteration > opt.opacity_reset_interval else None
+                if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0 and n < 360000:
+                    g.densify(de_thr, op_thr, self.scene.cameras_extent, size_thr, 5, 5, self.scene.model_path, iteration, self.stage)
+                n = g.get_xyz.shape[0]
+                if iteration > opt.pruning_from_iter and iteration % opt.pruning_interval == 0 and n > 200000:
+                    g.prune(de_thr, op_thr, self.scene.cameras_extent, size_thr)
+                if iteration % opt.opacity_reset_interval == 0:
+                    g.reset_opacity()
+
+            if iteration < opt.iterations:
+                g.optimizer.step()
+                g.optimizer.zero_grad(set_to_none=True)
+        return loss.detach()

@@ -1,0 +1,61 @@
+"""Losses of the 4DGS loop (reference utils/loss_utils.py:23-92).  l1_loss runs as one fused HIP pass that also
+produces the gradient image and the squared-error sum PSNR needs; ssim keeps the reference's definition
+(11x11 gaussian window, sigma 1.5, zero padding, C1=0.01^2, C2=0.03^2)."""
+from math import exp
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+_last_sums = {"sums": None, "n": 0, "batch": 1}
+
+
+def l1_loss(network_output, gt):
+    loss, sums = ops.BACKEND.l1_loss_with_sums(network_output, gt)
+    _last_sums.update(sums=sums, n=network_output.numel(), batch=network_output.shape[0] if network_output.dim() == 4 else 1)
+    return loss
+
+
+def psnr_from_last_l1():
+    """PSNR of the image pair of the most recent l1_loss call (batch of 1), without re-reading the images."""
+    s = _last_sums
+    mse = s["sums"][1] / s["n"]
+    return 20 * torch.log10(1.0 / torch.sqrt(mse))
+
+
+def l2_loss(network_output, gt):
+    return ((network_output - gt) ** 2).mean()
+
+
+def gaussian(window_size, sigma):
+    g = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
+    return g / g.sum()
+
+
+def create_window(window_size, channel):
+    w1 = gaussian(window_size, 1.5).unsqueeze(1)
+    w2 = w1.mm(w1.t()).float().unsqueeze(0).unsqueeze(0)
+    return w2.expand(channel, 1, window_size, window_size).contiguous()
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    channel = img1.size(-3)
+    window = create_window(window_size, channel).to(img1.device).type_as(img1)
+    return _ssim(img1, img2, window, window_size, channel, size_average)
+
+
+def _ssim(img1, img2, window, window_size, channel, size_average=True):
+    pad = window_size // 2
+
+    def blur(x):
+        return F.conv2d(x, window, padding=pad, groups=channel)
+
+    mu1, mu2 = blur(img1), blur(img2)
+    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = blur(img1 * img1) - mu1_sq
+    s2 = blur(img2 * img2) - mu2_sq
+    s12 = blur(img1 * img2) - mu12
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)

@@ -143,6 +143,67 @@ size_t mom_knn_scratch_bytes(int P);
 int mom_knn_mean_dist2(int P, const float* points /* [P,3] */, float* mean_dist2 /* [P] */, void* scratch,
                        mom_stream_t stream);
 
+/* ---- HexPlane feature field --------------------------------------------------------------
+ * Replaces HexPlaneField.forward (scene/hexplane.py:160-183: normalize_aabb, 6 bilinear
+ * grid_sample(align_corners=True, padding_mode='border') per level, product over planes,
+ * concat over levels) and its autograd backward (plane scatter-adds + the gradient wrt the
+ * sample positions).  Planes are CHANNEL-LAST: planes[l][p] points to [H][W][32] floats where,
+ * for plane p = (a,b) in the order (0,1),(0,2),(0,3),(1,2),(1,3),(2,3) of (x,y,z,t),
+ * W = res[l][a] and H = res[l][b].  aabb = the reference's 2x3 `aabb` parameter verbatim
+ * (row 0 then row 1; the reference stores xyz_max in row 0, hexplane.py:152-157).  `time` is
+ * the raw timestamp used as the 4th grid coordinate (gaussian_renderer/__init__.py:56). */
+typedef struct MomHexPlane {
+    int levels;            /* 1..4 */
+    int channels;          /* must be 32 */
+    int res[4][4];         /* per level: resolution along x, y, z, t */
+    const float* planes[4][6];
+    float* grads[4][6];    /* backward only: same layout as planes, ACCUMULATED into (+=, float atomics) */
+    float aabb[6];
+} MomHexPlane;
+/* feat [P, levels*32] row-major.  times: optional per-point timestamps [P]; null -> `time` for all points
+ * (render() uses one timestamp per camera). */
+int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time, float* feat,
+                         mom_stream_t stream);
+/* dfeat [P, levels*32]; plane gradients accumulate into hp->grads; dxyz [P,3] (may be null) is ACCUMULATED into */
+int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
+                          const float* dfeat, float* dxyz, mom_stream_t stream);
+
+/* ---- fused multi-tensor Adam (torch.optim.Adam, amsgrad=False, weight_decay=0) -----------
+ * One launch updates every listed tensor: exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
+ * p -= lr/bc1 * exp_avg / (sqrt(exp_avg_sq)/sqrt(bc2) + eps), bc = 1 - beta^step computed by the
+ * caller in double (as torch does).  Tensors are flat views of n floats in storage order; param,
+ * grad and both moments of one tensor must share that order. */
+#define MOM_ADAM_MAX_TENSORS 64
+typedef struct MomAdamTensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    size_t n;
+    float lr;
+    float bias_correction1;
+    float bias_correction2_sqrt;
+} MomAdamTensor;
+int mom_adam_step(const MomAdamTensor* tensors, int count, float beta1, float beta2, float eps, mom_stream_t stream);
+
+/* ---- L1 loss + PSNR sums + gradient (utils/loss_utils.py:23-24, utils/image_utils.py:17-38) --
+ * sums2[0] = sum |img-gt|, sums2[1] = sum (img-gt)^2 over n elements (zeroed by the call);
+ * dimg (may be null) = sign(img-gt)/n = d mean|img-gt| / d img. */
+int mom_l1_loss(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream);
+
+/* ---- HexPlane regularisers (scene/gaussian_model.py:730-769, scene/regulation.py:22-28) ----
+ * value = sum over planes of w_smooth * mean((p[h+2]-2p[h+1]+p[h])^2) + w_l1 * mean|1-p|
+ * (second difference along H, the reference's dim -2); if grad != null, grad_scale * d value / d plane is
+ * ADDED into it.  Channel-last [H][W][32] planes as above. */
+#define MOM_REG_MAX_PLANES 24
+typedef struct MomRegPlane {
+    const float* plane;
+    float* grad;
+    int H, W;
+    float w_smooth, w_l1, grad_scale;
+} MomRegPlane;
+int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom_stream_t stream);
+
 const char* mom_version(void);
 
 /* Self test of the wave64 DPP reduction used by the render backward:

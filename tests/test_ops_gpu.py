@@ -1,0 +1,155 @@
+"""GPU parity of the non-rasterizer HIP ops (HexPlane fwd/bwd, fused Adam, L1+PSNR, plane regularisers, distCUDA2)
+against the oracle (oracle/torch_ref.py = the reference's torch-op sequence on the CPU; oracle/raster_oracle.c knn)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from oracle import torch_ref as tr
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module("iclr2025_3d-mom_amd.ops")
+HexPlaneField = importlib.import_module("iclr2025_3d-mom_amd.scene.hexplane").HexPlaneField
+
+
+def _field(res=(8, 8, 8, 5), multires=(1, 2), seed=0):
+    torch.manual_seed(seed)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 4, 'output_coordinate_dim': 32, 'resolution': list(res)}
+    f = HexPlaneField(1.6, cfg, list(multires))
+    f.set_aabb([1.0, 1.2, 1.4], [-1.0, -1.2, -1.4])
+    with torch.no_grad():
+        for g in f.grids:
+            for p in g:
+                p.add_(torch.randn_like(p) * 0.2)
+    return f
+
+
+def _points(n, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([1.1, 1.3, 1.5])   # some outside the box
+    pts[0] = torch.tensor([1.0, 1.2, 1.4])      # exact corners
+    pts[1] = torch.tensor([-1.0, -1.2, -1.4])
+    return pts
+
+
+@pytest.mark.parametrize("res,multires,t", [((8, 8, 8, 5), (1, 2), 0.3), ((64, 64, 64, 50), (1, 2), 0.77),
+                                             ((16, 12, 10, 7), (1, 2, 4), 0.0), ((8, 8, 8, 5), (1,), 1.0)])
+def test_hexplane_forward_backward_parity(res, multires, t):
+    f = _field(res, multires)
+    pts = _points(257)
+    w = torch.randn(257, f.feat_dim, generator=torch.Generator().manual_seed(3))
+    # oracle on the CPU
+    p_cpu = pts.clone().requires_grad_(True)
+    planes_cpu = [[p.detach().clone().contiguous().requires_grad_(True) for p in g] for g in f.grids]
+    feat_ref = tr.hexplane_features(p_cpu, t, f.aabb.detach(), planes_cpu)
+    (feat_ref * w).sum().backward()
+    # HIP
+    fg = f.cuda()
+    p_gpu = pts.cuda().requires_grad_(True)
+    feat = fg(p_gpu, t)
+    (feat * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), feat_ref.detach().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(p_gpu.grad.cpu().numpy(), p_cpu.grad.numpy(), rtol=2e-4, atol=2e-5)
+    for gl, gc in zip(fg.grids, planes_cpu):
+        for a, b in zip(gl, gc):
+            assert a.grad.shape == b.grad.shape
+            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-4, atol=2e-5)
+    # per-point timestamps (the form the reference passes) give the same result as the scalar
+    feat2 = fg(p_gpu.detach(), torch.full((257, 1), t, device="cuda"))
+    np.testing.assert_array_equal(feat2.cpu().numpy(), feat.detach().cpu().numpy())
+
+
+def test_fused_adam_matches_torch_adam_incl_tiny_eps():
+    torch.manual_seed(0)
+    shapes = [(1000, 3), (1000, 1, 3), (1000, 15, 3), (1000, 1), (64, 64), (64,), (7,)]
+    ps_ref = [torch.randn(s) for s in shapes]
+    plane = ops.make_plane(32, 9, 11)
+    plane.copy_(torch.randn(1, 32, 9, 11))
+    ps_ref.append(plane.clone())          # keeps the channel-last strides
+    ps_hip = [p.clone().cuda() for p in ps_ref]
+    assert ps_hip[-1].stride() == ps_ref[-1].stride()
+    lrs = [1e-3, 2.5e-3, 1.25e-4, 5e-2, 1.6e-4, 1.6e-4, 0.0, 1.6e-3]
+    ref = torch.optim.Adam([{"params": [torch.nn.Parameter(p)], "lr": lr} for p, lr in zip(ps_ref, lrs)], lr=0.0, eps=1e-15)
+    hip = ops.FusedAdam([{"params": [torch.nn.Parameter(p)], "lr": lr} for p, lr in zip(ps_hip, lrs)], lr=0.0, eps=1e-15)
+    for it in range(3):
+        for gr, gh in zip(ref.param_groups, hip.param_groups):
+            g = torch.randn_like(gr["params"][0]) * (1e-9 if it == 1 else 1.0)   # tiny grads: eps=1e-15 matters
+            if it == 2 and gr["params"][0].shape == (7,):
+                continue                                                           # a param without grad is skipped
+            gr["params"][0].grad = g.clone()
+            gh["params"][0].grad = g.clone().cuda()
+        ref.step()
+        hip.step()
+        ref.zero_grad(set_to_none=True)
+        hip.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    for gr, gh in zip(ref.param_groups, hip.param_groups):
+        a, b = gh["params"][0].detach().cpu(), gr["params"][0].detach()
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=3e-6, atol=1e-7)
+        sa, sb = hip.state[gh["params"][0]], ref.state[gr["params"][0]]
+        np.testing.assert_allclose(sa["exp_avg"].cpu().numpy(), sb["exp_avg"].numpy(), rtol=2e-6, atol=1e-12)
+        np.testing.assert_allclose(sa["exp_avg_sq"].cpu().numpy(), sb["exp_avg_sq"].numpy(), rtol=2e-6, atol=1e-20)
+        assert float(sa["step"]) == float(sb["step"])
+    # state_dict round trip keeps the torch.optim.Adam layout
+    sd = hip.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_l1_and_psnr_sums():
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 3, 37, 53, generator=g)
+    gt = torch.rand(1, 3, 37, 53, generator=g)
+    gt[0, 0, 0, :5] = img[0, 0, 0, :5]      # exact zeros: sign(0) = 0
+    a = img.clone().requires_grad_(True)
+    loss_ref, sums_ref = tr.l1_loss_with_sums(a, gt)
+    loss_ref.backward()
+    b = img.cuda().requires_grad_(True)
+    loss, sums = ops.l1_loss_with_sums(b, gt.cuda())
+    (loss * 1.0).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss), float(loss_ref), rtol=1e-5)
+    np.testing.assert_allclose(sums.cpu().numpy(), sums_ref.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(b.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-6, atol=0)
+
+
+def test_plane_regulation_value_and_grads():
+    f = _field((8, 8, 8, 5), (1, 2))
+    planes_cpu, ws, wl = [], [], []
+    for g in f.grids:
+        for i, p in enumerate(g):
+            planes_cpu.append(p.detach().clone().contiguous().requires_grad_(True))
+            ws.append(0.01 if i in (2, 4, 5) else 1e-4)
+            wl.append(1e-4 if i in (2, 4, 5) else 0.0)
+    val_ref = tr.plane_regulation(planes_cpu, ws, wl)
+    (val_ref * 3.0).backward()
+    fg = f.cuda()
+    planes = [p for g in fg.grids for p in g]
+    val = ops.plane_regulation(planes, ws, wl)
+    (val * 3.0).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(val), float(val_ref), rtol=2e-5)
+    for a, b in zip(planes, planes_cpu):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("P", [1, 5, 1024, 1025, 20000])
+def test_dist_cuda2_matches_oracle(P):
+    knn = importlib.import_module("iclr2025_3d-mom_amd.simple_knn._C")
+    rng = np.random.default_rng(P)
+    pts = (rng.normal(size=(P, 3)) * [1.0, 2.0, 0.5] + [0.3, -0.2, 3.0]).astype(np.float32)
+    got = knn.distCUDA2(torch.from_numpy(pts).cuda()).cpu().numpy()
+    exp = ro.knn_mean_dist2(pts)
+    np.testing.assert_array_equal(got, exp)      # same float ops in the same order: bit-exact
+
+
+def test_ops_refuse_cpu_tensors():
+    N = importlib.import_module("iclr2025_3d-mom_amd._native")
+    with pytest.raises(N.MomError):
+        ops.l1_loss_with_sums(torch.zeros(3, 4, 4), torch.zeros(3, 4, 4))
+    knn = importlib.import_module("iclr2025_3d-mom_amd.simple_knn._C")
+    with pytest.raises(N.MomError):
+        knn.distCUDA2(torch.zeros(4, 3))
