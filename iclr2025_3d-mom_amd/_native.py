@@ -85,7 +85,7 @@ def _sig(lib):
     lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
     lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp]
     lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
-    lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_float, C.c_float, C.c_float, vp]
+    lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.mom_l1_loss.argtypes = [sz, vp, vp, vp, vp, vp]
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
     lib.mom_knn_scratch_bytes.restype = sz

@@ -15,7 +15,7 @@ struct AdamArgs {
     MomAdamTensor t[MOM_ADAM_MAX_TENSORS];
     unsigned block_start[MOM_ADAM_MAX_TENSORS + 1];
     int count;
-    float beta1, beta2, eps;
+    float beta1, beta2, eps, w1, w2;  // w = 1 - beta evaluated in double on the host, as torch does
 };
 constexpr int kAdamPerBlock = 256 * 8;
 
@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a)
     while (ti + 1 < a.count && blockIdx.x >= a.block_start[ti + 1]) ti++;
     const MomAdamTensor T = a.t[ti];
     const size_t base = (size_t)(blockIdx.x - a.block_start[ti]) * kAdamPerBlock;
-    const float w1 = 1.f - a.beta1, w2 = 1.f - a.beta2;
+    const float w1 = a.w1, w2 = a.w2;
     const float step_size = T.lr / T.bias_correction1;
     const float inv_bc2_sqrt = 1.f / T.bias_correction2_sqrt;
 #pragma unroll
@@ -131,13 +131,14 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __rest
 
 }  // namespace
 
-extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, float beta1, float beta2, float eps, mom_stream_t stream)
+extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double beta2, double eps, mom_stream_t stream)
 {
     if (count < 0 || (count > 0 && !tensors)) return MOM_EINVAL;
     int done = 0;
     while (done < count) {
         AdamArgs a;
-        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+        a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
+        a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2);
         int n = count - done;
         if (n > MOM_ADAM_MAX_TENSORS) n = MOM_ADAM_MAX_TENSORS;
         unsigned blocks = 0;

@@ -170,6 +170,17 @@ def plane_regulation(planes, w_smooth, w_l1):
 
 
 # --------------------------------------------------------------------------- Adam
+def _dense(t):
+    """True if t's elements tile its storage span without gaps or overlap (any dim order)."""
+    dims = sorted(((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1), reverse=True)
+    expect = 1
+    for st, sz in reversed(dims):
+        if st != expect:
+            return False
+        expect *= sz
+    return True
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False) whose step() is ONE HIP launch over all
     parameters with a gradient.  State layout ('step', 'exp_avg', 'exp_avg_sq') and param_groups are those of
@@ -200,7 +211,7 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 step = float(st["step"])
                 g = p.grad
-                if g.stride() != p.stride() or not p.is_non_overlapping_and_dense():
+                if g.stride() != p.stride() or not _dense(p):
                     raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
                 t = N.MomAdamTensor()
                 t.param, t.grad = p.data_ptr(), g.data_ptr()

@@ -137,8 +137,8 @@ typedef struct MomRasterLayout {
 int mom_raster_layout(int P, int W, int H, size_t capacity, MomRasterLayout* out);
 
 /* distCUDA2 (simple-knn/spatial.cu:15-25): mean squared distance to the 3 nearest
- * neighbours.  scratch must hold mom_knn_scratch_bytes(P).  Synchronises the
- * stream once internally (the reference does two blocking copies, simple_knn.cu:197,200). */
+ * neighbours.  scratch must hold mom_knn_scratch_bytes(P).  Fully stream-ordered (the
+ * reference does two blocking copies of the bounding box, simple_knn.cu:197,200). */
 size_t mom_knn_scratch_bytes(int P);
 int mom_knn_mean_dist2(int P, const float* points /* [P,3] */, float* mean_dist2 /* [P] */, void* scratch,
                        mom_stream_t stream);
@@ -184,7 +184,7 @@ typedef struct MomAdamTensor {
     float bias_correction1;
     float bias_correction2_sqrt;
 } MomAdamTensor;
-int mom_adam_step(const MomAdamTensor* tensors, int count, float beta1, float beta2, float eps, mom_stream_t stream);
+int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double beta2, double eps, mom_stream_t stream);
 
 /* ---- L1 loss + PSNR sums + gradient (utils/loss_utils.py:23-24, utils/image_utils.py:17-38) --
  * sums2[0] = sum |img-gt|, sums2[1] = sum (img-gt)^2 over n elements (zeroed by the call);

@@ -52,15 +52,17 @@ def test_hexplane_forward_backward_parity(res, multires, t):
     feat = fg(p_gpu, t)
     (feat * w.cuda()).sum().backward()
     torch.cuda.synchronize()
-    np.testing.assert_allclose(feat.detach().cpu().numpy(), feat_ref.detach().numpy(), rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(p_gpu.grad.cpu().numpy(), p_cpu.grad.numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(feat.detach().cpu().numpy(), feat_ref.detach().numpy(), rtol=2e-5, atol=5e-6)
+    def close(a, b):   # sums of signed terms: tolerance relative to the tensor's scale
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(b).max())))
+    close(p_gpu.grad.cpu().numpy(), p_cpu.grad.numpy())
     for gl, gc in zip(fg.grids, planes_cpu):
         for a, b in zip(gl, gc):
             assert a.grad.shape == b.grad.shape
-            np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-4, atol=2e-5)
+            close(a.grad.cpu().numpy(), b.grad.numpy())
     # per-point timestamps (the form the reference passes) give the same result as the scalar
     feat2 = fg(p_gpu.detach(), torch.full((257, 1), t, device="cuda"))
-    np.testing.assert_array_equal(feat2.cpu().numpy(), feat.detach().cpu().numpy())
+    np.testing.assert_array_equal(feat2.detach().cpu().numpy(), feat.detach().cpu().numpy())
 
 
 def test_fused_adam_matches_torch_adam_incl_tiny_eps():
