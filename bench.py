@@ -1,0 +1,150 @@
+#!/usr/bin/env python
+"""bench.py -- 4DGS fine-stage training steps/s on MI355X (BASELINE.json metric), config
+"200k Gaussians, 60 frames, 960x540, HexPlane on" (BASELINE.json configs[1]) on the synthetic scene of
+SURVEY.md section 8(d).  One step = one full iteration of the reference loop (train_4DGS.py:119-301):
+LR update, render (HexPlane + MLP deformation -> rasterizer), L1 + plane regularisers, backward, densification
+statistics, Adam on every Gaussian parameter and the deformation field.
+
+    python bench.py --gpus N --steps K --warmup W
+prints ONE JSON line (rank 0).  N > 1 (torchrun): camera-batch shard -- every rank renders a different camera
+of the same step and the parameter gradients are all-reduced over RCCL (weak scaling: per-GPU work fixed).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    "c2": dict(P=200_000, F=60, W=960, H=540, time_res=50, name="200k Gaussians, 60 frames, 960x540, HexPlane on"),
+    "c3": dict(P=1_000_000, F=120, W=1920, H=1080, time_res=100, name="1M Gaussians, 120 frames, 1920x1080"),
+    "c1": dict(P=5_000, F=8, W=256, H=256, time_res=50, name="5k Gaussians, 8 frames, 256x256"),
+}
+
+
+def build_state(cfg, device, backend_install=None):
+    import torch
+    pkg = importlib.import_module("iclr2025_3d-mom_amd")
+    A = importlib.import_module("iclr2025_3d-mom_amd.arguments")
+    S = importlib.import_module("iclr2025_3d-mom_amd.scene")
+    T = importlib.import_module("iclr2025_3d-mom_amd.train")
+    args, lp, op, pp, hp = A.default_args(time_resolution=cfg["time_res"])
+    torch.manual_seed(6666)
+    scene = S.SyntheticScene(cfg["P"], cfg["F"], cfg["W"], cfg["H"], seed=6666)
+    g = S.GaussianModel(lp.sh_degree, hp, device=device)
+    scene.init_gaussians(g)
+    scene.make_trained_like(g)
+    trainer = T.Trainer(scene, g, op, hp, pp, stage="fine", delta_scale=1, sync_every_step=False)
+    return scene, g, trainer, op
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """The oracle (C rasterizer restatement + the reference's torch-op sequence on the CPU) timed on this host's
+    cores on a bounded sample of the same workload."""
+    import torch
+    from oracle import cpu_backend
+    from oracle import raster_oracle as ro
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ro.set_threads(cores)
+    with cpu_backend.installed():
+        scene, g, trainer, op = build_state(cfg, "cpu")
+        trainer.step(5001)                      # warm-up
+        n, t0 = 0, time.time()
+        while True:
+            trainer.step(5002 + n)
+            n += 1
+            if time.time() - t0 > budget_s or n >= 20:
+                break
+        dt = (time.time() - t0) / n
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fine-stage steps of the same scene after 1 warm-up ({dt:.2f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-mode", default="async", choices=["async", "exact"])
+    ap.add_argument("--roofline-kernel", default="render_bwd")
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    cfg = CONFIGS[a.config]
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libmom4d has no CPU path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl")
+    dev = torch.device("cuda", local)
+    DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
+    scene, g, trainer, op = build_state(cfg, dev)
+    cams = trainer.cams
+    par = None
+    if world > 1:
+        par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+        par.attach(trainer, rank, world)
+    it0 = 5000  # mid-training iteration numbers: densification statistics on, no densify/reset in the window
+
+    def one(i):
+        # every rank takes a different camera of the cycle (camera-batch shard); N=1 walks all F+5 cameras
+        cam = cams[(i * world + rank) % len(cams)]
+        return trainer.step(it0 + 1 + (i % 90), cams=[cam])
+
+    DGR.set_sync_mode("exact")
+    one(0)                                                   # sizes the binning buffers
+    R = DGR.last_num_rendered()
+    if a.sync_mode == "async":
+        DGR.set_sync_mode("async", capacity_hint=int(R * 1.6) + 65536)
+    for i in range(a.warmup):
+        one(i + 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof = importlib.import_module("iclr2025_3d-mom_amd.profiling")
+    if rank == 0:
+        prof.enable(a.roofline_kernel)       # two hipEventRecord per step around the dominant kernel only
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = one(a.warmup + 1 + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt[0])
+    assert torch.isfinite(loss).all(), "loss is not finite"
+    out = {
+        "metric": "4DGS train-steps/sec @200k Gaussians, 960x540, 60 frames", "value": a.steps * world / dt,
+        "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["name"], "gaussians": cfg["P"], "frames": cfg["F"], "width": cfg["W"],
+                   "height": cfg["H"], "instances_R": int(DGR.last_num_rendered() or 0), "sh_degree": 3, "batch_size": 1,
+                   "lambda_dssim": 0, "parallelism": f"camera-batch x{world}" if world > 1 else "single",
+                   "host_sync": a.sync_mode, "final_loss": float(loss)},
+    }
+    if rank == 0:
+        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], out["config"]["instances_R"], cfg["W"] * cfg["H"])
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -204,6 +204,7 @@ extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* x
         for (int p = 0; p < 6; p++) { a.planes[l][p] = hp->planes[l][p]; a.grads[l][p] = nullptr; }
     for (int k = 0; k < 3; k++) { a.a0[k] = hp->aabb[k]; a.a1[k] = hp->aabb[3 + k]; }
     const long long units = (long long)P * hp->levels;
+    MomProfScope ps(MOM_P_HEX_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(hexplane_fwd_kernel, dim3((unsigned)((units + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a, xyz, feat);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
@@ -226,6 +227,7 @@ extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* 
         }
     for (int k = 0; k < 3; k++) { a.a0[k] = hp->aabb[k]; a.a1[k] = hp->aabb[3 + k]; }
     const long long units = (long long)P * hp->levels;
+    MomProfScope ps(MOM_P_HEX_BWD, (hipStream_t)stream);
     hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)((units + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a, xyz, dfeat, dxyz);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -98,6 +98,17 @@ static inline char* mom_align_ptr(void* p)
         }                                                              \
     } while (0)
 
+// per-kernel timing slots (profile.hip); no-ops unless enabled through mom_profile_enable
+enum { MOM_P_PRE_FWD = 0, MOM_P_HIST, MOM_P_SCAN, MOM_P_SCATTER, MOM_P_SORT, MOM_P_RENDER_FWD, MOM_P_RENDER_BWD, MOM_P_PRE_BWD,
+       MOM_P_HEX_FWD, MOM_P_HEX_BWD, MOM_P_ADAM, MOM_P_L1, MOM_P_REG, MOM_P_MLP_FWD, MOM_P_MLP_BWD };
+void mom_prof_begin(int slot, hipStream_t s);
+void mom_prof_end(int slot, hipStream_t s);
+struct MomProfScope {
+    int slot; hipStream_t s;
+    MomProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_) { mom_prof_begin(slot, s); }
+    ~MomProfScope() { mom_prof_end(slot, s); }
+};
+
 #ifdef __HIPCC__
 // ---- device helpers ----------------------------------------------------------
 // Tile rectangle of a splat: truncating casts then clamp (reference auxiliary.h:46-56).

@@ -151,6 +151,7 @@ extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, double bet
         a.block_start[n] = blocks;
         a.count = n;
         if (blocks) {
+            MomProfScope ps(MOM_P_ADAM, (hipStream_t)stream);
             hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
             if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
         }
@@ -166,6 +167,7 @@ extern "C" int mom_l1_loss(size_t n, const float* img, const float* gt, float* d
     if (n == 0) return MOM_OK;
     size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
     if (blocks > 2048) blocks = 2048;
+    MomProfScope ps(MOM_P_L1, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, img, gt, dimg, 1.0f / (float)n, sums2);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
@@ -184,6 +186,7 @@ extern "C" int mom_plane_regulation(const MomRegPlane* planes, int count, float*
     }
     a.block_start[count] = blocks;
     a.count = count;
+    MomProfScope ps(MOM_P_REG, (hipStream_t)stream);
     if (blocks) hipLaunchKernelGGL(plane_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, value);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

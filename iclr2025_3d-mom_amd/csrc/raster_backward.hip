@@ -302,6 +302,7 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
     b.dmeans2D = gr->dL_dmeans2D; b.dcolors = gr->dL_dcolors; b.dopacity = gr->dL_dopacity; b.dmeans3D = gr->dL_dmeans3D;
     b.dcov3D = gr->dL_dcov3D; b.dsh = gr->dL_dsh; b.dscales = a->scales ? gr->dL_dscales : nullptr;
     b.drot = a->scales ? gr->dL_drotations : nullptr;
+    MomProfScope ps(MOM_P_PRE_BWD, s);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a->P + 255) / 256), dim3(256), 0, s, b);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

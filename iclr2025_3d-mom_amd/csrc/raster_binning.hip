@@ -250,12 +250,15 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
     if (chunks < 1) chunks = 1;
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
+    mom_prof_begin(MOM_P_HIST, s);
     if (tiles <= kMaxLdsTiles)
         hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy, g.rec,
                            im.tile_counts);
     else
         hipLaunchKernelGGL(tile_hist_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, g.rec, im.tile_counts);
+    mom_prof_end(MOM_P_HIST, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    MomProfScope ps(MOM_P_SCAN, s);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tiles, im.tile_counts, im.tile_cursor, im.ranges, im.hdr,
                        num_rendered_dev);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
@@ -270,13 +273,16 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     if (chunks < 1) chunks = 1;
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+    mom_prof_begin(MOM_P_SCATTER, s);
     if (tiles <= kMaxLdsTiles)
         hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy,
                            g.rec, im.tile_cursor, b.keys, cap, im.hdr);
     else
         hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, g.rec,
                            im.tile_cursor, b.keys, cap, im.hdr);
+    mom_prof_end(MOM_P_SCATTER, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    MomProfScope ps(MOM_P_SORT, s);
     hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles), dim3(256), 0, s, im.ranges, b.keys, b.point_list, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -205,6 +205,7 @@ int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* ra
     p.focal_x = a->W / (2.0f * a->tan_fovx);
     p.view = a->viewmatrix; p.proj = a->projmatrix; p.cam = a->campos;
     const int blocks = (a->P + 255) / 256;
+    MomProfScope ps(MOM_P_PRE_FWD, s);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, s, p, radii, g.rec, g.cov3D, g.clamped);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -244,6 +244,7 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+    MomProfScope ps(MOM_P_RENDER_FWD, s);
     hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, gx * gy,
                        g.rec, a->background, im.final_T, im.n_contrib, out_color, out_depth, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
@@ -255,6 +256,7 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
     if (hipMemsetAsync(g.gacc, 0, (size_t)a->P * 48, s) != hipSuccess) return MOM_ELAUNCH;
+    MomProfScope ps(MOM_P_RENDER_BWD, s);
     hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, gx * gy,
                        g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;

@@ -206,6 +206,14 @@ int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom
 
 const char* mom_version(void);
 
+/* Per-kernel HIP-event timing (bench.py's live roofline figure).  Slots: see mom_profile_name(0..15).
+ * While a slot is enabled every launch of that kernel is bracketed by two hipEventRecord on the launch stream;
+ * mom_profile_read synchronises those events and returns the accumulated time and launch count. */
+#define MOM_PROF_SLOTS 16
+int mom_profile_enable(int slot, int on);
+int mom_profile_read(int slot, double* total_ms, long long* count, int reset);
+const char* mom_profile_name(int slot);
+
 /* Self test of the wave64 DPP reduction used by the render backward:
  * out[w] = sum(in[64w .. 64w+63]). */
 int mom_selftest_wave_sum(const float* in, float* out, int waves, mom_stream_t stream);
