@@ -42,13 +42,15 @@ def build_state(cfg, device, backend_install=None):
     return scene, g, trainer, op
 
 
-def cpu_baseline(cfg, budget_s=25.0):
+def cpu_baseline(cfg, budget_s=15.0):
     """The oracle (C rasterizer restatement + the reference's torch-op sequence on the CPU) timed on this host's
     cores on a bounded sample of the same workload."""
     import torch
     from oracle import cpu_backend
     from oracle import raster_oracle as ro
-    cores = os.cpu_count() or 1
+    # 16 threads is the fastest setting measured on the 2 x EPYC 9575F host of the GPU box (8: 2.4 s, 16: 1.4 s,
+    # 32: 1.6 s, 64: 2.5 s, 128: 4.5 s per step -- float `omp atomic` and torch's small ops stop scaling)
+    cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     ro.set_threads(cores)
     with cpu_backend.installed():

@@ -1,0 +1,81 @@
+"""Multi-GPU execution of the training step: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on MI355X; "gloo" in the CPU tests).
+
+The reference is single-GPU; its only batch axis is `batch_size` cameras per iteration rendered one after the other
+(train_4DGS.py:172-229) with the loss averaged over the batch.  CAMERA-BATCH SHARD reproduces exactly that with
+one camera per rank: every rank holds the full model (replica), renders and back-propagates its own camera, then
+
+  * parameter gradients: ONE sum-all-reduce over a single flat fp32 bucket (59 floats per Gaussian + the
+    deformation field; 59 MB at 200k Gaussians), scaled by 1/world -- identical to the reference's mean over the
+    batch.  On the xGMI full mesh RCCL moves S/8 per link per phase, so one large bucket is the right shape;
+  * densification statistics: max-all-reduce of the radii, sum-all-reduce of the screen-space gradients
+    (train_4DGS.py:203-204,227-229).
+
+Everything downstream (densify / prune / Adam) then runs replicated and stays bit-identical across ranks.  The one
+random draw in densify_and_split (gaussian_model.py:525) is made identical by seeding every rank's generator with
+(seed, iteration) before the call.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DistContext:
+    def __init__(self, rank, world, seed=6666):
+        self.rank, self.world, self.seed = rank, world, seed
+        self._flat = None
+
+    def sync_param_grads(self, optimizer):
+        """Average the gradients of every optimised parameter across ranks through one flat bucket."""
+        ps = [p for g in optimizer.param_groups for p in g["params"]]
+        if not ps:
+            return
+        dev = ps[0].device
+        n = sum(p.numel() for p in ps)
+        if self._flat is None or self._flat.numel() != n or self._flat.device != dev:
+            self._flat = torch.empty(n, dtype=torch.float32, device=dev)
+        flat, off = self._flat, 0
+        for p in ps:
+            k = p.numel()
+            seg = flat[off:off + k]
+            if p.grad is None:
+                seg.zero_()          # ranks must agree on the bucket layout even if a rank has no grad for p
+            else:
+                # storage-order copy keeps channel-last planes cheap
+                seg.view(p.grad.shape if p.grad.is_contiguous() else (-1,)).copy_(
+                    p.grad if p.grad.is_contiguous() else p.grad.permute(*_storage_order(p.grad)).reshape(-1))
+            off += k
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / self.world)
+        off = 0
+        for p in ps:
+            k = p.numel()
+            if p.grad is not None:
+                seg = flat[off:off + k]
+                if p.grad.is_contiguous():
+                    p.grad.copy_(seg.view(p.grad.shape))
+                else:
+                    order = _storage_order(p.grad)
+                    p.grad.permute(*order).copy_(seg.view([p.grad.shape[i] for i in order]))
+            off += k
+
+    def sync_stats(self, radii, vsp_grad):
+        dist.all_reduce(radii, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vsp_grad, op=dist.ReduceOp.SUM)
+        vsp_grad.mul_(1.0 / self.world)
+        return radii, radii > 0, vsp_grad
+
+    def seed_for(self, iteration):
+        """Same random stream on every rank for the densification draw of this iteration."""
+        torch.manual_seed(self.seed * 1_000_003 + iteration)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(self.seed * 1_000_003 + iteration)
+
+
+def _storage_order(t):
+    """Dimension order that walks t's memory contiguously (largest stride first)."""
+    return sorted(range(t.dim()), key=lambda i: (-t.stride(i), i))
+
+
+def attach(trainer, rank, world, seed=6666):
+    trainer.dist = DistContext(rank, world, seed)
+    return trainer.dist

@@ -23,6 +23,7 @@ class Trainer:
         self.sync_every_step = sync_every_step
         self.ema_loss, self.ema_psnr = 0.0, 0.0
         self.last = {}
+        self.dist = None     # set by parallel.attach(): camera-batch shard, one camera per rank
 
     def _draw(self):
         cams = []
@@ -63,6 +64,10 @@ class Trainer:
         vsp_grad = torch.zeros_like(vsp_l[0])
         for v in vsp_l:
             vsp_grad = vsp_grad + v.grad
+        if self.dist is not None:
+            self.dist.sync_param_grads(g.optimizer)
+            radii, visibility, vsp_grad = self.dist.sync_stats(radii, vsp_grad)
+            self.dist.seed_for(iteration)
 
         with torch.no_grad():
             if self.sync_every_step:

@@ -1,0 +1,294 @@
+"""Imports the reference's OWN Python modules (from /root/reference, build container only) and writes golden
+input/output vectors to tests/golden/*.npz.  The reference source never enters this repo: only these vectors do.
+
+    python oracle/ref_harness.py            # regenerates every fixture
+
+Missing third-party modules the reference imports at module top but never uses on this path (tkinter, lpips,
+open3d, plyfile, simple_knn) are stubbed; `scene` is registered as a bare package so that scene/__init__.py
+(which drags in torchvision/cv2 dataset readers) is bypassed; device="cuda" is redirected to the CPU.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def setup():
+    assert os.path.isdir(REF), "the reference tree is only mounted in the build container"
+    sys.path.insert(0, REF)
+    _stub("tkinter", W=None)
+    _stub("lpips")
+    _stub("open3d")
+    _stub("plyfile", PlyData=object, PlyElement=object)
+    _stub("simple_knn")
+    _stub("simple_knn._C", distCUDA2=lambda pts: torch.ones(pts.shape[0]))
+    scene = types.ModuleType("scene")
+    scene.__path__ = [os.path.join(REF, "scene")]
+    sys.modules["scene"] = scene
+    # device="cuda" -> cpu
+    for fn in ("zeros", "ones", "empty", "tensor", "full", "rand", "randn", "arange", "zeros_like", "ones_like"):
+        orig = getattr(torch, fn)
+
+        def wrap(*a, __orig=orig, **k):
+            if "device" in k and str(k["device"]).startswith("cuda"):
+                k["device"] = "cpu"
+            return __orig(*a, **k)
+
+        setattr(torch, fn, wrap)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    _to = torch.nn.Module.to
+
+    def to(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+        return _to(self, *a, **k)
+
+    torch.nn.Module.to = to
+    torch.cuda.empty_cache = lambda: None
+
+
+class HP:  # reduced ModelHiddenParams (arguments/__init__.py:77-105 with the dnerf_default overlay, small planes)
+    net_width = 64; timebase_pe = 4; defor_depth = 0; posebase_pe = 10; scale_rotation_pe = 2; opacity_pe = 2
+    timenet_width = 64; timenet_output = 32; bounds = 1.6; plane_tv_weight = 0.0001; time_smoothness_weight = 0.01
+    l1_time_planes = 0.0001
+    kplanes_config = {'grid_dimensions': 2, 'input_coordinate_dim': 4, 'output_coordinate_dim': 32, 'resolution': [8, 8, 8, 5]}
+    multires = [1, 2]; no_dx = False; no_grid = False; no_ds = False; no_dr = False; no_do = True; no_dshs = True
+    empty_voxel = False; grid_pe = 0; static_mlp = False; apply_rotation = False
+
+
+def points(n, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([1.1, 1.3, 1.5])
+    pts[0] = torch.tensor([1.0, 1.2, 1.4])
+    pts[1] = torch.tensor([-1.0, -1.2, -1.4])
+    return pts
+
+
+def g1_hexplane():
+    from scene.hexplane import HexPlaneField
+    torch.manual_seed(0)
+    f = HexPlaneField(1.6, HP.kplanes_config, HP.multires)
+    f.set_aabb([1.0, 1.2, 1.4], [-1.0, -1.2, -1.4])
+    with torch.no_grad():
+        for gl in f.grids:
+            for p in gl:
+                p.add_(torch.randn_like(p) * 0.2)
+    pts = points(257)
+    w = torch.randn(257, f.feat_dim, generator=torch.Generator().manual_seed(3))
+    out = {"pts": pts.numpy(), "w": w.numpy(), "aabb": f.aabb.detach().numpy()}
+    for l, gl in enumerate(f.grids):
+        for i, p in enumerate(gl):
+            out[f"plane_{l}_{i}"] = p.detach().numpy()
+    for t in (0.0, 0.3, 1.0):
+        p = pts.clone().requires_grad_(True)
+        f.zero_grad()
+        feat = f(p, torch.full((257, 1), t))
+        (feat * w).sum().backward()
+        out[f"feat_t{t}"] = feat.detach().numpy()
+        out[f"dpts_t{t}"] = p.grad.numpy()
+        for l, gl in enumerate(f.grids):
+            for i, pl in enumerate(gl):
+                out[f"dplane_{l}_{i}_t{t}"] = pl.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g1_hexplane.npz"), **out)
+    return f
+
+
+def g2_deform():
+    from scene.deformation import deform_network
+    torch.manual_seed(7)
+    net = deform_network(HP)
+    net.deformation_net.set_aabb([1.0, 1.2, 1.4], [-1.0, -1.2, -1.4])
+    n = 129
+    g = torch.Generator().manual_seed(11)
+    xyz = points(n, 5)
+    scal = torch.randn(n, 3, generator=g)
+    rot = torch.randn(n, 4, generator=g)
+    opa = torch.randn(n, 1, generator=g)
+    shs = torch.randn(n, 16, 3, generator=g)
+    flow = torch.randn(n, 3, generator=g) * 1e-2
+    out = {"xyz": xyz.numpy(), "scaling": scal.numpy(), "rotation": rot.numpy(), "opacity": opa.numpy(), "shs": shs.numpy(),
+           "scene_flow": flow.numpy()}
+    for k, v in net.state_dict().items():
+        out["sd__" + k] = v.numpy()
+    ws = [torch.randn(n, d, generator=g) for d in (3, 3, 4)]
+    for wi, w in enumerate(ws):
+        out[f"w{wi}"] = w.numpy()
+    for frame_num, delta_scale, t in ((0, 0, 0.0), (7, 1, 0.4)):
+        x = xyz.clone().requires_grad_(True)
+        s = scal.clone().requires_grad_(True)
+        r = rot.clone().requires_grad_(True)
+        net.zero_grad()
+        pts, sc, ro, op, sh = net(x, s, r, opa, shs, torch.full((n, 1), t), flow, torch.tensor(frame_num), delta_scale)
+        ((pts * ws[0]).sum() + (sc * ws[1]).sum() + (ro * ws[2]).sum()).backward()
+        tag = f"f{frame_num}_d{delta_scale}"
+        out[f"pts_{tag}"], out[f"scales_{tag}"], out[f"rots_{tag}"] = pts.detach().numpy(), sc.detach().numpy(), ro.detach().numpy()
+        out[f"dxyz_{tag}"], out[f"dscal_{tag}"], out[f"drot_{tag}"] = x.grad.numpy(), s.grad.numpy(), r.grad.numpy()
+        assert torch.equal(op, opa) and torch.equal(sh, shs)      # no_do / no_dshs: passed through
+        for k, p in net.named_parameters():
+            out[f"grad_{tag}__{k}"] = np.zeros(0, np.float32) if p.grad is None else p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g2_deform.npz"), **out)
+
+
+def g3_loss():
+    from utils.loss_utils import l1_loss, ssim
+    from utils.image_utils import psnr
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(1, 3, 37, 53, generator=g)
+    b = torch.rand(1, 3, 37, 53, generator=g)
+    x = a.clone().requires_grad_(True)
+    l1, s = l1_loss(x, b), ssim(x, b)
+    (l1 + 0.2 * (1.0 - s)).backward()
+    np.savez_compressed(os.path.join(OUT, "g3_loss.npz"), img=a.numpy(), gt=b.numpy(), l1=l1.item(), ssim=s.item(),
+                        psnr=psnr(a, b).numpy(), dimg=x.grad.numpy())
+
+
+def g4_lr():
+    from utils.general_utils import get_expon_lr_func
+    steps = [0, 1, 100, 3000, 20000, 30000]
+    scheds = {"xyz": (1.6e-4 * 0.29, 1.6e-6 * 0.29, 0.01, 20000), "deformation": (1.6e-4 * 0.29, 1.6e-6 * 0.29, 0.01, 20000),
+              "grid": (1.6e-3 * 0.29, 1.6e-5 * 0.29, 0.01, 20000)}
+    out = {"steps": np.array(steps)}
+    for k, (a, b, m, mx) in scheds.items():
+        f = get_expon_lr_func(lr_init=a, lr_final=b, lr_delay_mult=m, max_steps=mx)
+        out[k] = np.array([f(s) for s in steps], np.float64)
+        out[k + "_args"] = np.array([a, b, m, mx])
+    np.savez_compressed(os.path.join(OUT, "g4_lr.npz"), **out)
+
+
+def g5_cameras():
+    from utils.graphics_utils import getWorld2View2, getProjectionMatrix
+    Rl = torch.load(os.path.join(REF, "test_trajectory", "side_R_list"), map_location="cpu")
+    tl = torch.load(os.path.join(REF, "test_trajectory", "side_t_list"), map_location="cpu")
+    out = {}
+    for k in (0, 17, 59):
+        R = np.asarray(Rl[k].cpu() if torch.is_tensor(Rl[k]) else Rl[k], np.float64).reshape(3, 3)
+        T = np.asarray(tl[k].cpu() if torch.is_tensor(tl[k]) else tl[k], np.float64).reshape(3)
+        out[f"R{k}"], out[f"T{k}"] = R, T
+        out[f"w2v{k}"] = getWorld2View2(R, T)
+        out[f"w2v_ts{k}"] = getWorld2View2(R, T, np.array([0.1, -0.2, 0.3]), 1.5)
+    import math
+    fx, fy = 2 * math.atan(960 / (2 * 582.69 * 960 / 540)), 2 * math.atan(540 / (2 * 582.69))
+    out["fov"] = np.array([fx, fy])
+    out["proj"] = getProjectionMatrix(0.01, 100.0, fx, fy).numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_cameras.npz"), **out)
+
+
+def g6_sh_cov():
+    from utils.sh_utils import eval_sh
+    from utils.general_utils import build_scaling_rotation, strip_symmetric, build_rotation
+    g = torch.Generator().manual_seed(4)
+    sh = torch.randn(64, 3, 16, generator=g)
+    d = torch.nn.functional.normalize(torch.randn(64, 3, generator=g))
+    out = {"sh": sh.numpy(), "dirs": d.numpy()}
+    for deg in range(4):
+        out[f"rgb{deg}"] = eval_sh(deg, sh, d).numpy()
+    s = torch.rand(64, 3, generator=g) + 0.1
+    q = torch.randn(64, 4, generator=g)
+    L = build_scaling_rotation(0.7 * s, q)
+    out.update(scaling=s.numpy(), rotation=q.numpy(), cov=strip_symmetric(L @ L.transpose(1, 2)).numpy(),
+               rotmat=build_rotation(q).numpy())
+    np.savez_compressed(os.path.join(OUT, "g6_sh_cov.npz"), **out)
+
+
+def g7_regulation(field):
+    from scene.regulation import compute_plane_smoothness
+    planes = [p for gl in field.grids for p in gl]
+    for p in planes:
+        p.grad = None
+    total = 0
+    for gl in field.grids:      # GaussianModel.compute_regulation(0.01, 1e-4, 1e-4), gaussian_model.py:730-769
+        total = total + 1e-4 * sum(compute_plane_smoothness(gl[i]) for i in (0, 1, 3))
+        total = total + 0.01 * sum(compute_plane_smoothness(gl[i]) for i in (2, 4, 5))
+        total = total + 1e-4 * sum(torch.abs(1 - gl[i]).mean() for i in (2, 4, 5))
+    total.backward()
+    out = {"value": total.item()}
+    for l, gl in enumerate(field.grids):
+        for i, p in enumerate(gl):
+            out[f"dplane_{l}_{i}"] = p.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g7_regulation.npz"), **out)
+
+
+def g8_densify():
+    """P=500 model: one Adam step with fixed grads, then densify / prune / reset_opacity (gaussian_model.py:362-365,
+    409-581,681-715)."""
+    from scene.gaussian_model import GaussianModel
+    import argparse
+    torch.manual_seed(21)
+    gm = GaussianModel(3, HP)
+    n = 500
+    g = torch.Generator().manual_seed(22)
+    P = torch.nn.Parameter
+    gm._xyz = P(torch.randn(n, 3, generator=g))
+    gm._features_dc = P(torch.randn(n, 1, 3, generator=g))
+    gm._features_rest = P(torch.randn(n, 15, 3, generator=g) * 0.1)
+    gm._scaling = P(torch.randn(n, 3, generator=g) * 0.7 - 3.0)
+    gm._rotation = P(torch.randn(n, 4, generator=g))
+    gm._opacity = P(torch.randn(n, 1, generator=g) * 2)
+    gm._scene_flow = torch.randn(n, 3, generator=g) * 1e-2
+    gm._deformation_table = torch.ones(n, dtype=torch.bool)
+    gm.max_radii2D = torch.zeros(n)
+    gm.spatial_lr_scale = 0.29
+    opt = argparse.Namespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                             position_lr_max_steps=20000, deformation_lr_init=1.6e-4, deformation_lr_final=1.6e-6,
+                             deformation_lr_delay_mult=0.01, grid_lr_init=1.6e-3, grid_lr_final=1.6e-5, feature_lr=0.0025,
+                             opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+    gm.training_setup(opt)
+    out = {k: getattr(gm, k).detach().numpy().copy() for k in ("_xyz", "_features_dc", "_features_rest", "_scaling",
+                                                                  "_rotation", "_opacity", "_scene_flow")}
+    grads = {}
+    for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+        p = getattr(gm, name)
+        p.grad = torch.randn(p.shape, generator=g) * 1e-3
+        grads[name] = p.grad.numpy().copy()
+    out.update({"grad" + k: v for k, v in grads.items()})
+    gm.optimizer.step()
+    out.update({"after_step" + k: getattr(gm, k).detach().numpy().copy() for k in grads})
+    vsp = torch.randn(n, 3, generator=g) * 4e-4
+    vis = torch.rand(n, generator=g) > 0.2
+    out["vsp"], out["vis"] = vsp.numpy(), vis.numpy()
+    gm.add_densification_stats(vsp, vis)
+    out["accum"], out["denom"] = gm.xyz_gradient_accum.numpy().copy(), gm.denom.numpy().copy()
+    torch.manual_seed(33)
+    gm.densify(2e-4, 0.005, 5.0, None, 5, 5)
+    out["dens_P"] = gm._xyz.shape[0]
+    for k in ("_xyz", "_features_dc", "_scaling", "_rotation", "_opacity", "_scene_flow"):
+        out["dens" + k] = getattr(gm, k).detach().numpy().copy()
+    st = gm.optimizer.state[gm._xyz]
+    out["dens_exp_avg_xyz"], out["dens_exp_avg_sq_xyz"] = st["exp_avg"].numpy().copy(), st["exp_avg_sq"].numpy().copy()
+    gm.max_radii2D = (torch.rand(gm._xyz.shape[0], generator=g) * 40)
+    out["maxr"] = gm.max_radii2D.numpy().copy()
+    gm.prune(2e-4, 0.005, 5.0, 20)
+    out["prune_P"] = gm._xyz.shape[0]
+    out["prune_xyz"] = gm._xyz.detach().numpy().copy()
+    gm.reset_opacity()
+    out["reset_opacity"] = gm._opacity.detach().numpy().copy()
+    st = gm.optimizer.state[gm._opacity]
+    out["reset_exp_avg_abs_sum"] = float(st["exp_avg"].abs().sum() + st["exp_avg_sq"].abs().sum())
+    np.savez_compressed(os.path.join(OUT, "g8_densify.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    setup()
+    field = g1_hexplane()
+    g2_deform()
+    g3_loss()
+    g4_lr()
+    g5_cameras()
+    g6_sh_cov()
+    g7_regulation(field)
+    g8_densify()
+    print("golden fixtures written to", OUT, sorted(os.listdir(OUT)))
