@@ -52,6 +52,12 @@ class MomAdamTensor(C.Structure):
                 ("bias_correction2_sqrt", C.c_float)]
 
 
+class MomDeformMLP(C.Structure):
+    _fields_ = [("W0", C.c_void_p), ("b0", C.c_void_p), ("W1", C.c_void_p * 3), ("b1", C.c_void_p * 3),
+                ("W2", C.c_void_p * 3), ("b2", C.c_void_p * 3), ("dW0", C.c_void_p), ("db0", C.c_void_p),
+                ("dW1", C.c_void_p * 3), ("db1", C.c_void_p * 3), ("dW2", C.c_void_p * 3), ("db2", C.c_void_p * 3)]
+
+
 class MomRegPlane(C.Structure):
     _fields_ = [("plane", C.c_void_p), ("grad", C.c_void_p), ("H", C.c_int), ("W", C.c_int), ("w_smooth", C.c_float),
                 ("w_l1", C.c_float), ("grad_scale", C.c_float)]
@@ -88,6 +94,11 @@ def _sig(lib):
     lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.mom_l1_loss.argtypes = [sz, vp, vp, vp, vp, vp]
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
+    lib.mom_deform_scratch_bytes.restype = sz
+    lib.mom_deform_scratch_bytes.argtypes = []
+    lib.mom_deform_prepare.argtypes = [C.POINTER(MomDeformMLP), vp, vp]
+    lib.mom_deform_forward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_profile_enable.argtypes = [i32, i32]
     lib.mom_profile_read.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), i32]
     lib.mom_profile_name.restype = C.c_char_p
@@ -107,6 +118,7 @@ EXPORTS = [
     "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
+    "mom_deform_scratch_bytes", "mom_deform_prepare", "mom_deform_forward", "mom_deform_backward",
 ]
 
 

@@ -103,6 +103,68 @@ def hexplane_features(xyz, time, aabb, planes_by_level):
     return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), *flat)
 
 
+# --------------------------------------------------------------------------- fused deformation MLP
+class DeformMLPFunction(torch.autograd.Function):
+    """(pts, scales, rots) = fused trunk + pos/scales/rotations heads + residual adds
+    (reference scene/deformation.py:97-135 with the shipped config).  Parameter order:
+    W0,b0, W1p,b1p,W2p,b2p, W1s,b1s,W2s,b2s, W1r,b1r,W2r,b2r."""
+
+    @staticmethod
+    def _desc(params, grads=None):
+        d = N.MomDeformMLP()
+        W0, b0, *rest = params
+        d.W0, d.b0 = W0.data_ptr(), b0.data_ptr()
+        for k in range(3):
+            W1, b1, W2, b2 = rest[4 * k:4 * k + 4]
+            d.W1[k], d.b1[k], d.W2[k], d.b2[k] = W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr()
+        if grads is not None:
+            gW0, gb0, *grest = grads
+            d.dW0, d.db0 = gW0.data_ptr(), gb0.data_ptr()
+            for k in range(3):
+                g = grest[4 * k:4 * k + 4]
+                d.dW1[k], d.db1[k], d.dW2[k], d.db2[k] = (t.data_ptr() for t in g)
+        return d
+
+    @staticmethod
+    def forward(ctx, feat, xyz, scaling, rotation, scene_flow, flow_coef, *params):
+        _need_cuda(feat, "deform_mlp")
+        lib = N.lib()
+        P = feat.shape[0]
+        ps = [p.detach().contiguous() for p in params]
+        feat_c = feat.detach().contiguous()
+        scratch = torch.empty(lib.mom_deform_scratch_bytes(), dtype=torch.uint8, device=feat.device)
+        d = DeformMLPFunction._desc(ps)
+        s = N.current_stream()
+        N.check(lib.mom_deform_prepare(C.byref(d), scratch.data_ptr(), s), "mom_deform_prepare")
+        pts = torch.empty_like(xyz)
+        sc = torch.empty_like(scaling)
+        ro = torch.empty_like(rotation)
+        xyz_c, scal_c, rot_c, flow_c = (t.detach().contiguous() for t in (xyz, scaling, rotation, scene_flow))
+        N.check(lib.mom_deform_forward(C.byref(d), P, feat_c.data_ptr(), xyz_c.data_ptr(), scal_c.data_ptr(), rot_c.data_ptr(),
+                                       flow_c.data_ptr(), float(flow_coef), pts.data_ptr(), sc.data_ptr(), ro.data_ptr(),
+                                       scratch.data_ptr(), s), "mom_deform_forward")
+        ctx.save_for_backward(feat_c, scratch, *ps)
+        return pts, sc, ro
+
+    @staticmethod
+    def backward(ctx, dpts, dsc, dro):
+        feat_c, scratch, *ps = ctx.saved_tensors
+        lib = N.lib()
+        P = feat_c.shape[0]
+        grads = [torch.zeros_like(p) for p in ps]
+        d = DeformMLPFunction._desc(ps, grads)
+        dpts, dsc, dro = dpts.contiguous(), dsc.contiguous(), dro.contiguous()
+        dfeat = torch.empty_like(feat_c)
+        N.check(lib.mom_deform_backward(C.byref(d), P, feat_c.data_ptr(), dpts.data_ptr(), dsc.data_ptr(), dro.data_ptr(),
+                                        dfeat.data_ptr(), scratch.data_ptr(), N.current_stream()), "mom_deform_backward")
+        # identity paths: pts = xyz + ..., scales = scaling + ..., rots = rotation + ...; scene_flow has no grad
+        return (dfeat, dpts, dsc, dro, None, None, *grads)
+
+
+def deform_mlp(feat, xyz, scaling, rotation, scene_flow, flow_coef, params):
+    return DeformMLPFunction.apply(feat, xyz, scaling, rotation, scene_flow, flow_coef, *params)
+
+
 # --------------------------------------------------------------------------- L1 + PSNR
 class L1LossFunction(torch.autograd.Function):
     @staticmethod
@@ -233,6 +295,7 @@ class _HipBackend:
     restatement here EXPLICITLY (oracle.torch_ref.TorchBackend); nothing falls back to it by itself."""
     name = "hip"
     hexplane_features = staticmethod(hexplane_features)
+    deform_mlp = staticmethod(deform_mlp)
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
     plane_regulation = staticmethod(plane_regulation)
     Adam = FusedAdam

@@ -78,8 +78,30 @@ class Deformation(nn.Module):
     def forward_static(self, rays_pts_emb):
         return rays_pts_emb[:, :3] + self.static_mlp(self.grid(rays_pts_emb[:, :3]))
 
+    def _fusable(self):
+        a = self.args
+        return (self.W == 64 and self.D == 0 and self.grid.feat_dim == 64 and self.grid_pe == 0 and not a.no_grid
+                and not a.static_mlp and not a.no_dx and not a.no_ds and not a.no_dr and a.no_do and a.no_dshs
+                and not a.apply_rotation)
+
+    def _fused_params(self):
+        ps = [self.feature_out[0].weight, self.feature_out[0].bias]
+        for head in (self.pos_deform, self.scales_deform, self.rotations_deform):
+            ps += [head[1].weight, head[1].bias, head[3].weight, head[3].bias]
+        return ps
+
     def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb,
                         scene_flow, frame_num, delta_scale):
+        if self._fusable():
+            # shipped configuration: HexPlane lookup + trunk + three heads + residuals as two fused HIP ops
+            from .. import ops
+            t = time_emb[:, :1] if torch.is_tensor(time_emb) else time_emb
+            feat = self.grid(rays_pts_emb[:, :3], t)
+            coef = delta_scale * frame_num
+            coef = float(coef) if not torch.is_tensor(coef) else float(coef.item())
+            pts, scales, rotations = ops.BACKEND.deform_mlp(feat, rays_pts_emb[:, :3], scales_emb[:, :3], rotations_emb[:, :4],
+                                                            scene_flow, coef, self._fused_params())
+            return pts, scales, rotations, opacity_emb[:, :1], shs_emb
         hidden = self.query_time(rays_pts_emb, scales_emb, rotations_emb, time_feature, time_emb)
         a = self.args
         mask = self.static_mlp(hidden) if a.static_mlp else None   # default: mask == 1 (deformation.py:103)

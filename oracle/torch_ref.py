@@ -108,3 +108,17 @@ class TorchBackend:
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
     plane_regulation = staticmethod(plane_regulation)
     Adam = torch.optim.Adam
+
+
+def deform_mlp(feat, xyz, scaling, rotation, scene_flow, flow_coef, params):
+    """Deformation.forward_dynamic's MLP part (scene/deformation.py:97-135, shipped config) as plain torch ops."""
+    W0, b0, *rest = params
+    hidden = F.linear(feat, W0, b0)
+    outs = []
+    for k in range(3):
+        W1, b1, W2, b2 = rest[4 * k:4 * k + 4]
+        outs.append(F.linear(torch.relu(F.linear(torch.relu(hidden), W1, b1)), W2, b2))
+    return xyz + (outs[0] + flow_coef * scene_flow), scaling + outs[1], rotation + outs[2]
+
+
+TorchBackend.deform_mlp = staticmethod(deform_mlp)
