@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmom4d.so")
+LIB_PATH = os.environ.get("MOM4D_LIB") or os.path.join(_HERE, "lib", "libmom4d.so")
 _lib = None
 
 MOM_OK, MOM_EINVAL, MOM_ELAUNCH, MOM_ECAPACITY = 0, -1, -2, -3
@@ -89,8 +89,11 @@ def _sig(lib):
     lib.mom_raster_backward.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, sz, vp, vp, vp, C.POINTER(MomRasterGrads), vp]
     lib.mom_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
-    lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp]
-    lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
+    lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
+    lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp, vp]
+    lib.mom_morton_order_scratch_bytes.restype = sz
+    lib.mom_morton_order_scratch_bytes.argtypes = [i32]
+    lib.mom_morton_order.argtypes = [i32, vp, vp, vp, vp]
     lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.mom_l1_loss.argtypes = [sz, vp, vp, vp, vp, vp]
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
@@ -118,7 +121,7 @@ EXPORTS = [
     "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
-    "mom_deform_scratch_bytes", "mom_deform_prepare", "mom_deform_forward", "mom_deform_backward",
+    "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_deform_scratch_bytes", "mom_deform_prepare", "mom_deform_forward", "mom_deform_backward",
 ]
 
 

@@ -357,6 +357,7 @@ deform_bwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
             }
             // output layer: db2, dW2 (half-wave reductions), then dH1 = relu'(h1) * W2^T dout in place of a1
             const float* __restrict__ W2 = pick(m.W2, head);
+#ifndef MOM_DBG_SKIP_DW2
 #pragma unroll
             for (int n = 0; n < 4; n++) {
                 if (n < nout) {   // wave-uniform
@@ -378,6 +379,7 @@ deform_bwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
                         }
                 }
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
@@ -402,9 +404,13 @@ deform_bwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
                 }
             // a1 now holds dH1
             __builtin_amdgcn_sched_barrier(0);
+#ifndef MOM_DBG_SKIP_BG
             bias_grad(lds, 1 + head, a1, lane);
+#endif
             __builtin_amdgcn_sched_barrier(0);
+#ifndef MOM_DBG_SKIP_WG
             weight_grad(lds, stage, 1 + head, a1, a0, lane);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             layer64(m.Wb + (1 + head) * kFragFloats, a1, dA0, lane);   // dA0 += W1^T dH1
             __builtin_amdgcn_sched_barrier(0);

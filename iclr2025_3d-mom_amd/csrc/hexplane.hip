@@ -73,6 +73,7 @@ struct HexArgs {
     float a0[3], a1[3];  // aabb rows exactly as the reference stores them (row 0 = xyz_max, row 1 = xyz_min)
     float time;
     const float* times;  // optional per-point timestamps [P]; null -> `time` for every point
+    const uint32_t* order;  // optional processing order (a permutation of 0..P-1, e.g. Morton order); null -> identity
 };
 
 __constant__ int kCombA[6] = {0, 0, 0, 1, 1, 2};
@@ -90,8 +91,9 @@ __global__ void __launch_bounds__(256) hexplane_fwd_kernel(HexArgs a, const floa
 {
     const int ch = threadIdx.x & 31;
     const long long unit = (long long)blockIdx.x * 8 + (threadIdx.x >> 5);
-    const int g = (int)(unit / a.levels), lvl = (int)(unit % a.levels);
-    if (g >= a.P) return;
+    const int gi = (int)(unit / a.levels), lvl = (int)(unit % a.levels);
+    if (gi >= a.P) return;
+    const int g = a.order ? (int)a.order[gi] : gi;   // spatially sorted processing order (speed only)
     float c[4];
     norm_coords(a, xyz, g, c);
     float prod = 1.f;
@@ -188,16 +190,166 @@ hexplane_bwd_kernel(HexArgs a, const float* __restrict__ xyz, const float* __res
     }
 }
 
+
+// ---- aggregated backward -------------------------------------------------------------------------------------
+// One timestamp for every point (the render() case).  Two structural facts cut the float-atomic traffic of the
+// generic kernel above (1.2 GB per call at 200k Gaussians, and worse, all of it for the space-time planes lands
+// on just two texel rows):
+//  * space-time planes (x,t) (y,t) (z,t): the t interpolation is the same for every point, so a workgroup sums
+//    S[ix][ch] = sum gv * wx in an LDS line per plane and adds wt0*S / wt1*S to the two global rows once at the end;
+//  * space planes: a half-wave walks a CONTIGUOUS chunk of the (spatially sorted) processing order and keeps, per
+//    plane and corner, a pending texel row in registers; consecutive points that fall on the same texel are summed
+//    there and reach memory as ONE 128-byte atomic row.
+__device__ __forceinline__ int time_sample(float c, int size, int& i0, int& i1, float& w0, float& w1)
+{
+    float gm;
+    const float v = unnorm_clip(c, size, gm);
+    const int x0 = (int)floorf(v), x1 = x0 + 1;
+    w0 = (float)x1 - v;
+    w1 = v - (float)x0;
+    i0 = (x0 >= 0 && x0 < size) ? x0 : -1;
+    i1 = (x1 >= 0 && x1 < size) ? x1 : -1;
+    return 0;
+}
+
+__global__ void __launch_bounds__(256)
+hexplane_bwd_agg_kernel(HexArgs a, int chunk, const float* __restrict__ xyz, const float* __restrict__ dfeat, float* __restrict__ dxyz)
+{
+    extern __shared__ float s_line[];   // [3 space-time planes][Wmax][32]
+    const int ch = threadIdx.x & 31;
+    const int hw = (blockIdx.x * 256 + threadIdx.x) >> 5;          // half-wave id
+    const int begin = hw * chunk, end = min(a.P, begin + chunk);
+    for (int lvl = 0; lvl < a.levels; lvl++) {
+        const int Wx = a.res[lvl][0], Wy = a.res[lvl][1], Wz = a.res[lvl][2], Wt = a.res[lvl][3];
+        const int line_off[3] = {0, Wx * 32, (Wx + Wy) * 32};      // planes 2 (x,t), 4 (y,t), 5 (z,t)
+        const int line_total = (Wx + Wy + Wz) * 32;
+        __syncthreads();
+        for (int i = threadIdx.x; i < line_total; i += 256) s_line[i] = 0.f;
+        __syncthreads();
+        // the shared t interpolation
+        int t0, t1;
+        float wt0, wt1;
+        time_sample(a.time, Wt, t0, t1, wt0, wt1);
+        // pending rows: 3 space planes x 4 corners
+        int pid[3][4];
+        float pacc[3][4];
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) { pid[p][c] = -1; pacc[p][c] = 0.f; }
+        float* gsp[3] = {a.grads[lvl][0], a.grads[lvl][1], a.grads[lvl][3]};
+        for (int gi = begin; gi < end; gi++) {
+            const int g = a.order ? (int)a.order[gi] : gi;
+            float c[4];
+            norm_coords(a, xyz, g, c);
+            PlaneSample s[6];
+            float v[6], t00[6], t01[6], t10[6], t11[6];
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+                const int ca = kCombA[p], cb = kCombB[p];
+                s[p] = make_sample(c[ca], c[cb], a.res[lvl][ca], a.res[lvl][cb]);
+                const float* __restrict__ pl = a.planes[lvl][p];
+                t00[p] = s[p].i00 >= 0 ? pl[(size_t)s[p].i00 * 32 + ch] : 0.f;
+                t01[p] = s[p].i01 >= 0 ? pl[(size_t)s[p].i01 * 32 + ch] : 0.f;
+                t10[p] = s[p].i10 >= 0 ? pl[(size_t)s[p].i10 * 32 + ch] : 0.f;
+                t11[p] = s[p].i11 >= 0 ? pl[(size_t)s[p].i11 * 32 + ch] : 0.f;
+                float acc = 0.f;
+                acc += t00[p] * s[p].w00;
+                acc += t01[p] * s[p].w01;
+                acc += t10[p] * s[p].w10;
+                acc += t11[p] * s[p].w11;
+                v[p] = acc;
+            }
+            const float go = dfeat[(size_t)g * (a.levels * 32) + lvl * 32 + ch];
+            float pre[7], suf[7];
+            pre[0] = 1.f;
+#pragma unroll
+            for (int p = 0; p < 6; p++) pre[p + 1] = pre[p] * v[p];
+            suf[6] = 1.f;
+#pragma unroll
+            for (int p = 5; p >= 0; p--) suf[p] = suf[p + 1] * v[p];
+            float gc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < 6; p++) {
+                const float gv = go * pre[p] * suf[p + 1];
+                const int ca = kCombA[p], cb = kCombB[p];
+                if (cb == 3) {
+                    // space-time plane: W axis = space coordinate ca, H axis = t (shared)
+                    const int li = p == 2 ? 0 : (p == 4 ? 1 : 2);
+                    const float wx0 = (float)(s[p].ixn + 1) - s[p].ix, wx1 = s[p].ix - (float)s[p].ixn;
+                    const int Wd = a.res[lvl][ca];
+                    if (s[p].ixn >= 0 && s[p].ixn < Wd) atomicAdd(&s_line[line_off[li] + s[p].ixn * 32 + ch], gv * wx0);
+                    if (s[p].ixn + 1 >= 0 && s[p].ixn + 1 < Wd) atomicAdd(&s_line[line_off[li] + (s[p].ixn + 1) * 32 + ch], gv * wx1);
+                } else {
+                    const int si = p == 0 ? 0 : (p == 1 ? 1 : 2);   // planes 0 (x,y), 1 (x,z), 3 (y,z)
+                    const int ids[4] = {s[p].i00, s[p].i01, s[p].i10, s[p].i11};
+                    const float ws[4] = {s[p].w00, s[p].w01, s[p].w10, s[p].w11};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (ids[k] == pid[si][k]) {
+                            pacc[si][k] += gv * ws[k];
+                        } else {
+                            if (pid[si][k] >= 0) atomicAdd(&gsp[si][(size_t)pid[si][k] * 32 + ch], pacc[si][k]);
+                            pid[si][k] = ids[k];
+                            pacc[si][k] = gv * ws[k];
+                        }
+                    }
+                }
+                // grid gradient (same expressions as the generic kernel)
+                const float x0 = (float)s[p].ixn, y0 = (float)s[p].iyn, x1 = x0 + 1.f, y1 = y0 + 1.f;
+                float gix = 0.f, giy = 0.f;
+                gix -= t00[p] * (y1 - s[p].iy) * gv;
+                giy -= t00[p] * (x1 - s[p].ix) * gv;
+                gix += t01[p] * (y1 - s[p].iy) * gv;
+                giy -= t01[p] * (s[p].ix - x0) * gv;
+                gix -= t10[p] * (s[p].iy - y0) * gv;
+                giy += t10[p] * (x1 - s[p].ix) * gv;
+                gix += t11[p] * (s[p].iy - y0) * gv;
+                giy += t11[p] * (s[p].ix - x0) * gv;
+                if (ca < 3) gc[ca] += gix * s[p].gx_mul;
+                if (cb < 3) gc[cb] += giy * s[p].gy_mul;
+            }
+            if (dxyz) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const float tot = half_wave_sum(gc[k]) * (2.0f / (a.a1[k] - a.a0[k]));
+                    if (ch == 0) atomicAdd(&dxyz[3 * g + k], tot);
+                }
+            }
+        }
+        // drain the pending rows
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (pid[p][c] >= 0) atomicAdd(&gsp[p][(size_t)pid[p][c] * 32 + ch], pacc[p][c]);
+        __syncthreads();
+        // S lines -> the two global rows t0 / t1 of each space-time plane
+        float* gtp[3] = {a.grads[lvl][2], a.grads[lvl][4], a.grads[lvl][5]};
+        const int Wl[3] = {Wx, Wy, Wz};
+#pragma unroll
+        for (int li = 0; li < 3; li++) {
+            for (int i = threadIdx.x; i < Wl[li] * 32; i += 256) {
+                const float sv = s_line[line_off[li] + i];
+                if (sv != 0.f) {
+                    if (t0 >= 0) atomicAdd(&gtp[li][(size_t)t0 * Wl[li] * 32 + i], sv * wt0);
+                    if (t1 >= 0) atomicAdd(&gtp[li][(size_t)t1 * Wl[li] * 32 + i], sv * wt1);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
-extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time, float* feat,
-                                    mom_stream_t stream)
+extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
+                                    const uint32_t* order, float* feat, mom_stream_t stream)
 {
     if (!hp || hp->channels != 32 || hp->levels < 1 || hp->levels > 4 || P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!xyz || !feat) return MOM_EINVAL;
     HexArgs a;
-    a.P = P; a.levels = hp->levels; a.time = time; a.times = times;
+    a.P = P; a.levels = hp->levels; a.time = time; a.times = times; a.order = order;
     for (int l = 0; l < 4; l++)
         for (int k = 0; k < 4; k++) a.res[l][k] = hp->res[l][k];
     for (int l = 0; l < 4; l++)
@@ -210,13 +362,13 @@ extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* x
 }
 
 extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
-                                     const float* dfeat, float* dxyz, mom_stream_t stream)
+                                     const uint32_t* order, const float* dfeat, float* dxyz, mom_stream_t stream)
 {
     if (!hp || hp->channels != 32 || hp->levels < 1 || hp->levels > 4 || P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!xyz || !dfeat) return MOM_EINVAL;
     HexArgs a;
-    a.P = P; a.levels = hp->levels; a.time = time; a.times = times;
+    a.P = P; a.levels = hp->levels; a.time = time; a.times = times; a.order = order;
     for (int l = 0; l < 4; l++)
         for (int k = 0; k < 4; k++) a.res[l][k] = hp->res[l][k];
     for (int l = 0; l < 4; l++)
@@ -228,6 +380,19 @@ extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* 
     for (int k = 0; k < 3; k++) { a.a0[k] = hp->aabb[k]; a.a1[k] = hp->aabb[3 + k]; }
     const long long units = (long long)P * hp->levels;
     MomProfScope ps(MOM_P_HEX_BWD, (hipStream_t)stream);
+    // aggregated path: one shared timestamp and space-time lines that fit in LDS
+    int wmax = 0;
+    for (int l = 0; l < hp->levels; l++) {
+        const int w = hp->res[l][0] + hp->res[l][1] + hp->res[l][2];
+        if (w > wmax) wmax = w;
+    }
+    const size_t lds_bytes = (size_t)wmax * 32 * sizeof(float);
+    if (!times && lds_bytes <= 64 * 1024) {
+        const int blocks = 512;                       // persistent: 4096 half-waves, contiguous chunks of the order
+        const int chunk = (P + blocks * 8 - 1) / (blocks * 8);
+        hipLaunchKernelGGL(hexplane_bwd_agg_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, a, chunk, xyz, dfeat, dxyz);
+        return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+    }
     hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)((units + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a, xyz, dfeat, dxyz);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -274,3 +274,39 @@ extern "C" int mom_knn_mean_dist2(int P, const float* points, float* mean_dist2,
     hipLaunchKernelGGL(box_mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, vals[cur], boxes, mean_dist2);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
+
+// Spatial (Morton) processing order of a point set: the first half of SimpleKNN::knn on its own.  Used to walk the
+// Gaussians in a cache- and atomics-friendly order in the HexPlane kernels (results never depend on it).
+extern "C" size_t mom_morton_order_scratch_bytes(int P) { return mom_knn_scratch_bytes(P); }
+extern "C" int mom_morton_order(int P, const float* points, uint32_t* order, void* scratch, mom_stream_t stream)
+{
+    if (P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!points || !order || !scratch) return MOM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)P;
+    const int nb = (int)((n + kSortItems - 1) / kSortItems);
+    char* base = mom_align_ptr(scratch);
+    float* bb = (float*)base; base += mom_align_up(64);
+    unsigned* keys[2]; unsigned* vals[2];
+    keys[0] = (unsigned*)base; base += mom_align_up(n * 4);
+    keys[1] = (unsigned*)base; base += mom_align_up(n * 4);
+    vals[0] = (unsigned*)base; base += mom_align_up(n * 4);
+    vals[1] = (unsigned*)base; base += mom_align_up(n * 4);
+    unsigned* counts = (unsigned*)base;
+    if (hipMemsetAsync(bb, 0, 64, s) != hipSuccess) return MOM_ELAUNCH;
+    int rb = (P + 255) / 256;
+    if (rb > 1024) rb = 1024;
+    hipLaunchKernelGGL(bbox_kernel, dim3(rb), dim3(256), 0, s, P, points, bb);
+    hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, bb, keys[0], vals[0]);
+    int cur = 0;
+    for (int shift = 0; shift < 32; shift += 8) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(256), 0, s, P, nb, shift, keys[cur], counts);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, 256 * nb, counts);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(256), 0, s, P, nb, shift, keys[cur], vals[cur], counts, keys[cur ^ 1],
+                           vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    if (hipMemcpyAsync(order, vals[cur], n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return MOM_ELAUNCH;
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

@@ -64,7 +64,7 @@ class HexPlaneFunction(torch.autograd.Function):
     """features[P, L*32] = HexPlaneField(xyz, t) (reference scene/hexplane.py:160-183)."""
 
     @staticmethod
-    def forward(ctx, xyz, time, aabb, n_levels, *planes):
+    def forward(ctx, xyz, time, aabb, n_levels, order, *planes):
         _need_cuda(xyz, "hexplane")
         lv = [list(planes[6 * l:6 * l + 6]) for l in range(n_levels)]
         d, keep = _hexplane_desc(lv, aabb)
@@ -74,10 +74,11 @@ class HexPlaneFunction(torch.autograd.Function):
         # one timestamp per camera (a python float) or per-point timestamps (a tensor, as the reference passes)
         times = time.detach().reshape(-1).contiguous().float() if torch.is_tensor(time) else None
         tval = 0.0 if times is not None else float(time)
+        optr = None if order is None else order.data_ptr()
         N.check(N.lib().mom_hexplane_forward(C.byref(d), P, xyz_c.data_ptr(), None if times is None else times.data_ptr(),
-                                             tval, feat.data_ptr(), N.current_stream()), "mom_hexplane_forward")
+                                             tval, optr, feat.data_ptr(), N.current_stream()), "mom_hexplane_forward")
         ctx.save_for_backward(xyz_c, aabb, *planes)
-        ctx.times, ctx.time, ctx.n_levels = times, tval, n_levels
+        ctx.times, ctx.time, ctx.n_levels, ctx.order = times, tval, n_levels, order
         return feat
 
     @staticmethod
@@ -91,16 +92,31 @@ class HexPlaneFunction(torch.autograd.Function):
         dxyz = torch.zeros_like(xyz_c) if ctx.needs_input_grad[0] else None
         dfeat = dfeat.contiguous()
         N.check(N.lib().mom_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(),
-                                              None if ctx.times is None else ctx.times.data_ptr(), ctx.time, dfeat.data_ptr(),
+                                              None if ctx.times is None else ctx.times.data_ptr(), ctx.time,
+                                              None if ctx.order is None else ctx.order.data_ptr(), dfeat.data_ptr(),
                                               None if dxyz is None else dxyz.data_ptr(), N.current_stream()),
                 "mom_hexplane_backward")
         flat = [g for level in grads for g in level]
-        return (dxyz, None, None, None, *flat)
+        return (dxyz, None, None, None, None, *flat)
 
 
-def hexplane_features(xyz, time, aabb, planes_by_level):
+def hexplane_features(xyz, time, aabb, planes_by_level, order=None):
     flat = [p for level in planes_by_level for p in level]
-    return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), *flat)
+    return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), order, *flat)
+
+
+def morton_order(xyz):
+    """uint32 permutation that walks the points along a Morton curve (int32 tensor of the same bits)."""
+    _need_cuda(xyz, "morton_order")
+    lib = N.lib()
+    pts = xyz.detach().contiguous().float()
+    P = pts.shape[0]
+    order = torch.empty(P, dtype=torch.int32, device=pts.device)
+    if P:
+        scratch = torch.empty(lib.mom_morton_order_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
+        N.check(lib.mom_morton_order(P, pts.data_ptr(), order.data_ptr(), scratch.data_ptr(), N.current_stream()),
+                "mom_morton_order")
+    return order
 
 
 # --------------------------------------------------------------------------- fused deformation MLP
@@ -295,6 +311,7 @@ class _HipBackend:
     restatement here EXPLICITLY (oracle.torch_ref.TorchBackend); nothing falls back to it by itself."""
     name = "hip"
     hexplane_features = staticmethod(hexplane_features)
+    morton_order = staticmethod(morton_order)
     deform_mlp = staticmethod(deform_mlp)
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
     plane_regulation = staticmethod(plane_regulation)

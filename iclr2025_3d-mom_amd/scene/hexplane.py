@@ -50,6 +50,7 @@ class HexPlaneField(nn.Module):
         self.concat_features = True
         self.grids = nn.ModuleList()
         self.feat_dim = 0
+        self._order, self._order_age = None, 0   # cached spatial processing order (speed only, never a result)
         for res in self.multiscale_res_multipliers:
             config = self.grid_config[0].copy()
             # multi-resolution on the three space axes only (hexplane.py:131-134)
@@ -73,7 +74,21 @@ class HexPlaneField(nn.Module):
         """[N,3] points (+ [N,1] timestamps, or one python float for all points) -> [N, feat_dim]."""
         pts = pts.reshape(-1, pts.shape[-1])
         levels = [list(g) for g in self.grids]
-        return ops.BACKEND.hexplane_features(pts, timestamps, self.aabb, levels)
+        return ops.BACKEND.hexplane_features(pts, timestamps, self.aabb, levels, order=self._processing_order(pts))
+
+    REORDER_EVERY = 64
+
+    def _processing_order(self, pts):
+        """Morton order of the points, refreshed when their number changes (densify / prune) and every
+        REORDER_EVERY calls (positions drift slowly).  Only the speed of the fused kernels depends on it."""
+        if not hasattr(ops.BACKEND, "morton_order") or pts.shape[0] == 0:
+            return None
+        if self._order is None or self._order.shape[0] != pts.shape[0] or self._order.device != pts.device \
+                or self._order_age >= self.REORDER_EVERY:
+            self._order = ops.BACKEND.morton_order(pts)
+            self._order_age = 0
+        self._order_age += 1
+        return self._order
 
     def forward(self, pts: torch.Tensor, timestamps=None):
         return self.get_density(pts, timestamps)

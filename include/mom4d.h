@@ -162,11 +162,17 @@ typedef struct MomHexPlane {
 } MomHexPlane;
 /* feat [P, levels*32] row-major.  times: optional per-point timestamps [P]; null -> `time` for all points
  * (render() uses one timestamp per camera). */
-int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time, float* feat,
-                         mom_stream_t stream);
+int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
+                         const uint32_t* order, float* feat, mom_stream_t stream);
 /* dfeat [P, levels*32]; plane gradients accumulate into hp->grads; dxyz [P,3] (may be null) is ACCUMULATED into */
 int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
-                          const float* dfeat, float* dxyz, mom_stream_t stream);
+                          const uint32_t* order, const float* dfeat, float* dxyz, mom_stream_t stream);
+/* `order` (both calls, may be null = identity): a permutation of 0..P-1 giving the order in which points are
+ * processed, e.g. mom_morton_order(xyz).  It never changes a result (float atomics aside); walking the points in a
+ * spatially sorted order lets the backward sum consecutive points that hit the same texel in registers and issue one
+ * atomic row for the run. */
+size_t mom_morton_order_scratch_bytes(int P);
+int mom_morton_order(int P, const float* points /* [P,3] */, uint32_t* order /* [P] */, void* scratch, mom_stream_t stream);
 
 /* ---- fused multi-tensor Adam (torch.optim.Adam, amsgrad=False, weight_decay=0) -----------
  * One launch updates every listed tensor: exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;

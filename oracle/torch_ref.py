@@ -31,7 +31,7 @@ def grid_sample_wrapper(grid, coords):
     return out.view(B, C, n).transpose(-1, -2).squeeze()
 
 
-def hexplane_features(pts, timestamps, aabb, planes_by_level):
+def hexplane_features(pts, timestamps, aabb, planes_by_level, order=None):
     """HexPlaneField.get_density (scene/hexplane.py:160-175) + interpolate_ms_features (:73-106)."""
     pts = normalize_aabb(pts, aabb)
     if not torch.is_tensor(timestamps):

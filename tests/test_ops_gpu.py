@@ -60,9 +60,25 @@ def test_hexplane_forward_backward_parity(res, multires, t):
         for a, b in zip(gl, gc):
             assert a.grad.shape == b.grad.shape
             close(a.grad.cpu().numpy(), b.grad.numpy())
+    # the aggregated backward walks a Morton order; with the order disabled (identity) results agree to rounding
+    fg.zero_grad()
+    fg._order, fg._order_age = torch.arange(257, dtype=torch.int32, device="cuda"), -10**9
+    p2 = pts.cuda().requires_grad_(True)
+    (fg(p2, t) * w.cuda()).sum().backward()
+    close(p2.grad.cpu().numpy(), p_cpu.grad.numpy())
+    for gl, gc in zip(fg.grids, planes_cpu):
+        for a, b in zip(gl, gc):
+            close(a.grad.cpu().numpy(), b.grad.numpy())
     # per-point timestamps (the form the reference passes) give the same result as the scalar
-    feat2 = fg(p_gpu.detach(), torch.full((257, 1), t, device="cuda"))
+    fg.zero_grad()
+    p3 = pts.cuda().requires_grad_(True)
+    feat2 = fg(p3, torch.full((257, 1), t, device="cuda"))
     np.testing.assert_array_equal(feat2.detach().cpu().numpy(), feat.detach().cpu().numpy())
+    (feat2 * w.cuda()).sum().backward()        # generic (non-aggregated) backward kernel
+    close(p3.grad.cpu().numpy(), p_cpu.grad.numpy())
+    for gl, gc in zip(fg.grids, planes_cpu):
+        for a, b in zip(gl, gc):
+            close(a.grad.cpu().numpy(), b.grad.numpy())
 
 
 def test_fused_adam_matches_torch_adam_incl_tiny_eps():
@@ -188,3 +204,22 @@ def test_fused_deform_mlp_forward_backward(P):
     for a, b in zip(gp, gp_ref):
         rel = np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-30)
         assert rel <= 2e-3, (a.shape, rel)
+
+
+def test_morton_order_is_a_permutation_and_matches_oracle_sort():
+    rng = np.random.default_rng(0)
+    pts = (rng.normal(size=(5000, 3)) * [1.0, 2.0, 0.5] + [0.3, -0.2, 3.0]).astype(np.float32)
+    order = ops.morton_order(torch.from_numpy(pts).cuda()).cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(5000))
+    # Morton codes as simple_knn.cu:45-61 computes them (bounding box seeded with 0), stable sort
+    lo, hi = np.minimum(pts.min(0), 0).astype(np.float32), np.maximum(pts.max(0), 0).astype(np.float32)
+    q = (((pts - lo) / (hi - lo)) * np.float32(1023)).astype(np.uint32)
+
+    def prep(x):
+        x = (x | (x << 16)) & 0x030000FF
+        x = (x | (x << 8)) & 0x0300F00F
+        x = (x | (x << 4)) & 0x030C30C3
+        x = (x | (x << 2)) & 0x09249249
+        return x
+    code = prep(q[:, 0]) | (prep(q[:, 1]) << 1) | (prep(q[:, 2]) << 2)
+    np.testing.assert_array_equal(order, np.argsort(code, kind="stable"))
