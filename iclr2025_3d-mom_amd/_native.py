@@ -97,11 +97,10 @@ def _sig(lib):
     lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
     lib.mom_l1_loss.argtypes = [sz, vp, vp, vp, vp, vp]
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
-    lib.mom_deform_scratch_bytes.restype = sz
-    lib.mom_deform_scratch_bytes.argtypes = []
-    lib.mom_deform_prepare.argtypes = [C.POINTER(MomDeformMLP), vp, vp]
     lib.mom_deform_forward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
-    lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_deform_backward_scratch_bytes.restype = sz
+    lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
+    lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_profile_enable.argtypes = [i32, i32]
     lib.mom_profile_read.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), i32]
     lib.mom_profile_name.restype = C.c_char_p
@@ -121,7 +120,7 @@ EXPORTS = [
     "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
-    "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_deform_scratch_bytes", "mom_deform_prepare", "mom_deform_forward", "mom_deform_backward",
+    "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward",
 ]
 
 

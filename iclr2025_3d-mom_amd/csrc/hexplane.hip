@@ -15,6 +15,7 @@
 // border, nw/ne/sw/se weights, accumulation order nw,ne,sw,se) so that results agree with the
 // reference's torch ops to rounding.
 #include "mom_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -388,7 +389,11 @@ extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* 
     }
     const size_t lds_bytes = (size_t)wmax * 32 * sizeof(float);
     if (!times && lds_bytes <= 64 * 1024) {
-        const int blocks = 512;                       // persistent: 4096 half-waves, contiguous chunks of the order
+        static int blocks = 0;                        // persistent half-waves walking contiguous chunks of the order
+        if (!blocks) {
+            const char* e = getenv("MOM_HEX_BLOCKS");
+            blocks = e ? atoi(e) : 512;
+        }
         const int chunk = (P + blocks * 8 - 1) / (blocks * 8);
         hipLaunchKernelGGL(hexplane_bwd_agg_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, a, chunk, xyz, dfeat, dxyz);
         return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;

@@ -148,31 +148,33 @@ class DeformMLPFunction(torch.autograd.Function):
         P = feat.shape[0]
         ps = [p.detach().contiguous() for p in params]
         feat_c = feat.detach().contiguous()
-        scratch = torch.empty(lib.mom_deform_scratch_bytes(), dtype=torch.uint8, device=feat.device)
         d = DeformMLPFunction._desc(ps)
         s = N.current_stream()
-        N.check(lib.mom_deform_prepare(C.byref(d), scratch.data_ptr(), s), "mom_deform_prepare")
         pts = torch.empty_like(xyz)
         sc = torch.empty_like(scaling)
         ro = torch.empty_like(rotation)
         xyz_c, scal_c, rot_c, flow_c = (t.detach().contiguous() for t in (xyz, scaling, rotation, scene_flow))
+        need_bwd = any(ctx.needs_input_grad)
+        a0 = torch.empty_like(feat_c) if need_bwd else None
         N.check(lib.mom_deform_forward(C.byref(d), P, feat_c.data_ptr(), xyz_c.data_ptr(), scal_c.data_ptr(), rot_c.data_ptr(),
                                        flow_c.data_ptr(), float(flow_coef), pts.data_ptr(), sc.data_ptr(), ro.data_ptr(),
-                                       scratch.data_ptr(), s), "mom_deform_forward")
-        ctx.save_for_backward(feat_c, scratch, *ps)
+                                       None if a0 is None else a0.data_ptr(), s), "mom_deform_forward")
+        ctx.save_for_backward(feat_c, a0 if a0 is not None else feat_c, *ps)
         return pts, sc, ro
 
     @staticmethod
     def backward(ctx, dpts, dsc, dro):
-        feat_c, scratch, *ps = ctx.saved_tensors
+        feat_c, a0, *ps = ctx.saved_tensors
         lib = N.lib()
         P = feat_c.shape[0]
         grads = [torch.zeros_like(p) for p in ps]
         d = DeformMLPFunction._desc(ps, grads)
         dpts, dsc, dro = dpts.contiguous(), dsc.contiguous(), dro.contiguous()
         dfeat = torch.empty_like(feat_c)
-        N.check(lib.mom_deform_backward(C.byref(d), P, feat_c.data_ptr(), dpts.data_ptr(), dsc.data_ptr(), dro.data_ptr(),
-                                        dfeat.data_ptr(), scratch.data_ptr(), N.current_stream()), "mom_deform_backward")
+        scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=feat_c.device)
+        N.check(lib.mom_deform_backward(C.byref(d), P, feat_c.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(),
+                                        dro.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), N.current_stream()),
+                "mom_deform_backward")
         # identity paths: pts = xyz + ..., scales = scaling + ..., rots = rotation + ...; scene_flow has no grad
         return (dfeat, dpts, dsc, dro, None, None, *grads)
 

@@ -366,8 +366,10 @@ class GaussianModel:
         self._opacity = self.replace_tensor_to_optimizer(new, "opacity")["opacity"]
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        # masked accumulate == the reference's boolean-mask indexing (:713-715) without nonzero()'s host sync
+        m = update_filter.unsqueeze(-1).to(self.xyz_gradient_accum.dtype)
+        self.xyz_gradient_accum += torch.norm(viewspace_point_tensor[:, :2], dim=-1, keepdim=True) * m
+        self.denom += m
 
     @torch.no_grad()
     def update_deformation_table(self, threshold):

@@ -79,7 +79,9 @@ class Trainer:
             self.last = {"loss": loss.detach(), "l1": Ll1.detach(), "points": g._xyz.shape[0]}
 
             if iteration < opt.densify_until_iter:
-                g.max_radii2D[visibility] = torch.max(g.max_radii2D[visibility], radii[visibility].float())
+                # same values as the reference's boolean-mask indexing (train_4DGS.py:266), without the host sync a
+                # nonzero() costs: invisible entries keep their old value
+                g.max_radii2D = torch.where(visibility, torch.max(g.max_radii2D, radii.float()), g.max_radii2D)
                 g.add_densification_stats(vsp_grad, visibility)
                 if self.stage == "coarse":
                     op_thr, de_thr = opt.opacity_threshold_coarse, opt.densify_grad_threshold_coarse

@@ -213,24 +213,23 @@ int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom
 /* ---- fused deformation MLP (scene/deformation.py:53-65,97-135; W = 64, defor_depth = 0, heads pos/scales/rot) ----
  *   h0 = W0 feat + b0 ;  o_k = W2_k relu(W1_k relu(h0) + b1_k) + b2_k  for k in {pos, scales, rot}
  *   pts = xyz + o_pos + flow_coef * scene_flow ; scales = scaling + o_scales ; rots = rotation + o_rot
- * (flow_coef = delta_scale * frame_num, deformation.py:114).  Weights are nn.Linear tensors ([out,in] row-major).
- * mom_deform_prepare must run (on the same stream) after every weight update and before forward/backward: it
- * re-packs the four 64x64 matrices into MFMA fragment order inside `scratch` (mom_deform_scratch_bytes()). */
+ * (flow_coef = delta_scale * frame_num, deformation.py:114).  Weights are nn.Linear tensors ([out,in] row-major);
+ * both kernels are persistent and keep all four 64x64 matrices in LDS. */
 typedef struct MomDeformMLP {
     const float *W0, *b0;            /* feature_out.0: [64,64], [64] */
     const float *W1[3], *b1[3];      /* {pos,scales,rotations}_deform.1: [64,64], [64] */
     const float *W2[3], *b2[3];      /* {pos,scales,rotations}_deform.3: [3|3|4,64], [3|3|4] */
     float *dW0, *db0, *dW1[3], *db1[3], *dW2[3], *db2[3];   /* backward only: ACCUMULATED into (+=) */
 } MomDeformMLP;
-size_t mom_deform_scratch_bytes(void);
-int mom_deform_prepare(const MomDeformMLP* w, void* scratch, mom_stream_t stream);
+/* a0_save (may be null for inference): [P,64], receives relu(h0) for the backward pass */
 int mom_deform_forward(const MomDeformMLP* w, int P, const float* feat /* [P,64] */, const float* xyz, const float* scaling,
                        const float* rotation, const float* scene_flow, float flow_coef, float* pts, float* scales, float* rots,
-                       void* scratch, mom_stream_t stream);
+                       float* a0_save, mom_stream_t stream);
 /* d{pts,scales,rots}: gradients of the three outputs; writes dfeat [P,64]; weight/bias gradients accumulate into w->d*.
  * (The identity paths d xyz += dpts etc. are the caller's.) */
-int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* dpts, const float* dscales,
-                        const float* drots, float* dfeat, void* scratch, mom_stream_t stream);
+size_t mom_deform_backward_scratch_bytes(int P);   /* 4 x [P,64] floats: the per-layer pre-activation gradients */
+int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
+                        const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream);
 
 const char* mom_version(void);
 
