@@ -26,7 +26,7 @@ CONFIGS = {
 }
 
 
-def build_state(cfg, device, backend_install=None):
+def build_state(cfg, device, fused=False):
     import torch
     pkg = importlib.import_module("iclr2025_3d-mom_amd")
     A = importlib.import_module("iclr2025_3d-mom_amd.arguments")
@@ -38,7 +38,7 @@ def build_state(cfg, device, backend_install=None):
     g = S.GaussianModel(lp.sh_degree, hp, device=device)
     scene.init_gaussians(g)
     scene.make_trained_like(g)
-    trainer = T.Trainer(scene, g, op, hp, pp, stage="fine", delta_scale=1, sync_every_step=False)
+    trainer = T.Trainer(scene, g, op, hp, pp, stage="fine", delta_scale=1, sync_every_step=False, fused=fused)
     return scene, g, trainer, op
 
 
@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-mode", default="async", choices=["async", "exact"])
     ap.add_argument("--roofline-kernel", default="render_bwd")
+    ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
+                    help="fused: explicit launch sequence (fused_step.py); autograd: render() + loss.backward()")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -90,7 +92,7 @@ def main():
         dist.init_process_group("nccl")
     dev = torch.device("cuda", local)
     DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
-    scene, g, trainer, op = build_state(cfg, dev)
+    scene, g, trainer, op = build_state(cfg, dev, fused=(a.path == "fused"))
     cams = trainer.cams
     par = None
     if world > 1:
@@ -105,8 +107,8 @@ def main():
 
     DGR.set_sync_mode("exact")
     one(0)                                                   # sizes the binning buffers
-    R = DGR.last_num_rendered()
-    if a.sync_mode == "async":
+    R = DGR.last_num_rendered() if trainer.fused is None else int(trainer.fused.nr_host[0])
+    if a.sync_mode == "async" and trainer.fused is None:
         DGR.set_sync_mode("async", capacity_hint=int(R * 1.6) + 65536)
     for i in range(a.warmup):
         one(i + 1)
@@ -135,7 +137,8 @@ def main():
         "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "gaussians": cfg["P"], "frames": cfg["F"], "width": cfg["W"],
-                   "height": cfg["H"], "instances_R": int(DGR.last_num_rendered() or 0), "sh_degree": 3, "batch_size": 1,
+                   "height": cfg["H"], "instances_R": int((DGR.last_num_rendered() if trainer.fused is None else trainer.fused.nr_host[0]) or 0),
+                   "sh_degree": 3, "step_path": a.path, "batch_size": 1,
                    "lambda_dssim": 0, "parallelism": f"camera-batch x{world}" if world > 1 else "single",
                    "host_sync": a.sync_mode, "final_loss": float(loss)},
     }

@@ -23,7 +23,7 @@ class MomError(RuntimeError):
 
 class MomRasterArgs(C.Structure):
     _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
-                ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p),
+                ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p),
                 ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
                 ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("scale_modifier", C.c_float),
@@ -32,7 +32,7 @@ class MomRasterArgs(C.Structure):
 
 class MomRasterGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D",
-                                          "dL_dsh", "dL_dscales", "dL_drotations")]
+                                          "dL_dsh", "dL_dsh_rest", "dL_dscales", "dL_drotations")]
 
 
 class MomRasterLayout(C.Structure):
@@ -101,6 +101,8 @@ def _sig(lib):
     lib.mom_deform_backward_scratch_bytes.restype = sz
     lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
     lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_activations_forward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_activations_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_profile_enable.argtypes = [i32, i32]
     lib.mom_profile_read.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), i32]
     lib.mom_profile_name.restype = C.c_char_p
@@ -120,7 +122,7 @@ EXPORTS = [
     "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
-    "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward",
+    "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward",
 ]
 
 

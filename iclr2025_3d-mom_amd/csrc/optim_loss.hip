@@ -129,6 +129,42 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __rest
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(out, tot);
 }
 
+
+// ---------------------------------------------------------------- activations (exp / normalize / sigmoid)
+__global__ void __launch_bounds__(256) act_fwd_kernel(int P, const float* __restrict__ sr, const float* __restrict__ rr,
+                                                     const float* __restrict__ orr, float* __restrict__ s, float* __restrict__ r,
+                                                     float* __restrict__ o)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s[3 * i + k] = expf(sr[3 * i + k]);
+    const float4 q = *reinterpret_cast<const float4*>(rr + 4 * i);
+    const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    *reinterpret_cast<float4*>(r + 4 * i) = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    o[i] = 1.0f / (1.0f + expf(-orr[i]));
+}
+__global__ void __launch_bounds__(256)
+act_bwd_kernel(int P, const float* __restrict__ s, const float* __restrict__ rr, const float* __restrict__ o,
+               const float* __restrict__ ds, const float* __restrict__ dr, const float* __restrict__ dop, float* __restrict__ dsr,
+               float* __restrict__ drr, float* __restrict__ dor)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dsr[3 * i + k] = ds[3 * i + k] * s[3 * i + k];
+    const float4 q = *reinterpret_cast<const float4*>(rr + 4 * i);
+    const float4 g = *reinterpret_cast<const float4*>(dr + 4 * i);
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    const float n = fmaxf(nrm, 1e-12f);
+    const float4 u = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+    // d/dq (q/|q|) : (g - u (u.g)) / |q|   (zero through the clamp when |q| < eps, as ATen does)
+    const float dot = (nrm >= 1e-12f) ? (u.x * g.x + u.y * g.y + u.z * g.z + u.w * g.w) : 0.f;
+    *reinterpret_cast<float4*>(drr + 4 * i) = make_float4((g.x - u.x * dot) / n, (g.y - u.y * dot) / n, (g.z - u.z * dot) / n, (g.w - u.w * dot) / n);
+    const float y = o[i];
+    dor[i] = dop[i] * ((1.0f - y) * y);
+}
+
 }  // namespace
 
 extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double beta2, double eps, mom_stream_t stream)
@@ -188,5 +224,27 @@ extern "C" int mom_plane_regulation(const MomRegPlane* planes, int count, float*
     a.count = count;
     MomProfScope ps(MOM_P_REG, (hipStream_t)stream);
     if (blocks) hipLaunchKernelGGL(plane_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, value);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+extern "C" int mom_activations_forward(int P, const float* scales_raw, const float* rots_raw, const float* opac_raw, float* scales,
+                                       float* rots, float* opac, mom_stream_t stream)
+{
+    if (P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!scales_raw || !rots_raw || !opac_raw || !scales || !rots || !opac) return MOM_EINVAL;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, scales_raw, rots_raw, opac_raw, scales,
+                       rots, opac);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+extern "C" int mom_activations_backward(int P, const float* scales, const float* rots_raw, const float* opac, const float* dscales,
+                                        const float* drots, const float* dopac, float* dscales_raw, float* drots_raw,
+                                        float* dopac_raw, mom_stream_t stream)
+{
+    if (P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!scales || !rots_raw || !opac || !dscales || !drots || !dopac || !dscales_raw || !drots_raw || !dopac_raw) return MOM_EINVAL;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, scales, rots_raw, opac, dscales, drots,
+                       dopac, dscales_raw, drots_raw, dopac_raw);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -124,6 +124,7 @@ int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, vo
     if (!geom || !binning || !image || !radii || !dL_dout_color || !gr) return MOM_EINVAL;
     if (!gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dmeans3D || !gr->dL_dcov3D) return MOM_EINVAL;
     if (a->M > 0 && !a->colors_precomp && !gr->dL_dsh) return MOM_EINVAL;
+    if (a->shs_rest && !gr->dL_dsh_rest) return MOM_EINVAL;
     if (a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return MOM_EINVAL;
     GeomView g; ImageView im; BinView b;
     geom_view(mom_align_ptr(geom), a->P, &g);

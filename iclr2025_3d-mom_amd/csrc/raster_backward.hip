@@ -44,14 +44,14 @@ __constant__ float bSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
 
 struct BwdArgs {
     int P, D, M, W, H;
-    const float *means3D, *shs, *scales, *rotations, *cov3D;  // cov3D = precomputed input or geom cov3D
+    const float *means3D, *shs, *shs_rest, *scales, *rotations, *cov3D;  // cov3D = precomputed input or geom cov3D
     const float *view, *proj, *cam;
     const int* radii;
     const uchar4* clamped;
     const float* gacc;
     float scale_modifier, tan_fovx, tan_fovy, h_x, h_y;
     int colors_from_sh;
-    float *dmeans2D, *dcolors, *dopacity, *dmeans3D, *dcov3D, *dsh, *dscales, *drot;
+    float *dmeans2D, *dcolors, *dopacity, *dmeans3D, *dcov3D, *dsh, *dsh_rest, *dscales, *drot;
 };
 
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
@@ -78,7 +78,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
-    float* dsh = a.dsh ? a.dsh + (size_t)idx * a.M * 3 : nullptr;
+    // SH gradient rows: one [P,M,3] tensor, or DC and rest apart (dshr[3*i+c] valid for i >= 1)
+    const bool split = a.dsh_rest != nullptr;
+    float* dsh = a.dsh ? a.dsh + (size_t)idx * (split ? 1 : a.M) * 3 : nullptr;
+    float* dshr = split ? a.dsh_rest + (size_t)idx * (a.M - 1) * 3 - 3 : dsh;
 
     if (vis) {
         const float mx = a.means3D[3 * idx], my = a.means3D[3 * idx + 1], mz = a.means3D[3 * idx + 2];
@@ -164,13 +167,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
             const float dox = mx - cam[0], doy = my - cam[1], doz = mz - cam[2];
             const float len = sqrtf(dox * dox + doy * doy + doz * doz);
             const float x = dox / len, y = doy / len, z = doz / len;
-            const float* sh = a.shs + (size_t)idx * a.M * 3;
+            const float* sh0 = a.shs + (size_t)idx * (a.shs_rest ? 1 : a.M) * 3;
+            const float* sh = a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0;
             const uchar4 cl = a.clamped[idx];
             const float dRGB[3] = {cl.x ? 0.f : ga[6], cl.y ? 0.f : ga[7], cl.z ? 0.f : ga[8]};
             float ddir[3] = {0.f, 0.f, 0.f};
 #define SH(i, c) sh[(i) * 3 + (c)]
-#define DSH(i, s) { const float s__ = (s); dsh[(i) * 3 + 0] = s__ * dRGB[0]; dsh[(i) * 3 + 1] = s__ * dRGB[1]; dsh[(i) * 3 + 2] = s__ * dRGB[2]; }
-            DSH(0, bSH_C0);
+#define DSH(i, s) { const float s__ = (s); dshr[(i) * 3 + 0] = s__ * dRGB[0]; dshr[(i) * 3 + 1] = s__ * dRGB[1]; dshr[(i) * 3 + 2] = s__ * dRGB[2]; }
+            dsh[0] = bSH_C0 * dRGB[0]; dsh[1] = bSH_C0 * dRGB[1]; dsh[2] = bSH_C0 * dRGB[2];
             if (a.D > 0) {
                 DSH(1, -bSH_C1 * y);
                 DSH(2, bSH_C1 * z);
@@ -220,7 +224,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
             }
             // coefficients above the active degree receive zero gradient
             const int used = (a.D + 1) * (a.D + 1);
-            for (int i = used; i < a.M; i++) { dsh[i * 3 + 0] = 0.f; dsh[i * 3 + 1] = 0.f; dsh[i * 3 + 2] = 0.f; }
+            for (int i = used; i < a.M; i++) { dshr[i * 3 + 0] = 0.f; dshr[i * 3 + 1] = 0.f; dshr[i * 3 + 2] = 0.f; }
 #undef SH
 #undef DSH
             // through the normalisation of the view direction (auxiliary.h:107-117)
@@ -268,7 +272,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
         }
     }
     if (dsh && !(vis && a.colors_from_sh)) {
-        for (int i = 0; i < a.M * 3; i++) dsh[i] = 0.f;
+        dsh[0] = dsh[1] = dsh[2] = 0.f;
+        for (int i = 3; i < a.M * 3; i++) dshr[i] = 0.f;
     }
 
 #pragma unroll
@@ -291,7 +296,7 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
 {
     BwdArgs b;
     b.P = a->P; b.D = a->D; b.M = a->M; b.W = a->W; b.H = a->H;
-    b.means3D = a->means3D; b.shs = a->shs; b.scales = a->scales; b.rotations = a->rotations;
+    b.means3D = a->means3D; b.shs = a->shs; b.shs_rest = a->shs_rest; b.scales = a->scales; b.rotations = a->rotations;
     b.cov3D = a->cov3D_precomp ? a->cov3D_precomp : g.cov3D;
     b.view = a->viewmatrix; b.proj = a->projmatrix; b.cam = a->campos;
     b.radii = radii; b.clamped = g.clamped; b.gacc = g.gacc;
@@ -300,7 +305,7 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
     b.h_x = a->W / (2.0f * a->tan_fovx);
     b.colors_from_sh = (a->colors_precomp == nullptr && a->shs != nullptr && gr->dL_dsh != nullptr) ? 1 : 0;
     b.dmeans2D = gr->dL_dmeans2D; b.dcolors = gr->dL_dcolors; b.dopacity = gr->dL_dopacity; b.dmeans3D = gr->dL_dmeans3D;
-    b.dcov3D = gr->dL_dcov3D; b.dsh = gr->dL_dsh; b.dscales = a->scales ? gr->dL_dscales : nullptr;
+    b.dcov3D = gr->dL_dcov3D; b.dsh = gr->dL_dsh; b.dsh_rest = a->shs_rest ? gr->dL_dsh_rest : nullptr; b.dscales = a->scales ? gr->dL_dscales : nullptr;
     b.drot = a->scales ? gr->dL_drotations : nullptr;
     MomProfScope ps(MOM_P_PRE_BWD, s);
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a->P + 255) / 256), dim3(256), 0, s, b);

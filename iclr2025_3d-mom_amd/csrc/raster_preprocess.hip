@@ -44,7 +44,7 @@ __constant__ float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.457
 
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
-    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *cam;  // device pointers, [16] [16] [3]
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
 };
@@ -135,11 +135,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             dx = dx / len; dy = dy / len; dz = dz / len;
-            const float* sh = a.shs + (size_t)idx * a.M * 3;
+            // coefficient i of this Gaussian: one [P,M,3] tensor, or DC and rest stored apart
+            const float* sh0 = a.shs + (size_t)idx * (a.shs_rest ? 1 : a.M) * 3;
+            const float* sh = a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0;   // sh[3*i+c] valid for i >= 1
             float res[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                float v = kSH_C0 * sh[c];
+                float v = kSH_C0 * sh0[c];
                 if (a.D > 0) {
                     const float x = dx, y = dy, z = dz;
                     v = v - kSH_C1 * y * sh[3 + c] + kSH_C1 * z * sh[6 + c] - kSH_C1 * x * sh[9 + c];
@@ -197,7 +199,7 @@ int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* ra
     p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
     p.gx = (a->W + MOM_TILE - 1) / MOM_TILE;
     p.gy = (a->H + MOM_TILE - 1) / MOM_TILE;
-    p.means3D = a->means3D; p.shs = a->shs; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
+    p.means3D = a->means3D; p.shs = a->shs; p.shs_rest = a->shs_rest; p.colors_precomp = a->colors_precomp; p.opacities = a->opacities;
     p.scales = a->scales; p.rotations = a->rotations; p.cov3D_precomp = a->cov3D_precomp;
     p.scale_modifier = a->scale_modifier; p.tan_fovx = a->tan_fovx; p.tan_fovy = a->tan_fovy;
     // rasterizer_impl.cu:223-224

@@ -1,0 +1,190 @@
+"""One fine-stage training iteration as an explicit sequence of ~25 libmom4d launches -- no autograd graph, no
+per-op tensor allocation, no host synchronisation.
+
+It computes exactly what `train.Trainer.step` computes through `render()` + `loss.backward()` (the reference's
+train_4DGS.py:149-297 with batch_size 1, stage "fine", lambda_dssim 0, the shipped deformation config) and leaves the
+same `.grad` tensors behind, so the optimizer step, the densification statistics and everything downstream are shared
+with the autograd path.  `tests/test_fused_step_gpu.py` checks the two paths against each other.
+
+Order of launches: hexplane_fwd -> deform_fwd -> activations_fwd -> preprocess / binning / sort / render_fwd -> l1 ->
+render_bwd / preprocess_bwd -> activations_bwd -> deform_bwd (dx, dw) -> hexplane_bwd -> plane_reg -> adam.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+from . import ops
+from .diff_gaussian_rasterization import _C as RC
+
+
+class FusedStep:
+    def __init__(self, gaussians, opt, hyper, background):
+        self.g, self.opt, self.hyper, self.bg = gaussians, opt, hyper, background
+        dn = gaussians._deformation.deformation_net
+        if not dn._fusable():
+            raise N.MomError("FusedStep needs the shipped deformation configuration (W=64, D=0, no_do, no_dshs)")
+        self.P = -1
+        self.lib = N.lib()
+        self.last = {}
+
+    # ------------------------------------------------------------------ buffers (re-made when P changes)
+    def _ensure(self, P, W, H, dev):
+        if P == self.P and getattr(self, "_wh", None) == (W, H):
+            return
+        self.P, self._wh = P, (W, H)
+        f = dict(dtype=torch.float32, device=dev)
+        e = lambda *s: torch.empty(*s, **f)
+        self.feat, self.a0, self.dfeat = e(P, 64), e(P, 64), e(P, 64)
+        self.pts, self.sc_d, self.rot_d = e(P, 3), e(P, 3), e(P, 4)
+        self.sc, self.rot, self.op = e(P, 3), e(P, 4), e(P, 1)
+        self.color, self.depth = e(3, H, W), e(1, H, W)
+        self.radii = torch.empty(P, dtype=torch.int32, device=dev)
+        self.geom = torch.empty(self.lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
+        self.img = torch.empty(self.lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        self.nr_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.cap = 0
+        self.binning = None
+        self.dimg, self.sums = e(3, H, W), e(2)
+        self.g2d, self.gcol, self.gop_act, self.gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 6)
+        self.gsc_act, self.grot_act = e(P, 3), e(P, 4)
+        # parameter gradients (persist across steps; .grad points at them)
+        self.gxyz, self.gdc, self.grest = e(P, 3), e(P, 1, 3), e(P, 15, 3)
+        self.gsc, self.grot, self.gop = e(P, 3), e(P, 4), e(P, 1)
+        self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+        self.regval = e(1)
+
+    def _deform_grads(self):
+        """Flat zero-able gradient storage for the deformation field (planes channel-last + live MLP tensors)."""
+        dn = self.g._deformation.deformation_net
+        planes = [p for lv in dn.grid.grids for p in lv]
+        mlp = dn._fused_params()
+        key = tuple(p.data_ptr() for p in planes + mlp)
+        if getattr(self, "_dg_key", None) != key:
+            n = sum(p.numel() for p in planes + mlp)
+            self._dg_flat = torch.zeros(n, dtype=torch.float32, device=planes[0].device)
+            off, self._dg_planes, self._dg_mlp = 0, [], []
+            for p in planes:       # same channel-last strides as the parameter
+                st = ops.plane_storage(p)
+                v = self._dg_flat[off:off + p.numel()].view(st.shape).permute(2, 0, 1).unsqueeze(0)
+                self._dg_planes.append(v)
+                off += p.numel()
+            for p in mlp:
+                self._dg_mlp.append(self._dg_flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            self._dg_key = key
+        return planes, mlp
+
+    # ------------------------------------------------------------------ one iteration (forward + backward)
+    def forward_backward(self, cam, delta_scale=1):
+        g, lib, s = self.g, self.lib, N.current_stream()
+        dev = g._xyz.device
+        P = g._xyz.shape[0]
+        W, H = int(cam.image_width), int(cam.image_height)
+        self._ensure(P, W, H, dev)
+        view, proj, campos, gt = cam.device_tensors(dev)
+        dn = g._deformation.deformation_net
+        field = dn.grid
+        planes, mlp = self._deform_grads()
+        self._dg_flat.zero_()
+        xyz, scal, rot, opac = g._xyz.detach(), g._scaling.detach(), g._rotation.detach(), g._opacity.detach()
+        flow = g._scene_flow if g._scene_flow.is_contiguous() else g._scene_flow.contiguous()
+        for t in (xyz, scal, rot, opac, g._features_dc, g._features_rest):
+            assert t.is_contiguous()
+        time = float(cam.time)
+        order = field._processing_order(xyz)
+        optr = None if order is None else order.data_ptr()
+
+        # ---- deformation field
+        levels = [list(lv) for lv in field.grids]
+        gl, k = [], 0
+        for lv in levels:
+            gl.append(self._dg_planes[k:k + 6])
+            k += 6
+        hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in levels], field.aabb, gl)
+        N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.feat.data_ptr(), s), "hexplane_fwd")
+        md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], self._dg_mlp)
+        coef = float(delta_scale * cam.frame_num)
+        N.check(lib.mom_deform_forward(C.byref(md), P, self.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                       flow.data_ptr(), coef, self.pts.data_ptr(), self.sc_d.data_ptr(),
+                                       self.rot_d.data_ptr(), self.a0.data_ptr(), s), "deform_fwd")
+        N.check(lib.mom_activations_forward(P, self.sc_d.data_ptr(), self.rot_d.data_ptr(), opac.data_ptr(), self.sc.data_ptr(),
+                                            self.rot.data_ptr(), self.op.data_ptr(), s), "act_fwd")
+        # ---- rasterizer forward (async: capacity from the previous iterations, checked below)
+        a = N.MomRasterArgs()
+        a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H
+        a.background, a.means3D = self.bg.data_ptr(), self.pts.data_ptr()
+        a.shs, a.shs_rest = g._features_dc.data_ptr(), g._features_rest.data_ptr()
+        a.colors_precomp, a.opacities = None, self.op.data_ptr()
+        a.scales, a.rotations, a.cov3D_precomp = self.sc.data_ptr(), self.rot.data_ptr(), None
+        a.viewmatrix, a.projmatrix, a.campos = view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+        a.scale_modifier = 1.0
+        a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        a.prefiltered, a.debug = 0, 0
+        # the previous iteration's instance count / overflow flag are long complete: read them without blocking
+        prev_R = int(self.nr_host[0])
+        if int(self.status_host[0]) & 1:
+            raise N.MomError(f"binning capacity {self.cap} overflowed (count {prev_R}); re-run this iteration")
+        N.check(lib.mom_raster_forward_geometry(C.byref(a), self.geom.data_ptr(), self.img.data_ptr(), self.radii.data_ptr(),
+                                                self.nr_dev.data_ptr(), self.nr_host.data_ptr(), s), "raster_geometry")
+        if self.cap == 0:                       # first call: size exactly (one sync)
+            torch.cuda.current_stream().synchronize()
+            prev_R = int(self.nr_host[0])
+        want = int(prev_R * 1.5) + 65536
+        if self.binning is None or want > self.cap or want < self.cap // 4:
+            self.cap = want
+            self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, self.cap), dtype=torch.uint8, device=dev)
+        N.check(lib.mom_raster_forward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
+                                              self.img.data_ptr(), self.color.data_ptr(), self.depth.data_ptr(),
+                                              self.nr_dev[1:].data_ptr(), s), "raster_render")
+        self.status_host.copy_(self.nr_dev[1:], non_blocking=True)
+        # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
+        n = self.color.numel()
+        N.check(lib.mom_l1_loss(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
+        # ---- rasterizer backward
+        gr = N.MomRasterGrads()
+        gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = self.g2d.data_ptr(), self.gcol.data_ptr(), self.gop_act.data_ptr()
+        gr.dL_dmeans3D, gr.dL_dcov3D = self.gxyz.data_ptr(), self.gcov.data_ptr()
+        gr.dL_dsh, gr.dL_dsh_rest = self.gdc.data_ptr(), self.grest.data_ptr()
+        gr.dL_dscales, gr.dL_drotations = self.gsc_act.data_ptr(), self.grot_act.data_ptr()
+        N.check(lib.mom_raster_backward(C.byref(a), self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
+                                        self.cap, self.img.data_ptr(), self.dimg.data_ptr(), None, C.byref(gr), s), "raster_bwd")
+        N.check(lib.mom_activations_backward(P, self.sc.data_ptr(), self.rot_d.data_ptr(), self.op.data_ptr(),
+                                             self.gsc_act.data_ptr(), self.grot_act.data_ptr(), self.gop_act.data_ptr(),
+                                             self.gsc.data_ptr(), self.grot.data_ptr(), self.gop.data_ptr(), s), "act_bwd")
+        # ---- deformation backward: pts = xyz + dx(...) so d xyz starts as d pts (already in gxyz); the HexPlane adds its share
+        N.check(lib.mom_deform_backward(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
+                                        self.gsc.data_ptr(), self.grot.data_ptr(), self.dfeat.data_ptr(),
+                                        self.dh_scratch.data_ptr(), s), "deform_bwd")
+        N.check(lib.mom_hexplane_backward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.dfeat.data_ptr(),
+                                          self.gxyz.data_ptr(), s), "hexplane_bwd")
+        # ---- plane regularisers (value + gradient added into the plane gradients)
+        hy = self.hyper
+        reg = None
+        if hy.time_smoothness_weight != 0:
+            arr = (N.MomRegPlane * len(planes))()
+            for i, p in enumerate(planes):
+                st, gs = ops.plane_storage(p.detach()), ops.plane_storage(self._dg_planes[i])
+                arr[i].plane, arr[i].grad = st.data_ptr(), gs.data_ptr()
+                arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+                tplane = (i % 6) in (2, 4, 5)
+                arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
+                arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
+                arr[i].grad_scale = 1.0
+            N.check(lib.mom_plane_regulation(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
+            reg = self.regval
+        # ---- hand the gradients to the parameters
+        for p, gbuf in ((g._xyz, self.gxyz), (g._features_dc, self.gdc), (g._features_rest, self.grest), (g._scaling, self.gsc),
+                        (g._rotation, self.grot), (g._opacity, self.gop)):
+            p.grad = gbuf
+        for p, gbuf in zip(planes, self._dg_planes):
+            p.grad = gbuf
+        for p, gbuf in zip(mlp, self._dg_mlp):
+            p.grad = gbuf
+        l1 = self.sums[0] / n
+        loss = l1 if reg is None else l1 + reg[0]
+        self.last = {"l1": l1, "loss": loss, "mse_sum": self.sums[1], "n": n}
+        return loss, self.radii, self.g2d

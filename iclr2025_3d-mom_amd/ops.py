@@ -261,6 +261,11 @@ def _dense(t):
     return True
 
 
+def _same_layout(a, b):
+    """Same shape and same strides on every dimension that has more than one element."""
+    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam (amsgrad=False, weight_decay=0, maximize=False) whose step() is ONE HIP launch over all
     parameters with a gradient.  State layout ('step', 'exp_avg', 'exp_avg_sq') and param_groups are those of
@@ -291,7 +296,7 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] += 1
                 step = float(st["step"])
                 g = p.grad
-                if g.stride() != p.stride() or not _dense(p):
+                if not _same_layout(g, p) or not _dense(p):
                     raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
                 t = N.MomAdamTensor()
                 t.param, t.grad = p.data_ptr(), g.data_ptr()

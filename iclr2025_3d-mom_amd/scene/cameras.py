@@ -34,8 +34,9 @@ class Camera(nn.Module):
         """(view, full_proj, camera_center[, gt image]) staged on `device` once -- the reference re-uploads the three
         matrices and the ground-truth image every iteration (gaussian_renderer/__init__.py:49-52, train_4DGS.py:194)."""
         if self._dev_cache is None or self._dev_cache[0].device != torch.device(device):
-            self._dev_cache = (self.world_view_transform.to(device), self.full_proj_transform.to(device),
-                               self.camera_center.to(device), self.original_image.to(device))
+            # contiguous: world_view_transform is a transposed view, and the C ABI takes raw pointers
+            self._dev_cache = (self.world_view_transform.to(device).contiguous(), self.full_proj_transform.to(device).contiguous(),
+                               self.camera_center.to(device).contiguous(), self.original_image.to(device).contiguous())
         return self._dev_cache
 
 

@@ -130,7 +130,7 @@ class GaussianModel:
         self._deformation_table = torch.gt(torch.ones((n,), device=dev), 0)
         if scene_flow is None:
             scene_flow = torch.load(os.path.join(os.path.dirname(TrainData_path), 'scene_flow.pth'), map_location="cpu")
-        flow = scene_flow.T.float().to(dev) * flow_scale
+        flow = (scene_flow.T.float().to(dev) * flow_scale).contiguous()
         print("flow_scale: ", flow_scale)
         self._scene_flow = flow.detach().requires_grad_(False)
 

@@ -12,7 +12,7 @@ from .utils.loss_utils import l1_loss, psnr_from_last_l1, ssim
 
 class Trainer:
     def __init__(self, scene, gaussians, opt, hyper, pipe, stage="fine", delta_scale=1, white_background=False,
-                 sync_every_step=True):
+                 sync_every_step=True, fused=False):
         self.scene, self.g, self.opt, self.hyper, self.pipe, self.stage = scene, gaussians, opt, hyper, pipe, stage
         self.delta_scale = delta_scale
         dev = gaussians._xyz.device
@@ -24,6 +24,11 @@ class Trainer:
         self.ema_loss, self.ema_psnr = 0.0, 0.0
         self.last = {}
         self.dist = None     # set by parallel.attach(): camera-batch shard, one camera per rank
+        # fused=True: the iteration runs as an explicit launch sequence (fused_step.py) instead of render()+autograd
+        self.fused = None
+        if fused and stage == "fine" and opt.lambda_dssim == 0 and opt.batch_size == 1:
+            from .fused_step import FusedStep
+            self.fused = FusedStep(gaussians, opt, hyper, self.background)
 
     def _draw(self):
         cams = []
@@ -39,6 +44,8 @@ class Trainer:
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         cams = cams or self._draw()
+        if self.fused is not None and len(cams) == 1:
+            return self._step_fused(iteration, cams[0])
         images, gts, radii_l, vis_l, vsp_l = [], [], [], [], []
         for cam in cams:
             pkg = render(cam, g, self.pipe, self.background, stage=self.stage, cam_type=self.scene.dataset_type,
@@ -77,6 +84,26 @@ class Trainer:
                 self.ema_loss = 0.4 * loss.item() + 0.6 * self.ema_loss
                 self.ema_psnr = 0.4 * float(psnr_from_last_l1()) + 0.6 * self.ema_psnr
             self.last = {"loss": loss.detach(), "l1": Ll1.detach(), "points": g._xyz.shape[0]}
+        return self._after_backward(iteration, loss.detach(), radii, visibility, vsp_grad)
+
+    def _step_fused(self, iteration, cam):
+        with torch.no_grad():
+            loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale)
+            visibility = radii > 0
+            if self.dist is not None:
+                self.dist.sync_param_grads(self.g.optimizer)
+                radii, visibility, vsp_grad = self.dist.sync_stats(radii.clone(), vsp_grad.clone())
+                self.dist.seed_for(iteration)
+            if self.sync_every_step:
+                if torch.isnan(loss).any():
+                    raise FloatingPointError("loss is nan")
+                self.ema_loss = 0.4 * loss.item() + 0.6 * self.ema_loss
+            self.last = {"loss": loss, "l1": self.fused.last["l1"], "points": self.g._xyz.shape[0]}
+        return self._after_backward(iteration, loss, radii, visibility, vsp_grad)
+
+    def _after_backward(self, iteration, loss, radii, visibility, vsp_grad):
+        g, opt = self.g, self.opt
+        with torch.no_grad():
 
             if iteration < opt.densify_until_iter:
                 # same values as the reference's boolean-mask indexing (train_4DGS.py:266), without the host sync a
@@ -102,4 +129,4 @@ class Trainer:
             if iteration < opt.iterations:
                 g.optimizer.step()
                 g.optimizer.zero_grad(set_to_none=True)
-        return loss.detach()
+        return loss

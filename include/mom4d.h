@@ -52,7 +52,10 @@ typedef struct MomRasterArgs {
     int W, H;              /* image size in pixels */
     const float* background;     /* [3] */
     const float* means3D;        /* [P,3] */
-    const float* shs;            /* [P,M,3] or null */
+    const float* shs;            /* [P,M,3] or null; if shs_rest != null: the DC coefficient only, [P,1,3] */
+    const float* shs_rest;       /* null, or [P,M-1,3]: coefficients 1..M-1 stored apart (GaussianModel keeps
+                                    _features_dc and _features_rest as two tensors; this avoids the torch.cat of
+                                    get_features, scene/gaussian_model.py:137-140) */
     const float* colors_precomp; /* [P,3] or null */
     const float* opacities;      /* [P] (already activated) */
     const float* scales;         /* [P,3] or null */
@@ -103,7 +106,8 @@ typedef struct MomRasterGrads {
     float* dL_dopacity;   /* [P,1] */
     float* dL_dmeans3D;   /* [P,3] */
     float* dL_dcov3D;     /* [P,6] */
-    float* dL_dsh;        /* [P,M,3] or null when M == 0 */
+    float* dL_dsh;        /* [P,M,3] or null when M == 0; with dL_dsh_rest != null: the DC part only, [P,1,3] */
+    float* dL_dsh_rest;   /* null, or [P,M-1,3] */
     float* dL_dscales;    /* [P,3] or null when scales absent */
     float* dL_drotations; /* [P,4] or null when rotations absent */
 } MomRasterGrads;
@@ -173,6 +177,15 @@ int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const 
  * atomic row for the run. */
 size_t mom_morton_order_scratch_bytes(int P);
 int mom_morton_order(int P, const float* points /* [P,3] */, uint32_t* order /* [P] */, void* scratch, mom_stream_t stream);
+
+/* ---- activations of render() (gaussian_renderer/__init__.py:130-132) and their backward, one launch each ----
+ * scales = exp(scales_raw), rots = rots_raw / max(|rots_raw|, 1e-12) (F.normalize), opac = sigmoid(opac_raw) */
+int mom_activations_forward(int P, const float* scales_raw, const float* rots_raw, const float* opac_raw, float* scales,
+                            float* rots, float* opac, mom_stream_t stream);
+/* in: activated values + raw rotations + gradients wrt the activated values; out: gradients wrt the raw values */
+int mom_activations_backward(int P, const float* scales, const float* rots_raw, const float* opac, const float* dscales,
+                             const float* drots, const float* dopac, float* dscales_raw, float* drots_raw, float* dopac_raw,
+                             mom_stream_t stream);
 
 /* ---- fused multi-tensor Adam (torch.optim.Adam, amsgrad=False, weight_decay=0) -----------
  * One launch updates every listed tensor: exp_avg.lerp_(g, 1-b1); exp_avg_sq = b2*v + (1-b2) g*g;
