@@ -353,27 +353,42 @@ deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat,
         zero_tile(dW[L][1]);
         db[L][0] = db[L][1] = 0.f;
     }
-    for (int g0 = g_begin; g0 < g_end; g0 += 2) {
-        const int g = g0 + h;                           // K slot of this lane half
-        const bool ok = g < g_end;
-        const size_t row = (size_t)(ok ? g : g_begin) * kHid;
-        float xb[2][2];                                  // B fragments: [trunk|heads][kt]
+    // UNR K-steps (2 gaussians each) per trip: all 12*UNR operand loads are issued before the first MFMA needs one
+    constexpr int UNR = 4;
+    for (int g0 = g_begin; g0 < g_end; g0 += 2 * UNR) {
+        float xb[UNR][2][2], da[UNR][4][2];
+        bool okv[UNR];
 #pragma unroll
-        for (int kt = 0; kt < 2; kt++) {
-            xb[0][kt] = ok ? feat[row + 32 * kt + col] : 0.f;
-            xb[1][kt] = ok ? a0g[row + 32 * kt + col] : 0.f;
+        for (int u = 0; u < UNR; u++) {
+            const int g = g0 + 2 * u + h;               // K slot of this lane half
+            const bool ok = g < g_end;
+            okv[u] = ok;
+            const size_t row = (size_t)(ok ? g : g_begin) * kHid;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                xb[u][0][kt] = feat[row + 32 * kt + col];
+                xb[u][1][kt] = a0g[row + 32 * kt + col];
+            }
+#pragma unroll
+            for (int L = 0; L < 4; L++) {
+                const float* __restrict__ d = dH + (size_t)L * PH + row;
+                da[u][L][0] = d[col];
+                da[u][L][1] = d[32 + col];
+            }
         }
 #pragma unroll
-        for (int L = 0; L < 4; L++) {
-            const float* __restrict__ d = dH + (size_t)L * PH + row;
-            const float a_lo = ok ? d[col] : 0.f, a_hi = ok ? d[32 + col] : 0.f;
-            db[L][0] += a_lo;
-            db[L][1] += a_hi;
-            const int x = L == 0 ? 0 : 1;
-            dW[L][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, xb[x][0], dW[L][0][0], 0, 0, 0);
-            dW[L][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, xb[x][1], dW[L][0][1], 0, 0, 0);
-            dW[L][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, xb[x][0], dW[L][1][0], 0, 0, 0);
-            dW[L][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, xb[x][1], dW[L][1][1], 0, 0, 0);
+        for (int u = 0; u < UNR; u++) {
+#pragma unroll
+            for (int L = 0; L < 4; L++) {
+                const float a_lo = okv[u] ? da[u][L][0] : 0.f, a_hi = okv[u] ? da[u][L][1] : 0.f;
+                db[L][0] += a_lo;
+                db[L][1] += a_hi;
+                const int x = L == 0 ? 0 : 1;
+                dW[L][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, xb[u][x][0], dW[L][0][0], 0, 0, 0);
+                dW[L][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, xb[u][x][1], dW[L][0][1], 0, 0, 0);
+                dW[L][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, xb[u][x][0], dW[L][1][0], 0, 0, 0);
+                dW[L][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, xb[u][x][1], dW[L][1][1], 0, 0, 0);
+            }
         }
     }
     // combine the four waves in LDS, then one float atomic per weight per workgroup

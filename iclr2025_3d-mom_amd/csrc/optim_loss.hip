@@ -89,6 +89,8 @@ struct RegArgs {
     int count;
 };
 
+constexpr int kRegRows = 16;   // rows of H per workgroup (plus a 2-row halo on each side)
+
 __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __restrict__ out /* [0] = value */)
 {
     __shared__ float s[4];
@@ -96,22 +98,28 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __rest
     while (pi + 1 < a.count && blockIdx.x >= a.block_start[pi + 1]) pi++;
     const MomRegPlane P = a.p[pi];
     const int row = P.W * 32;  // floats per h
-    const int col = (blockIdx.x - a.block_start[pi]) * 256 + threadIdx.x;
+    const int cblocks = (row + 255) / 256;
+    const int local = blockIdx.x - a.block_start[pi];
+    const int col = (local % cblocks) * 256 + threadIdx.x;
+    const int h_begin = (local / cblocks) * kRegRows, h_end = min(P.H, h_begin + kRegRows);
     float val = 0.f;
     if (col < row) {
         const float* __restrict__ t = P.plane;
         float* __restrict__ g = P.grad;
         const int H = P.H;
-        // smoothness: mean over (c, H-2, W) of (t[h+2] - 2 t[h+1] + t[h])^2, weight ws
+        // smoothness: mean over (c, H-2, W) of s_h^2 with s_h = t[h+2] - 2 t[h+1] + t[h], weight w_smooth;
+        // d/dt[h] sum s^2 = 2 (s_{h-2} - 2 s_{h-1} + s_h).  This workgroup owns rows [h_begin, h_end): it adds the
+        // value terms s_h for h in its range and writes the gradient of its rows (needs s_{h-2} .. s_h => rows h-2 .. h+2).
         const float cs = (H > 2 && P.w_smooth != 0.f) ? P.w_smooth / ((float)(H - 2) * (float)row) : 0.f;
         const float cl = P.w_l1 != 0.f ? P.w_l1 / ((float)H * (float)row) : 0.f;
-        float sm2 = 0.f, sm1 = 0.f;  // second differences s_{h-2}, s_{h-1}
-        float t0 = t[col], t1 = H > 1 ? t[(size_t)row + col] : 0.f;
-        for (int h = 0; h < H; h++) {
-            const float t2 = (h + 2 < H) ? t[(size_t)(h + 2) * row + col] : 0.f;
-            const float sh = (h + 2 < H) ? (t2 - 2.f * t1 + t0) : 0.f;  // s_h
+        auto T = [&](int h) { return (h >= 0 && h < H) ? t[(size_t)h * row + col] : 0.f; };
+        auto S = [&](int h, float a0, float a1, float a2) { return (h >= 0 && h + 2 < H) ? (a2 - 2.f * a1 + a0) : 0.f; };
+        float tm2 = T(h_begin - 2), tm1 = T(h_begin - 1), t0 = T(h_begin), t1 = T(h_begin + 1);
+        float sm2 = S(h_begin - 2, tm2, tm1, t0), sm1 = S(h_begin - 1, tm1, t0, t1);
+        for (int h = h_begin; h < h_end; h++) {
+            const float t2 = T(h + 2);
+            const float sh = S(h, t0, t1, t2);
             val += cs * sh * sh;
-            // d/dt[h] sum s^2 = 2 (s_{h-2} - 2 s_{h-1} + s_h)
             float gr = 2.f * cs * (sm2 - 2.f * sm1 + sh);
             if (cl != 0.f) {
                 const float d = 1.f - t0;
@@ -129,7 +137,8 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __rest
     if (threadIdx.x == 0 && tot != 0.f) atomicAdd(out, tot);
 }
 
-
+}  // namespace
+namespace {
 // ---------------------------------------------------------------- activations (exp / normalize / sigmoid)
 __global__ void __launch_bounds__(256) act_fwd_kernel(int P, const float* __restrict__ sr, const float* __restrict__ rr,
                                                      const float* __restrict__ orr, float* __restrict__ s, float* __restrict__ r,
@@ -218,7 +227,7 @@ extern "C" int mom_plane_regulation(const MomRegPlane* planes, int count, float*
         a.p[i] = planes[i];
         if (!a.p[i].plane || a.p[i].H < 1 || a.p[i].W < 1) return MOM_EINVAL;
         a.block_start[i] = blocks;
-        blocks += (unsigned)((a.p[i].W * 32 + 255) / 256);
+        blocks += (unsigned)(((a.p[i].W * 32 + 255) / 256) * ((a.p[i].H + kRegRows - 1) / kRegRows));
     }
     a.block_start[count] = blocks;
     a.count = count;
