@@ -8,8 +8,9 @@
 //
 // Backward: instead of the reference's 10 global float atomics per (pixel,
 // splat) pair, each wave reduces its 64 pixels' contributions in registers
-// (DPP row operations) and issues ONE 40-byte atomic instruction per (wave,
-// splat) into the per-Gaussian accumulator record gacc[P][12].
+// (a packed DPP reduce-scatter, reduce_scatter10) and issues ONE 40-byte atomic
+// instruction per (wave, splat) into the per-Gaussian accumulator record
+// gacc[P][12].
 #include "mom_common.h"
 
 namespace {
@@ -44,6 +45,45 @@ __device__ __forceinline__ float wave_sum(float v)
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
 #endif
+}
+
+// Pair step of a reduce-scatter: lanes whose `upper` bit is clear end up with the pair-sum of x, the others with the
+// pair-sum of y (the partner lane, CTRL, differs in exactly that bit).
+template <int CTRL>
+__device__ __forceinline__ float dpp_pair(float x, float y, bool upper)
+{
+    const float keep = upper ? y : x, send = upper ? x : y;
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
+}
+// Sums ten per-lane values over the 64 lanes of the wave; lane k (k < 10) returns the total of v[k] (the other
+// lanes return totals of some component too -- callers only use lanes 0..9).  About half the instructions of ten
+// wave_sum calls: two scatter steps inside each quad pack the ten values into three registers (a lane's low two bits
+// pick its component), two row rotations sum those over the 16-lane rows, a lane select merges the three registers,
+// and gfx950's v_permlane16_swap / v_permlane32_swap add the four rows.
+__device__ __forceinline__ float reduce_scatter10(const float (&v)[10], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float a0 = dpp_pair<0xB1>(v[0], v[1], b0);     // quad_perm [1,0,3,2]
+    const float a1 = dpp_pair<0xB1>(v[2], v[3], b0);
+    const float a2 = dpp_pair<0xB1>(v[4], v[5], b0);
+    const float a3 = dpp_pair<0xB1>(v[6], v[7], b0);
+    const float a4 = dpp_pair<0xB1>(v[8], v[9], b0);
+    float c0 = dpp_pair<0x4E>(a0, a1, b1);               // quad_perm [2,3,0,1]: lane l holds v[l & 3] over its quad
+    float c1 = dpp_pair<0x4E>(a2, a3, b1);               //                      v[4 + (l & 3)]
+    float c2 = dpp_add<0x4E, 0xF>(a4);                   //                      v[8 + (l & 1)]
+    c0 = dpp_add<0x124, 0xF>(c0); c1 = dpp_add<0x124, 0xF>(c1); c2 = dpp_add<0x124, 0xF>(c2);   // row_ror:4
+    c0 = dpp_add<0x128, 0xF>(c0); c1 = dpp_add<0x128, 0xF>(c1); c2 = dpp_add<0x128, 0xF>(c2);   // row_ror:8
+    const int k = lane & 15;
+    float m = k < 4 ? c0 : (k < 8 ? c1 : c2);            // lane k of every row: row total of v[k]
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return m;
 }
 
 __global__ void __launch_bounds__(256)
@@ -186,7 +226,8 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                   g_d = 0.f;
             if (valid) {
                 const float4 r2 = s_rec[j * 3 + 2];
-                T = T / (1.f - alpha);
+                const float inv_1ma = 1.f / (1.f - alpha);      // shared by T and the background term below
+                T = T * inv_1ma;
                 const float w = alpha * T;
                 float dL_dalpha = 0.f;
                 accum0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
@@ -207,7 +248,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 g_d = w * dpd;
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
                 // no derivative for the 0.99 cap, exactly as the reference (backward.cu:571)
                 const float dL_dG = r1.w * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
@@ -220,18 +261,8 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 g_cw = -0.5f * gdy * dy * dL_dG;
                 g_op = G * dL_dalpha;
             }
-            const float s0 = wave_sum(g_mx), s1 = wave_sum(g_my), s2 = wave_sum(g_cx), s3 = wave_sum(g_cy), s4 = wave_sum(g_cw),
-                        s5 = wave_sum(g_op), s6 = wave_sum(g_c0), s7 = wave_sum(g_c1), s8 = wave_sum(g_c2), s9 = wave_sum(g_d);
-            float v = s0;
-            v = lane == 1 ? s1 : v;
-            v = lane == 2 ? s2 : v;
-            v = lane == 3 ? s3 : v;
-            v = lane == 4 ? s4 : v;
-            v = lane == 5 ? s5 : v;
-            v = lane == 6 ? s6 : v;
-            v = lane == 7 ? s7 : v;
-            v = lane == 8 ? s8 : v;
-            v = lane == 9 ? s9 : v;
+            const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};
+            const float v = reduce_scatter10(gv, lane);
             if (lane < 10) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
         }
     }
