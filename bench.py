@@ -67,6 +67,24 @@ def cpu_baseline(cfg, budget_s=15.0):
             "sample": f"{n} fine-stage steps of the same scene after 1 warm-up ({dt:.2f} s/step)"}
 
 
+def measured_traffic(kernel, cfg):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json: two
+    separate --pmc passes, unit and gfx950 corrections applied there), or None when no summary exists for exactly this
+    workload -- PMC counters cannot be collected from inside this process."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    for f in reversed(files):
+        with open(f) as fh:
+            doc = json.load(fh)
+        if (doc.get("workload"), doc.get("gaussians"), doc.get("width"), doc.get("height")) != \
+                (cfg["name"], cfg["P"], cfg["W"], cfg["H"]):
+            continue
+        k = doc.get("kernels", {}).get(kernel)
+        if k:
+            return k["traffic_bytes"]
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +161,8 @@ def main():
                    "host_sync": a.sync_mode, "final_loss": float(loss)},
     }
     if rank == 0:
-        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], out["config"]["instances_R"], cfg["W"] * cfg["H"])
+        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], out["config"]["instances_R"], cfg["W"] * cfg["H"],
+                                        traffic=measured_traffic(a.roofline_kernel, cfg))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

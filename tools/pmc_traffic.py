@@ -1,0 +1,102 @@
+"""Summarise two rocprofv3 --pmc passes into profiles/<prefix>_pmc_traffic.{json,_per_kernel.csv}.
+
+Collect on the GPU box (two SEPARATE passes: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2), with the program
+directly after `--`:
+
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- \
+        python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- \
+        python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
+
+then here:
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/*/*_counter_collection.csv \
+        gpurun_out/pmc_write/*/*_counter_collection.csv profiles/r01_f
+
+Corrections (MI355X_MICROARCH.md, HBM section): counter values are KiB; on gfx950 FETCH_SIZE reports half of the bytes
+of a coalesced streaming read, so it is doubled; WRITE_SIZE is exact.  The script prints the calibration against
+adam_kernel, whose byte counts are known exactly (16 B read and 12 B written per optimised float), and refuses to
+write a summary when that calibration is off by more than 3 %.  bench.py reads the newest summary whose workload
+matches and reports it as roofline.traffic.
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+# kernel symbol -> the name bench.py / profiling.py use
+NAMES = {
+    "render_bwd_kernel": "render_bwd", "render_fwd_kernel": "render_fwd", "hexplane_bwd4_kernel": "hexplane_bwd",
+    "hexplane_fwd4_kernel": "hexplane_fwd", "adam_kernel": "adam", "l1_kernel": "l1_loss",
+    "preprocess_fwd_kernel": "preprocess_fwd", "preprocess_bwd_kernel": "preprocess_bwd", "tile_sort_kernel": "tile_sort",
+    "deform_fwd_kernel": "mlp_fwd", "deform_bwd_dx_kernel": "mlp_bwd_dx", "deform_bwd_dw_kernel": "mlp_bwd_dw",
+    "plane_reg_kernel": "plane_reg",
+}
+SKIP = 5  # warm-up launches left out of the average
+
+# bench.py config c2 (the workload the metric is quoted on)
+WORKLOAD = {"workload": "200k Gaussians, 60 frames, 960x540, HexPlane on", "gaussians": 200000, "width": 960, "height": 540}
+DEFORM_FLOATS = 2_904_970
+
+
+def load(path):
+    per_kernel = collections.defaultdict(list)
+    with open(path) as fh:
+        for row in csv.DictReader(fh):
+            m = re.search(r"(\w+_kernel)", row["Kernel_Name"])
+            if m:
+                per_kernel[m.group(1)].append(float(row["Counter_Value"]))
+    return per_kernel
+
+
+def main():
+    if len(sys.argv) != 4:
+        sys.exit(__doc__)
+    fetch, write, prefix = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    rows, kernels = [], {}
+    for sym, short in NAMES.items():
+        fv, wv = fetch.get(sym, [])[SKIP:], write.get(sym, [])[SKIP:]
+        if not fv or not wv:
+            continue
+        f_kib, w_kib = sum(fv) / len(fv), sum(wv) / len(wv)
+        rd, wr = int(round(f_kib * 1024 * 2)), int(round(w_kib * 1024))
+        rows.append([sym, len(fv), round(f_kib, 1), round(w_kib, 1), rd, wr, rd + wr])
+        kernels[short] = {"launches_averaged": len(fv), "FETCH_SIZE_KiB_raw": round(f_kib, 1),
+                          "WRITE_SIZE_KiB_raw": round(w_kib, 1), "read_bytes": rd, "write_bytes": wr,
+                          "traffic_bytes": rd + wr}
+
+    floats = WORKLOAD["gaussians"] * 59 + DEFORM_FLOATS
+    want_rd, want_wr = floats * 16, floats * 12
+    got = kernels.get("adam")
+    if not got:
+        sys.exit("no adam_kernel launches in the counter files: cannot calibrate")
+    err_rd, err_wr = got["read_bytes"] / want_rd - 1, got["write_bytes"] / want_wr - 1
+    print(f"calibration on adam_kernel: read {got['read_bytes'] / 1e6:.2f} MB vs {want_rd / 1e6:.2f} MB ({err_rd:+.2%}), "
+          f"written {got['write_bytes'] / 1e6:.2f} MB vs {want_wr / 1e6:.2f} MB ({err_wr:+.2%})")
+    if abs(err_rd) > 0.03 or abs(err_wr) > 0.03:
+        sys.exit("calibration off by more than 3 %: not writing a summary")
+
+    with open(prefix + "_pmc_traffic_per_kernel.csv", "w", newline="") as out:
+        w = csv.writer(out)
+        w.writerow(["kernel", "launches_averaged", "FETCH_SIZE_KiB_raw_avg", "WRITE_SIZE_KiB_raw_avg", "read_bytes_corrected",
+                    "write_bytes", "traffic_bytes_per_launch"])
+        w.writerows(rows)
+    doc = dict(WORKLOAD)
+    doc.update({
+        "what": "HBM-side traffic per launch from rocprofv3 PMC counters, one MI355X, bench.py config c2",
+        "method": "two separate --pmc passes, per-dispatch values averaged over the launches after the first %d" % SKIP,
+        "corrections": {"unit": "counter values are KiB (x1024)", "FETCH_SIZE": "x2 on gfx950", "WRITE_SIZE": "exact"},
+        "calibration": {"adam_kernel_read_error": round(err_rd, 4), "adam_kernel_write_error": round(err_wr, 4),
+                        "note": "the x2 read correction is calibrated on streaming reads; for the gather kernels "
+                                "(render_*, hexplane_*) the read figure is an upper bound"},
+        "kernels": kernels,
+    })
+    with open(prefix + "_pmc_traffic.json", "w") as out:
+        json.dump(doc, out, indent=1)
+    for r in rows:
+        print(r)
+
+
+if __name__ == "__main__":
+    main()
