@@ -86,6 +86,27 @@ __device__ __forceinline__ float reduce_scatter10(const float (&v)[10], int lane
     return m;
 }
 
+// A splat can reach alpha >= 1/255 at a pixel only if power >= ln(1 / (255 opacity)).  The staging thread stores that
+// bound, lowered by a margin that dwarfs the rounding of logf, of the product and of mom_exp (all below 1e-6 here),
+// in the LDS copy of the record (r0.w, whose tile count the compositing kernels do not use).  The loops then skip a
+// splat for the whole wave with `!__any(!(power < bound))` before paying for exp; every pair that survives still takes
+// the exact tests, so results do not change.  Written as !(power < bound) so that a NaN falls through to them.
+__device__ __forceinline__ float power_bound(float opacity) { return -logf(255.0f * opacity) - 1e-3f; }
+
+// Exponent of the splat's Gaussian at a pixel.  render_fwd and render_bwd must round it identically, or a pair sitting on
+// the 1/255 threshold could be composited by one pass and not by the other; with contraction left to the compiler the
+// same source expression was fused differently from one kernel (and one edit) to the next.  So: contraction off, the
+// fusions spelled out.
+__device__ __forceinline__ float splat_power(const float4 r0, const float4 r1, float pxf, float pyf, float& dx, float& dy)
+{
+#pragma clang fp contract(off)
+    dx = r0.x - pxf;
+    dy = r0.y - pyf;
+    const float ax = r1.x * dx, cy = r1.z * dy, bx = r1.y * dx;
+    const float quad = __builtin_fmaf(cy, dy, ax * dx);          // conic.x dx^2 + conic.z dy^2
+    return __builtin_fmaf(-0.5f, quad, -(bx * dy));             // -0.5 quad - conic.y dx dy
+}
+
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt,
                   const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
@@ -116,8 +137,11 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         const int progress = i * 256 + threadIdx.x;
         if (range.x + progress < range.y) {
             const size_t id = point_list[range.x + progress];
-            s_rec[threadIdx.x * 3 + 0] = rec[3 * id + 0];
-            s_rec[threadIdx.x * 3 + 1] = rec[3 * id + 1];
+            float4 q0 = rec[3 * id + 0];
+            const float4 q1 = rec[3 * id + 1];
+            q0.w = power_bound(q1.w);
+            s_rec[threadIdx.x * 3 + 0] = q0;
+            s_rec[threadIdx.x * 3 + 1] = q1;
             s_rec[threadIdx.x * 3 + 2] = rec[3 * id + 2];
         }
         __syncthreads();
@@ -126,8 +150,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             contributor++;
             const float4 r0 = s_rec[j * 3 + 0];
             const float4 r1 = s_rec[j * 3 + 1];
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+            float dx, dy;
+            const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
+            if (!__any(!(power < r0.w))) continue;   // no lane of the wave can reach 1/255 (power_bound)
             if (power > 0.0f) continue;
             const float alpha = fminf(0.99f, r1.w * mom_exp(power));
             if (alpha < 1.0f / 255.0f) continue;
@@ -198,6 +223,11 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+    // splats behind the last contributor of every pixel of this wave need no work at all
+    int wave_last = last_contributor;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
 
     for (int i = 0; i < rounds; i++, toDo -= 256) {
         __syncthreads();
@@ -205,18 +235,23 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         if (range.x + progress < range.y) {
             const uint32_t id = point_list[range.y - progress - 1];
             s_id[threadIdx.x] = id;
-            s_rec[threadIdx.x * 3 + 0] = rec[3 * (size_t)id + 0];
-            s_rec[threadIdx.x * 3 + 1] = rec[3 * (size_t)id + 1];
+            float4 q0 = rec[3 * (size_t)id + 0];
+            const float4 q1 = rec[3 * (size_t)id + 1];
+            q0.w = power_bound(q1.w);
+            s_rec[threadIdx.x * 3 + 0] = q0;
+            s_rec[threadIdx.x * 3 + 1] = q1;
             s_rec[threadIdx.x * 3 + 2] = rec[3 * (size_t)id + 2];
         }
         __syncthreads();
         const int nb = min(256, toDo);
         for (int j = 0; j < nb; j++) {
             contributor--;
+            if ((int)contributor >= wave_last) continue;   // wave-uniform: occluded for all 64 pixels
             const float4 r0 = s_rec[j * 3 + 0];
             const float4 r1 = s_rec[j * 3 + 1];
-            const float dx = r0.x - pxf, dy = r0.y - pyf;
-            const float power = -0.5f * (r1.x * dx * dx + r1.z * dy * dy) - r1.y * dx * dy;
+            float dx, dy;
+            const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
+            if (!__any(!(power < r0.w))) continue;         // no lane of the wave can reach 1/255 (power_bound)
             const float G = mom_exp(power);
             const float alpha = fminf(0.99f, r1.w * G);
             const bool valid = inside && ((int)contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
