@@ -112,6 +112,8 @@ def main():
     DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
     scene, g, trainer, op = build_state(cfg, dev, fused=(a.path == "fused"))
     cams = trainer.cams
+    for c in cams:                       # inputs resident in HBM before the timed region: the cameras' matrices and
+        c.device_tensors(dev)            # ground-truth images are uploaded here, not on first use inside it
     par = None
     if world > 1:
         par = importlib.import_module("iclr2025_3d-mom_amd.parallel")

@@ -104,7 +104,7 @@ class FusedStep:
         for lv in levels:
             gl.append(self._dg_planes[k:k + 6])
             k += 6
-        hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in levels], field.aabb, gl)
+        hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in levels], field.aabb, gl, aabb_host=field.aabb_host())
         N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.feat.data_ptr(), s), "hexplane_fwd")
         md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], self._dg_mlp)
         coef = float(delta_scale * cam.frame_num)

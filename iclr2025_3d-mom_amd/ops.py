@@ -33,7 +33,9 @@ def make_plane(C_, H, W, device=None):
     return torch.empty(1, H, W, C_, device=device).permute(0, 3, 1, 2)
 
 
-def _hexplane_desc(planes_by_level, aabb, grads_by_level=None):
+def _hexplane_desc(planes_by_level, aabb, grads_by_level=None, aabb_host=None):
+    """MomHexPlane descriptor.  `aabb_host`: the six aabb floats already on the host (HexPlaneField.aabb_host());
+    without it they are read back from the `aabb` tensor, which blocks the host until the GPU has drained."""
     d = N.MomHexPlane()
     d.levels = len(planes_by_level)
     d.channels = planes_by_level[0][0].shape[1]
@@ -54,7 +56,7 @@ def _hexplane_desc(planes_by_level, aabb, grads_by_level=None):
                 keep.append(gs)
         for k in range(4):
             d.res[l][k] = res[k]
-    a = aabb.detach().float().cpu().reshape(-1).tolist()
+    a = aabb_host if aabb_host is not None else aabb.detach().float().cpu().reshape(-1).tolist()
     for k in range(6):
         d.aabb[k] = a[k]
     return d, keep
@@ -64,10 +66,11 @@ class HexPlaneFunction(torch.autograd.Function):
     """features[P, L*32] = HexPlaneField(xyz, t) (reference scene/hexplane.py:160-183)."""
 
     @staticmethod
-    def forward(ctx, xyz, time, aabb, n_levels, order, *planes):
+    def forward(ctx, xyz, time, aabb, n_levels, order, aabb_host, *planes):
         _need_cuda(xyz, "hexplane")
         lv = [list(planes[6 * l:6 * l + 6]) for l in range(n_levels)]
-        d, keep = _hexplane_desc(lv, aabb)
+        d, keep = _hexplane_desc(lv, aabb, aabb_host=aabb_host)
+        ctx.aabb_host = aabb_host
         xyz_c = xyz.detach().contiguous().float()
         P = xyz_c.shape[0]
         feat = torch.empty((P, n_levels * 32), dtype=torch.float32, device=xyz.device)
@@ -87,7 +90,7 @@ class HexPlaneFunction(torch.autograd.Function):
         n_levels = ctx.n_levels
         lv = [list(planes[6 * l:6 * l + 6]) for l in range(n_levels)]
         grads = [[torch.zeros_like(p) for p in level] for level in lv]   # preserves the channel-last strides
-        d, keep = _hexplane_desc(lv, aabb, grads)
+        d, keep = _hexplane_desc(lv, aabb, grads, aabb_host=ctx.aabb_host)
         P = xyz_c.shape[0]
         dxyz = torch.zeros_like(xyz_c) if ctx.needs_input_grad[0] else None
         dfeat = dfeat.contiguous()
@@ -97,12 +100,12 @@ class HexPlaneFunction(torch.autograd.Function):
                                               None if dxyz is None else dxyz.data_ptr(), N.current_stream()),
                 "mom_hexplane_backward")
         flat = [g for level in grads for g in level]
-        return (dxyz, None, None, None, None, *flat)
+        return (dxyz, None, None, None, None, None, *flat)
 
 
-def hexplane_features(xyz, time, aabb, planes_by_level, order=None):
+def hexplane_features(xyz, time, aabb, planes_by_level, order=None, aabb_host=None):
     flat = [p for level in planes_by_level for p in level]
-    return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), order, *flat)
+    return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), order, aabb_host, *flat)
 
 
 def morton_order(xyz):

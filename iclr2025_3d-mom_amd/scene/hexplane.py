@@ -65,6 +65,16 @@ class HexPlaneField(nn.Module):
     def get_aabb(self):
         return self.aabb[0], self.aabb[1]
 
+    def aabb_host(self):
+        """The six aabb floats as a python list, read back from the device only when the parameter was replaced
+        (set_aabb) or written in place (load_state_dict) since the last call -- not once per iteration."""
+        a = self.aabb
+        key = (id(a), a._version, a.data_ptr())
+        if getattr(self, "_aabb_host_key", None) != key:
+            self._aabb_host_val = a.detach().float().cpu().reshape(-1).tolist()
+            self._aabb_host_key = key
+        return self._aabb_host_val
+
     def set_aabb(self, xyz_max, xyz_min):
         aabb = torch.tensor([xyz_max, xyz_min], dtype=torch.float32)
         self.aabb = nn.Parameter(aabb.to(self.aabb.device), requires_grad=False)
@@ -74,7 +84,8 @@ class HexPlaneField(nn.Module):
         """[N,3] points (+ [N,1] timestamps, or one python float for all points) -> [N, feat_dim]."""
         pts = pts.reshape(-1, pts.shape[-1])
         levels = [list(g) for g in self.grids]
-        return ops.BACKEND.hexplane_features(pts, timestamps, self.aabb, levels, order=self._processing_order(pts))
+        return ops.BACKEND.hexplane_features(pts, timestamps, self.aabb, levels, order=self._processing_order(pts),
+                                             aabb_host=self.aabb_host() if self.aabb.is_cuda else None)
 
     REORDER_EVERY = 64
 

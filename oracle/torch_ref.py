@@ -31,8 +31,9 @@ def grid_sample_wrapper(grid, coords):
     return out.view(B, C, n).transpose(-1, -2).squeeze()
 
 
-def hexplane_features(pts, timestamps, aabb, planes_by_level, order=None):
-    """HexPlaneField.get_density (scene/hexplane.py:160-175) + interpolate_ms_features (:73-106)."""
+def hexplane_features(pts, timestamps, aabb, planes_by_level, order=None, aabb_host=None):
+    """HexPlaneField.get_density (scene/hexplane.py:160-175) + interpolate_ms_features (:73-106).
+    `order` and `aabb_host` are speed hints of the HIP backend and are ignored here."""
     pts = normalize_aabb(pts, aabb)
     if not torch.is_tensor(timestamps):
         timestamps = torch.full((pts.shape[0], 1), float(timestamps), dtype=pts.dtype, device=pts.device)
