@@ -26,13 +26,14 @@ CONFIGS = {
 }
 
 
-def build_state(cfg, device, fused=False):
+def build_state(cfg, device, fused=False, lambda_dssim=0.0):
     import torch
     pkg = importlib.import_module("iclr2025_3d-mom_amd")
     A = importlib.import_module("iclr2025_3d-mom_amd.arguments")
     S = importlib.import_module("iclr2025_3d-mom_amd.scene")
     T = importlib.import_module("iclr2025_3d-mom_amd.train")
     args, lp, op, pp, hp = A.default_args(time_resolution=cfg["time_res"])
+    op.lambda_dssim = lambda_dssim      # 0 is the reference's default; 0.2 is the "SSIM/L1" loss of the north star
     torch.manual_seed(6666)
     scene = S.SyntheticScene(cfg["P"], cfg["F"], cfg["W"], cfg["H"], seed=6666)
     g = S.GaussianModel(lp.sh_degree, hp, device=device)
@@ -85,6 +86,52 @@ def measured_traffic(kernel, cfg):
     return None
 
 
+def metric_name():
+    """BASELINE.json's metric string, verbatim (it travels with the repo); the literal is the same text."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as fh:
+            return json.load(fh)["metric"]
+    except (OSError, KeyError, ValueError):
+        return "4DGS train-steps/sec @200k Gaussians, 960\u00d7540, 60 frames; render FPS"
+
+
+def timed_steps(one, first, steps):
+    """`steps` training steps between two synchronisations -> seconds."""
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = one(first + i)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, loss
+
+
+def render_fps(scene, g, pp, background, delta_scale, passes=2):
+    """Second half of the metric: no-grad gaussian_renderer.render() over the reference's 59-pose `side` trajectory
+    (render_4DGS.py:88 -> render_set), images left on the device (the reference's "pure" rate, without its PNG writer)."""
+    import torch
+    R = importlib.import_module("iclr2025_3d-mom_amd.gaussian_renderer")
+    cams = scene.getVideoCameras_side()
+    dev = g._xyz.device
+    for c in cams:
+        c.device_tensors(dev)
+    with torch.no_grad():
+        for c in cams[:8]:
+            R.render(c, g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            for c in cams:
+                out = R.render(c, g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)["render"]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    n = passes * len(cams)
+    return {"value": n / dt, "unit": "frames/s", "frames": n, "ms_per_frame": 1e3 * dt / n,
+            "trajectory": "side, 59 poses (test_trajectory/side_{R,t}_list, last pose dropped)",
+            "mode": "no-grad render(), deformation on, images kept on the device (no PNG writer)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +141,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-mode", default="async", choices=["async", "exact"])
     ap.add_argument("--roofline-kernel", default="render_bwd")
+    ap.add_argument("--lambda-dssim", type=float, default=0.0,
+                    help="weight of the SSIM loss term in the headline value (0 = the reference's default)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the two extra single-GPU legs (training with lambda_dssim 0.2, render FPS)")
     ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
                     help="fused: explicit launch sequence (fused_step.py); autograd: render() + loss.backward()")
     a = ap.parse_args()
@@ -110,7 +161,7 @@ def main():
         dist.init_process_group("nccl")
     dev = torch.device("cuda", local)
     DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
-    scene, g, trainer, op = build_state(cfg, dev, fused=(a.path == "fused"))
+    scene, g, trainer, op = build_state(cfg, dev, fused=(a.path == "fused"), lambda_dssim=a.lambda_dssim)
     cams = trainer.cams
     for c in cams:                       # inputs resident in HBM before the timed region: the cameras' matrices and
         c.device_tensors(dev)            # ground-truth images are uploaded here, not on first use inside it
@@ -153,18 +204,32 @@ def main():
         dt = float(tt[0])
     assert torch.isfinite(loss).all(), "loss is not finite"
     out = {
-        "metric": "4DGS train-steps/sec @200k Gaussians, 960x540, 60 frames", "value": a.steps * world / dt,
+        "metric": metric_name(), "value": a.steps * world / dt,
         "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "gaussians": cfg["P"], "frames": cfg["F"], "width": cfg["W"],
                    "height": cfg["H"], "instances_R": int((DGR.last_num_rendered() if trainer.fused is None else trainer.fused.nr_host[0]) or 0),
                    "sh_degree": 3, "step_path": a.path, "batch_size": 1,
-                   "lambda_dssim": 0, "parallelism": f"camera-batch x{world}" if world > 1 else "single",
+                   "lambda_dssim": a.lambda_dssim, "parallelism": f"camera-batch x{world}" if world > 1 else "single",
                    "host_sync": a.sync_mode, "final_loss": float(loss)},
     }
     if rank == 0:
         out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], out["config"]["instances_R"], cfg["W"] * cfg["H"],
                                         traffic=measured_traffic(a.roofline_kernel, cfg))
+        if world == 1 and not a.no_extra:
+            # the metric's two other readings, on the same scene and model state: the SSIM/L1 loss of the
+            # north star, and render FPS.  Both after the headline region, so they cannot disturb it.
+            prof.enable(a.roofline_kernel, False)
+            k2 = max(1, min(a.steps, 50))
+            op.lambda_dssim = 0.2
+            for i in range(5):
+                one(a.warmup + a.steps + 1 + i)
+            dt2, loss2 = timed_steps(one, a.warmup + a.steps + 6, k2)
+            op.lambda_dssim = a.lambda_dssim
+            assert torch.isfinite(loss2).all(), "loss (lambda_dssim 0.2) is not finite"
+            out["with_ssim"] = {"lambda_dssim": 0.2, "value": k2 / dt2, "unit": "steps/s", "steps": k2,
+                                "ms_per_step": 1e3 * dt2 / k2, "final_loss": float(loss2)}
+            out["render_fps"] = render_fps(scene, g, trainer.pipe, trainer.background, trainer.delta_scale)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))

@@ -2,7 +2,7 @@
 per-op tensor allocation, no host synchronisation.
 
 It computes exactly what `train.Trainer.step` computes through `render()` + `loss.backward()` (the reference's
-train_4DGS.py:149-297 with batch_size 1, stage "fine", lambda_dssim 0, the shipped deformation config) and leaves the
+train_4DGS.py:149-297 with batch_size 1, stage "fine", L1 (+ lambda_dssim SSIM) loss, the shipped deformation config) and leaves the
 same `.grad` tensors behind, so the optimizer step, the densification statistics and everything downstream are shared
 with the autograd path.  `tests/test_fused_step_gpu.py` checks the two paths against each other.
 
@@ -49,6 +49,7 @@ class FusedStep:
         self.cap = 0
         self.binning = None
         self.dimg, self.sums = e(3, H, W), e(2)
+        self.ssim_dm = None                  # SSIM term: made on first use (lambda_dssim may be switched on later)
         self.g2d, self.gcol, self.gop_act, self.gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 6)
         self.gsc_act, self.grot_act = e(P, 3), e(P, 4)
         # parameter gradients (persist across steps; .grad points at them)
@@ -144,6 +145,17 @@ class FusedStep:
         # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
         n = self.color.numel()
         N.check(lib.mom_l1_loss(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
+        lam = float(self.opt.lambda_dssim)
+        if lam != 0:
+            # loss += lambda_dssim * (1 - ssim(image, gt))  (train_4DGS.py:222-223): its gradient is added into dimg
+            win = ops._ssim_window()
+            if self.ssim_dm is None:         # derivative maps and the map sum (mom_ssim_forward)
+                self.ssim_dm = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev)
+                self.ssim_sum = torch.empty(1, dtype=torch.float64, device=dev)
+            N.check(lib.mom_ssim_forward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
+                                         self.ssim_sum.data_ptr(), s), "ssim_fwd")
+            N.check(lib.mom_ssim_backward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
+                                          -lam / n, None, self.dimg.data_ptr(), s), "ssim_bwd")
         # ---- rasterizer backward
         gr = N.MomRasterGrads()
         gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = self.g2d.data_ptr(), self.gcol.data_ptr(), self.gop_act.data_ptr()
@@ -186,5 +198,7 @@ class FusedStep:
             p.grad = gbuf
         l1 = self.sums[0] / n
         loss = l1 if reg is None else l1 + reg[0]
+        if lam != 0:
+            loss = loss + lam * (1.0 - (self.ssim_sum[0] / n).float())
         self.last = {"l1": l1, "loss": loss, "mse_sum": self.sums[1], "n": n}
         return loss, self.radii, self.g2d

@@ -212,6 +212,65 @@ def l1_loss_with_sums(img, gt):
     return L1LossFunction.apply(img, gt)
 
 
+# --------------------------------------------------------------------------- SSIM
+def ssim_window():
+    """The 11 taps of the reference's gaussian(11, 1.5) (utils/loss_utils.py:29-31), computed the way it computes them
+    (python doubles rounded to float32, then normalised in float32), as a ctypes array for the C ABI."""
+    from math import exp
+    g = torch.tensor([exp(-(x - 5) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)], dtype=torch.float32)
+    g = g / g.sum()
+    return (C.c_float * 11)(*g.tolist())
+
+
+_SSIM_WINDOW = None
+
+
+def _ssim_window():
+    global _SSIM_WINDOW
+    if _SSIM_WINDOW is None:
+        _SSIM_WINDOW = ssim_window()
+    return _SSIM_WINDOW
+
+
+class SSIMFunction(torch.autograd.Function):
+    """mean SSIM of two images (reference utils/loss_utils.py:52-92 with its default window), gradient w.r.t. img1."""
+
+    @staticmethod
+    def forward(ctx, img1, img2):
+        _need_cuda(img1, "ssim")
+        a = img1.detach().contiguous().float()
+        b = img2.detach().contiguous().float()
+        if a.shape != b.shape or a.dim() < 3:
+            raise N.MomError(f"ssim: expected two [...,C,H,W] images of one shape, got {tuple(a.shape)} and {tuple(b.shape)}")
+        H, W = a.shape[-2], a.shape[-1]
+        Cn = a.numel() // max(1, H * W)
+        need_grad = ctx.needs_input_grad[0]
+        dm = torch.empty((3,) + tuple(a.shape), dtype=torch.float32, device=a.device) if need_grad else None
+        total = torch.empty(1, dtype=torch.float64, device=a.device)
+        N.check(N.lib().mom_ssim_forward(Cn, H, W, _ssim_window(), a.data_ptr(), b.data_ptr(),
+                                         None if dm is None else dm.data_ptr(), total.data_ptr(), N.current_stream()),
+                "mom_ssim_forward")
+        if need_grad:
+            ctx.save_for_backward(a, b, dm)
+        ctx.dims = (Cn, H, W)
+        return (total / max(1, a.numel())).float().reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, dm = ctx.saved_tensors
+        Cn, H, W = ctx.dims
+        dimg = torch.zeros_like(a)
+        g = g.detach().contiguous().float()
+        N.check(N.lib().mom_ssim_backward(Cn, H, W, _ssim_window(), a.data_ptr(), b.data_ptr(), dm.data_ptr(),
+                                          1.0 / max(1, a.numel()), g.data_ptr(), dimg.data_ptr(), N.current_stream()),
+                "mom_ssim_backward")
+        return dimg, None
+
+
+def ssim(img1, img2):
+    return SSIMFunction.apply(img1, img2)
+
+
 # --------------------------------------------------------------------------- plane regularisers
 class PlaneRegFunction(torch.autograd.Function):
     """value = sum_p  w_smooth[p] * smooth2(plane_p) + w_l1[p] * mean|1 - plane_p|."""
@@ -324,6 +383,7 @@ class _HipBackend:
     morton_order = staticmethod(morton_order)
     deform_mlp = staticmethod(deform_mlp)
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
+    ssim = staticmethod(ssim)
     plane_regulation = staticmethod(plane_regulation)
     Adam = FusedAdam
 

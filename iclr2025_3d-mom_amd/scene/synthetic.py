@@ -90,7 +90,29 @@ class SyntheticScene:
     def getVideoCameras_up(self):
         return self._video
 
-    getVideoCameras_side = getVideoCameras_zoom = getVideoCameras_circle = getVideoCameras_up
+    getVideoCameras_zoom = getVideoCameras_circle = getVideoCameras_up
+
+    @staticmethod
+    def side_trajectory():
+        """(R[60,3,3], t[60,3]) of the reference's `side` render path (test_trajectory/side_{R,t}_list): no rotation,
+        the camera slides along x from +0.09 to -0.09 in 60 equal steps.  tests/golden/g9_side_trajectory.npz holds
+        the reference's own lists; tests/test_golden_cpu.py checks this restatement against them."""
+        R = np.broadcast_to(np.eye(3, dtype=np.float32), (60, 3, 3)).copy()
+        t = np.zeros((60, 3), dtype=np.float32)
+        t[:, 0] = np.linspace(0.09, -0.09, 60, dtype=np.float64).astype(np.float32)
+        return R, t
+
+    def getVideoCameras_side(self):
+        """The 59 cameras render_4DGS.py renders for the "side" video (scene/dataset_readers.py:1003-1018: pose idx,
+        time of video frame idx, frame_num = idx, and the last of the 60 poses is dropped)."""
+        if getattr(self, "_side", None) is None:
+            R, t = self.side_trajectory()
+            F = len(self._video)
+            self._side = [Camera(colmap_id=i, R=R[i].astype(np.float64), T=t[i].astype(np.float64), FoVx=self.FovX, FoVy=self.FovY,
+                                 image=self._video[i % F].original_image, gt_alpha_mask=None, image_name=f"side{i}", uid=i,
+                                 data_device=self._video[0].data_device, time=((i % F) / (F - 1) if F > 1 else 0.0),
+                                 frame_num=i % F) for i in range(59)]
+        return self._side
 
     def init_gaussians(self, gaussians, flow_scale=2):
         """What Scene.__init__ does with a fresh model (scene/__init__.py:78-89)."""

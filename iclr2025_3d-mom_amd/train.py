@@ -26,7 +26,7 @@ class Trainer:
         self.dist = None     # set by parallel.attach(): camera-batch shard, one camera per rank
         # fused=True: the iteration runs as an explicit launch sequence (fused_step.py) instead of render()+autograd
         self.fused = None
-        if fused and stage == "fine" and opt.lambda_dssim == 0 and opt.batch_size == 1:
+        if fused and stage == "fine" and opt.batch_size == 1:
             from .fused_step import FusedStep
             self.fused = FusedStep(gaussians, opt, hyper, self.background)
 

@@ -4,7 +4,6 @@ produces the gradient image and the squared-error sum PSNR needs; ssim keeps the
 from math import exp
 
 import torch
-import torch.nn.functional as F
 
 from .. import ops
 
@@ -40,22 +39,9 @@ def create_window(window_size, channel):
 
 
 def ssim(img1, img2, window_size=11, size_average=True):
-    channel = img1.size(-3)
-    window = create_window(window_size, channel).to(img1.device).type_as(img1)
-    return _ssim(img1, img2, window, window_size, channel, size_average)
-
-
-def _ssim(img1, img2, window, window_size, channel, size_average=True):
-    pad = window_size // 2
-
-    def blur(x):
-        return F.conv2d(x, window, padding=pad, groups=channel)
-
-    mu1, mu2 = blur(img1), blur(img2)
-    mu1_sq, mu2_sq, mu12 = mu1.pow(2), mu2.pow(2), mu1 * mu2
-    s1 = blur(img1 * img1) - mu1_sq
-    s2 = blur(img2 * img2) - mu2_sq
-    s12 = blur(img1 * img2) - mu12
-    C1, C2 = 0.01 ** 2, 0.03 ** 2
-    m = ((2 * mu12 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
-    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+    """Reference utils/loss_utils.py:52-56.  The training loop only ever calls it with the defaults (train_4DGS.py:222),
+    and that is what libmom4d's fused kernels implement (ops.ssim); other windows / per-image means have no HIP kernel
+    and are refused rather than served by a torch fallback."""
+    if window_size != 11 or not size_average:
+        raise ops.N.MomError("ssim: libmom4d implements the reference's default window (11, sigma 1.5) with size_average=True only")
+    return ops.BACKEND.ssim(img1, img2)

@@ -210,6 +210,21 @@ int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double 
  * dimg (may be null) = sign(img-gt)/n = d mean|img-gt| / d img. */
 int mom_l1_loss(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream);
 
+/* ---- SSIM term of the loss (utils/loss_utils.py:29-92: ssim / _ssim / create_window / gaussian) ----
+ * 11x11 Gaussian window = outer product of the 11 taps in window11 (host pointer; the reference's
+ * gaussian(11, 1.5)), zero padding 5, C1 = 0.01^2, C2 = 0.03^2.  Images are [C][H][W] (any leading batch
+ * dimension folded into C: the reference's conv2d is depthwise and its mean runs over every element).
+ * forward:  *sum (device, zeroed by the call) = sum over all C*H*W elements of the SSIM map, so that
+ *           ssim = *sum / (C*H*W); dm (device, [3][C][H][W], or null when no gradient is wanted) receives the
+ *           map's partial derivatives with respect to the blurred mu1, E[img1^2], E[img1*img2].
+ * backward: dimg1 += scale * (scale_dev ? *scale_dev : 1) * d(*sum)/d img1, computed from dm.  For the loss
+ *           term lambda * (1 - ssim) pass scale = -lambda / (C*H*W); scale_dev (device scalar, may be null)
+ *           lets an autograd caller apply its upstream gradient without reading it back. */
+int mom_ssim_forward(int C, int H, int W, const float* window11, const float* img1, const float* img2, float* dm,
+                     double* sum, mom_stream_t stream);
+int mom_ssim_backward(int C, int H, int W, const float* window11, const float* img1, const float* img2, const float* dm,
+                      float scale, const float* scale_dev, float* dimg1, mom_stream_t stream);
+
 /* ---- HexPlane regularisers (scene/gaussian_model.py:730-769, scene/regulation.py:22-28) ----
  * value = sum over planes of w_smooth * mean((p[h+2]-2p[h+1]+p[h])^2) + w_l1 * mean|1-p|
  * (second difference along H, the reference's dim -2); if grad != null, grad_scale * d value / d plane is

@@ -280,15 +280,30 @@ def g8_densify():
     np.savez_compressed(os.path.join(OUT, "g8_densify.npz"), **out)
 
 
+def g9_side_trajectory():
+    """The reference's `side` render trajectory (test_trajectory/side_{R,t}_list, loaded at scene/dataset_readers.py:
+    1170-1171 and turned into cameras at :1003-1018, where the last pose is dropped): 60 rotations and translations.
+    Pure pose data; pins scene/synthetic.py's analytic restatement of it."""
+    R = torch.load(os.path.join(REF, "test_trajectory", "side_R_list"), map_location="cpu", weights_only=False)
+    t = torch.load(os.path.join(REF, "test_trajectory", "side_t_list"), map_location="cpu", weights_only=False)
+    np.savez_compressed(os.path.join(OUT, "g9_side_trajectory.npz"), R=np.stack([np.asarray(r) for r in R]),
+                        t=np.stack([np.asarray(x) for x in t]))
+
+
 if __name__ == "__main__":
+    # python oracle/ref_harness.py            -> every fixture
+    # python oracle/ref_harness.py g9 g3      -> only the named ones (g7 needs g1's field, so it pulls g1 in)
+    only = set(sys.argv[1:])
+    want = lambda n: not only or n in only
     os.makedirs(OUT, exist_ok=True)
     setup()
-    field = g1_hexplane()
-    g2_deform()
-    g3_loss()
-    g4_lr()
-    g5_cameras()
-    g6_sh_cov()
-    g7_regulation(field)
-    g8_densify()
+    field = g1_hexplane() if want("g1") or want("g7") else None
+    if want("g2"): g2_deform()
+    if want("g3"): g3_loss()
+    if want("g4"): g4_lr()
+    if want("g5"): g5_cameras()
+    if want("g6"): g6_sh_cov()
+    if want("g7"): g7_regulation(field)
+    if want("g8"): g8_densify()
+    if want("g9"): g9_side_trajectory()
     print("golden fixtures written to", OUT, sorted(os.listdir(OUT)))

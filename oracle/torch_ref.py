@@ -107,6 +107,7 @@ class TorchBackend:
     name = "torch-oracle"
     hexplane_features = staticmethod(hexplane_features)
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
+    ssim = staticmethod(ssim)
     plane_regulation = staticmethod(plane_regulation)
     Adam = torch.optim.Adam
 

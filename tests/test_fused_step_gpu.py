@@ -12,10 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _run(fused, steps=3):
+def _run(fused, steps=3, lambda_dssim=0.0):
     import bench
     cfg = dict(P=6000, F=4, W=160, H=96, time_res=10, name="tiny")
-    scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=fused)
+    scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=fused, lambda_dssim=lambda_dssim)
+    assert (trainer.fused is not None) == fused
     losses = []
     for it in range(steps):
         cam = trainer.cams[(3 * it + 1) % len(trainer.cams)]
@@ -29,9 +30,11 @@ def _run(fused, steps=3):
     return losses, {k: v.detach().float().cpu().numpy().copy() for k, v in out.items()}
 
 
-def test_fused_step_matches_autograd_path():
-    la, pa = _run(False)
-    lf, pf = _run(True)
+@pytest.mark.parametrize("lambda_dssim", [0.0, 0.2])
+def test_fused_step_matches_autograd_path(lambda_dssim):
+    """lambda_dssim 0 is the reference's default loss, 0.2 adds the SSIM term (train_4DGS.py:222-223)."""
+    la, pa = _run(False, lambda_dssim=lambda_dssim)
+    lf, pf = _run(True, lambda_dssim=lambda_dssim)
     np.testing.assert_allclose(lf, la, rtol=2e-5)
     for k in pa:
         a, b = pf[k], pa[k]

@@ -262,3 +262,20 @@ def test_ply_and_checkpoint_round_trip(tmp_path):
         for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
             np.testing.assert_array_equal(getattr(g2, k).detach().numpy(), d[k])
         assert g2.active_sh_degree == 3
+
+
+def test_g9_side_render_trajectory():
+    """scene/synthetic.py restates the reference's `side` render path analytically; the fixture holds the reference's own
+    pose lists (test_trajectory/side_{R,t}_list).  59 cameras: the reader drops the last pose (dataset_readers.py:1014)."""
+    d = load("g9_side_trajectory.npz")
+    S = importlib.import_module(pkg + ".scene")
+    R, t = S.SyntheticScene.side_trajectory()
+    np.testing.assert_array_equal(R, d["R"])
+    np.testing.assert_allclose(t, d["t"], rtol=0, atol=1e-8)
+    scene = S.SyntheticScene(64, 60, 32, 24, seed=1)
+    cams = scene.getVideoCameras_side()
+    assert len(cams) == 59 and scene.getVideoCameras_side() is cams
+    for i in (0, 17, 58):
+        np.testing.assert_allclose(cams[i].T, d["t"][i], atol=1e-8)
+        np.testing.assert_array_equal(cams[i].R, d["R"][i])
+        assert cams[i].frame_num == i and abs(cams[i].time - i / 59) < 1e-12

@@ -223,3 +223,60 @@ def test_morton_order_is_a_permutation_and_matches_oracle_sort():
         return x
     code = prep(q[:, 0]) | (prep(q[:, 1]) << 1) | (prep(q[:, 2]) << 2)
     np.testing.assert_array_equal(order, np.argsort(code, kind="stable"))
+
+
+# ---------------------------------------------------------------------------------------------- SSIM (survey a13)
+def _image_pair(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.rand(shape, generator=g)
+    img = (gt + 0.15 * torch.randn(shape, generator=g)).clamp(0, 1)
+    return img, gt
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 80), (3, 37, 53), (1, 16, 16), (3, 5, 7), (2, 3, 40, 33)])
+def test_ssim_value_and_gradient_match_the_oracle(shape):
+    """ops.ssim (one fused HIP kernel per direction) against the reference's five depthwise conv2d on the CPU
+    (oracle/torch_ref.ssim, itself pinned by tests/golden/g3_loss.npz).  Ragged sizes exercise the zero padding and the
+    partial tiles; the 4-D case the folded batch dimension."""
+    img, gt = _image_pair(shape, seed=sum(shape))
+    x_ref = img.clone().requires_grad_(True)
+    v_ref = tr.ssim(x_ref if x_ref.dim() == 4 else x_ref[None], gt if gt.dim() == 4 else gt[None])
+    v_ref.backward()
+    x = img.cuda().requires_grad_(True)
+    v = ops.ssim(x, gt.cuda())
+    (0.2 * (1.0 - v)).backward()                     # the loss term of train_4DGS.py:222-223
+    np.testing.assert_allclose(float(v), float(v_ref), rtol=2e-6, atol=1e-7)          # tolerance: fp32 blur order
+    g, g_ref = x.grad.cpu().numpy(), (-0.2 * x_ref.grad).numpy()
+    assert np.abs(g - g_ref).max() <= 2e-5 * np.abs(g_ref).max() + 1e-9, (np.abs(g - g_ref).max(), np.abs(g_ref).max())
+
+
+def test_ssim_properties_at_the_benchmark_size():
+    """Size-independent properties at 3x540x960: ssim(x, x) = 1 with a vanishing gradient, symmetry of the value, and
+    the gradient agrees with a directional finite difference of the HIP forward."""
+    img, gt = _image_pair((3, 540, 960), seed=5)
+    a, b = img.cuda(), gt.cuda()
+    x = a.clone().requires_grad_(True)
+    one = ops.ssim(x, a)
+    one.backward()
+    assert abs(float(one) - 1.0) <= 1e-6
+    assert float(x.grad.abs().max()) <= 1e-6
+    assert abs(float(ops.ssim(a, b)) - float(ops.ssim(b, a))) <= 1e-6
+    x = a.clone().requires_grad_(True)
+    ops.ssim(x, b).backward()
+    d = torch.randn(a.shape, generator=torch.Generator().manual_seed(9)).cuda()
+    eps = 1e-2
+    fd = (float(ops.ssim(a + eps * d, b)) - float(ops.ssim(a - eps * d, b))) / (2 * eps)
+    an = float((x.grad * d).sum())
+    assert abs(fd - an) <= 2e-2 * abs(an) + 1e-6, (fd, an)
+
+
+def test_loss_utils_ssim_runs_the_hip_kernels_and_refuses_other_windows():
+    L = importlib.import_module("iclr2025_3d-mom_amd.utils.loss_utils")
+    N = importlib.import_module("iclr2025_3d-mom_amd._native")
+    img, gt = _image_pair((3, 48, 48), seed=3)
+    v = L.ssim(img.cuda(), gt.cuda())
+    np.testing.assert_allclose(float(v), float(tr.ssim(img[None], gt[None])), rtol=2e-6)
+    with pytest.raises(N.MomError):
+        L.ssim(img.cuda(), gt.cuda(), window_size=7)
+    with pytest.raises(N.MomError):
+        L.ssim(img, gt)                                  # CPU tensors: no fallback
