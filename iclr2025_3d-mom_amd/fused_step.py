@@ -28,6 +28,7 @@ class FusedStep:
         self.P = -1
         self.lib = N.lib()
         self.last = {}
+        self.dist = None      # parallel.DistContext (camera-batch shard): set by parallel.attach()
 
     # ------------------------------------------------------------------ buffers (re-made when P changes)
     def _ensure(self, P, W, H, dev):
@@ -52,9 +53,15 @@ class FusedStep:
         self.ssim_dm = None                  # SSIM term: made on first use (lambda_dssim may be switched on later)
         self.g2d, self.gcol, self.gop_act, self.gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 6)
         self.gsc_act, self.grot_act = e(P, 3), e(P, 4)
-        # parameter gradients (persist across steps; .grad points at them)
-        self.gxyz, self.gdc, self.grest = e(P, 3), e(P, 1, 3), e(P, 15, 3)
-        self.gsc, self.grot, self.gop = e(P, 3), e(P, 4), e(P, 1)
+        # parameter gradients (persist across steps; .grad points at them).  They live in two flat buckets so that a
+        # multi-GPU run all-reduces them in place, without packing: `early` (final once the activation backward has run:
+        # SH, scaling, rotation, opacity = 56 floats per Gaussian) and `late` (xyz + the deformation field, final only
+        # after the HexPlane backward; made in _deform_grads).
+        self.early = e(56 * P)
+        cut = [0, 3 * P, 48 * P, 51 * P, 55 * P, 56 * P]
+        seg = lambda i: self.early[cut[i]:cut[i + 1]]
+        self.gdc, self.grest = seg(0).view(P, 1, 3), seg(1).view(P, 15, 3)
+        self.gsc, self.grot, self.gop = seg(2).view(P, 3), seg(3).view(P, 4), seg(4).view(P, 1)
         self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
         self.regval = e(1)
 
@@ -63,10 +70,11 @@ class FusedStep:
         dn = self.g._deformation.deformation_net
         planes = [p for lv in dn.grid.grids for p in lv]
         mlp = dn._fused_params()
-        key = tuple(p.data_ptr() for p in planes + mlp)
+        key = tuple(p.data_ptr() for p in planes + mlp) + (self.P,)
         if getattr(self, "_dg_key", None) != key:
             n = sum(p.numel() for p in planes + mlp)
-            self._dg_flat = torch.zeros(n, dtype=torch.float32, device=planes[0].device)
+            self._dg_flat = torch.zeros(n + 3 * self.P, dtype=torch.float32, device=planes[0].device)   # the `late` bucket
+            self.gxyz = self._dg_flat[n:].view(self.P, 3)
             off, self._dg_planes, self._dg_mlp = 0, [], []
             for p in planes:       # same channel-last strides as the parameter
                 st = ops.plane_storage(p)
@@ -145,6 +153,10 @@ class FusedStep:
         # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
         n = self.color.numel()
         N.check(lib.mom_l1_loss(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
+        # camera-batch shard: the batch loss is the mean over the ranks' cameras (train_4DGS.py:189-229), so every
+        # gradient carries 1/world and the all-reduces below are plain sums (1/2, 1/4, 1/8 are exact in fp32)
+        dc = self.dist
+        inv_world = 1.0 / dc.world if dc is not None else 1.0
         lam = float(self.opt.lambda_dssim)
         if lam != 0:
             # loss += lambda_dssim * (1 - ssim(image, gt))  (train_4DGS.py:222-223): its gradient is added into dimg
@@ -156,6 +168,8 @@ class FusedStep:
                                          self.ssim_sum.data_ptr(), s), "ssim_fwd")
             N.check(lib.mom_ssim_backward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
                                           -lam / n, None, self.dimg.data_ptr(), s), "ssim_bwd")
+        if dc is not None:
+            self.dimg.mul_(inv_world)
         # ---- rasterizer backward
         gr = N.MomRasterGrads()
         gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = self.g2d.data_ptr(), self.gcol.data_ptr(), self.gop_act.data_ptr()
@@ -164,12 +178,25 @@ class FusedStep:
         gr.dL_dscales, gr.dL_drotations = self.gsc_act.data_ptr(), self.grot_act.data_ptr()
         N.check(lib.mom_raster_backward(C.byref(a), self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
                                         self.cap, self.img.data_ptr(), self.dimg.data_ptr(), None, C.byref(gr), s), "raster_bwd")
+        if dc is not None:      # densification statistics (train_4DGS.py:203-204,227-229): largest radius, mean 2-D gradient
+            dc.start(self.radii, "max")
+            dc.start(self.g2d, "sum")
         N.check(lib.mom_activations_backward(P, self.sc.data_ptr(), self.rot_d.data_ptr(), self.op.data_ptr(),
                                              self.gsc_act.data_ptr(), self.grot_act.data_ptr(), self.gop_act.data_ptr(),
                                              self.gsc.data_ptr(), self.grot.data_ptr(), self.gop.data_ptr(), s), "act_bwd")
+        d_sc, d_rot = self.gsc, self.grot       # also the gradients w.r.t. the MLP's scale / rotation outputs
+        if dc is not None:      # 56 of the 59 floats per Gaussian travel underneath the deformation backward
+            # the deformation backward below still reads this rank's own d_sc / d_rot while the bucket is being reduced in
+            # place: give it private copies (7 floats per Gaussian)
+            if getattr(self, "_loc", None) is None or self._loc[0].shape[0] != P:
+                self._loc = (torch.empty_like(self.gsc), torch.empty_like(self.grot))
+            d_sc, d_rot = self._loc
+            d_sc.copy_(self.gsc)
+            d_rot.copy_(self.grot)
+            dc.start(self.early, "sum")
         # ---- deformation backward: pts = xyz + dx(...) so d xyz starts as d pts (already in gxyz); the HexPlane adds its share
         N.check(lib.mom_deform_backward(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
-                                        self.gsc.data_ptr(), self.grot.data_ptr(), self.dfeat.data_ptr(),
+                                        d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
                                         self.dh_scratch.data_ptr(), s), "deform_bwd")
         N.check(lib.mom_hexplane_backward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.dfeat.data_ptr(),
                                           self.gxyz.data_ptr(), s), "hexplane_bwd")
@@ -185,9 +212,11 @@ class FusedStep:
                 tplane = (i % 6) in (2, 4, 5)
                 arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
                 arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
-                arr[i].grad_scale = 1.0
+                arr[i].grad_scale = inv_world      # identical on every rank: the sum over ranks restores it
             N.check(lib.mom_plane_regulation(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
             reg = self.regval
+        if dc is not None:
+            dc.start(self._dg_flat, "sum")     # xyz + deformation field; the caller waits (DistContext.finish) before Adam
         # ---- hand the gradients to the parameters
         for p, gbuf in ((g._xyz, self.gxyz), (g._features_dc, self.gdc), (g._features_rest, self.grest), (g._scaling, self.gsc),
                         (g._rotation, self.grot), (g._opacity, self.gop)):

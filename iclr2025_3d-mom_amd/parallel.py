@@ -11,6 +11,12 @@ one camera per rank: every rank holds the full model (replica), renders and back
   * densification statistics: max-all-reduce of the radii, sum-all-reduce of the screen-space gradients
     (train_4DGS.py:203-204,227-229).
 
+The fused training step (fused_step.py) keeps its gradients in two flat buckets from the start, scales the loss
+gradient by 1/world at its source and calls start() as soon as a bucket is final: the 56-floats-per-Gaussian bucket
+(SH, scaling, rotation, opacity) is all-reduced on RCCL's stream while the deformation backward still runs; only the
+bucket with xyz and the deformation field (3 floats per Gaussian + 2.9 M) is exposed.  finish() makes the compute
+stream wait for all of them before Adam.  No packing, no rescaling pass.
+
 Everything downstream (densify / prune / Adam) then runs replicated and stays bit-identical across ranks.  The one
 random draw in densify_and_split (gaussian_model.py:525) is made identical by seeding every rank's generator with
 (seed, iteration) before the call.
@@ -23,6 +29,22 @@ class DistContext:
     def __init__(self, rank, world, seed=6666):
         self.rank, self.world, self.seed = rank, world, seed
         self._flat = None
+        self._pending = []
+
+    _OPS = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}
+
+    def start(self, tensor, op="sum"):
+        """Begin an in-place all-reduce of `tensor` (a whole, contiguous buffer) without waiting for it."""
+        if not tensor.is_contiguous():
+            raise ValueError("start() all-reduces in place and needs a contiguous buffer")
+        self._pending.append(dist.all_reduce(tensor, op=self._OPS[op], async_op=True))
+
+    def finish(self):
+        """Every all-reduce begun with start() is complete for work issued after this returns (on a GPU the current
+        stream waits for RCCL's; the host does not block)."""
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
 
     def sync_param_grads(self, optimizer):
         """Average the gradients of every optimised parameter across ranks through one flat bucket."""
@@ -78,4 +100,6 @@ def _storage_order(t):
 
 def attach(trainer, rank, world, seed=6666):
     trainer.dist = DistContext(rank, world, seed)
+    if getattr(trainer, "fused", None) is not None:
+        trainer.fused.dist = trainer.dist
     return trainer.dist

@@ -89,11 +89,12 @@ class Trainer:
     def _step_fused(self, iteration, cam):
         with torch.no_grad():
             loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale)
-            visibility = radii > 0
             if self.dist is not None:
-                self.dist.sync_param_grads(self.g.optimizer)
-                radii, visibility, vsp_grad = self.dist.sync_stats(radii.clone(), vsp_grad.clone())
+                # the step began its all-reduces as each bucket became final (fused_step.py); radii and vsp_grad come
+                # back reduced in place (largest radius over the ranks, mean screen-space gradient)
+                self.dist.finish()
                 self.dist.seed_for(iteration)
+            visibility = radii > 0
             if self.sync_every_step:
                 if torch.isnan(loss).any():
                     raise FloatingPointError("loss is nan")

@@ -61,3 +61,53 @@ def test_camera_batch_shard_matches_single_process_batch(tmp_path):
     for k in s.files:
         np.testing.assert_array_equal(a[k], b[k])                      # replicas stay bit-identical
         np.testing.assert_allclose(a[k], s[k], rtol=2e-5, atol=1e-7)   # and equal the batch_size=2 reference semantics
+
+
+def _run_async_buckets(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    dc = P.DistContext(rank, world)
+    g = torch.Generator().manual_seed(100 + rank)
+    radii = torch.randint(0, 50, (257,), generator=g, dtype=torch.int32)
+    early, late = torch.randn(56 * 257, generator=g), torch.randn(4099, generator=g)
+    mine = {"radii": radii.numpy().copy(), "early": early.numpy().copy(), "late": late.numpy().copy()}
+    dc.start(radii, "max")          # the order fused_step.py issues them in
+    dc.start(early, "sum")
+    early_view_ok = True
+    try:
+        dc.start(early.view(257, 56).t(), "sum")      # not a whole contiguous buffer: refused, nothing enqueued
+        early_view_ok = False
+    except ValueError:
+        pass
+    dc.start(late, "sum")
+    dc.finish()
+    dc.finish()                     # idempotent: nothing pending
+    dist.barrier()
+    dist.destroy_process_group()
+    np.savez(out, radii=radii.numpy(), early=early.numpy(), late=late.numpy(), refused=np.array(early_view_ok),
+             **{"mine_" + k: v for k, v in mine.items()})
+
+
+@pytest.mark.timeout(300)
+def test_async_bucket_all_reduce_world2(tmp_path):
+    """DistContext.start()/finish(): several in-place all-reduces in flight at once (max for the radii, sum for the two
+    gradient buckets), finished together -- the protocol the fused step uses to overlap its exchange with the backward."""
+    port = 31500 + os.getpid() % 2000
+    outs = [str(tmp_path / f"a{r}.npz") for r in range(2)]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run_async_buckets, args=(r, 2, port, outs[r])) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=250)
+        assert p.exitcode == 0
+    a, b = np.load(outs[0]), np.load(outs[1])
+    assert bool(a["refused"]) and bool(b["refused"])
+    np.testing.assert_array_equal(a["radii"], np.maximum(a["mine_radii"], b["mine_radii"]))
+    for k in ("early", "late"):
+        np.testing.assert_array_equal(a[k], b[k])                                   # every rank holds the same sum
+        np.testing.assert_allclose(a[k], a["mine_" + k] + b["mine_" + k], rtol=0, atol=0)
+    np.testing.assert_array_equal(a["radii"], b["radii"])
