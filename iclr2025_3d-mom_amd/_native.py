@@ -27,7 +27,8 @@ class MomRasterArgs(C.Structure):
                 ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
                 ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("scale_modifier", C.c_float),
-                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int)]
+                ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int),
+                ("tile_row0", C.c_int), ("tile_row1", C.c_int)]     # tile-row shard: 0,0 = every row
 
 
 class MomRasterGrads(C.Structure):
@@ -87,6 +88,8 @@ def _sig(lib):
     lib.mom_raster_forward_geometry.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, vp, vp, vp]
     lib.mom_raster_forward_render.argtypes = [C.POINTER(MomRasterArgs), vp, vp, sz, vp, vp, vp, vp, vp]
     lib.mom_raster_backward.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, sz, vp, vp, vp, C.POINTER(MomRasterGrads), vp]
+    lib.mom_raster_backward_render.argtypes = [C.POINTER(MomRasterArgs), vp, vp, sz, vp, vp, vp, vp]
+    lib.mom_raster_backward_geometry.argtypes = [C.POINTER(MomRasterArgs), vp, vp, C.POINTER(MomRasterGrads), vp]
     lib.mom_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
     lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
@@ -125,7 +128,7 @@ EXPORTS = [
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
     "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward",
-    "mom_ssim_forward", "mom_ssim_backward",
+    "mom_ssim_forward", "mom_ssim_backward", "mom_raster_backward_render", "mom_raster_backward_geometry",
 ]
 
 

@@ -88,6 +88,14 @@ static inline char* mom_align_ptr(void* p)
     return (char*)(((uintptr_t)p + MOM_ALIGN - 1) & ~(uintptr_t)(MOM_ALIGN - 1));
 }
 
+// Local tile rows of a (possibly tile-row sharded) launch: [r0, r1) within [0, gy).
+static inline void mom_tile_rows(const MomRasterArgs* a, int gy, int* r0, int* r1)
+{
+    if (a->tile_row0 == 0 && a->tile_row1 == 0) { *r0 = 0; *r1 = gy; return; }
+    *r0 = a->tile_row0 < 0 ? 0 : (a->tile_row0 > gy ? gy : a->tile_row0);
+    *r1 = a->tile_row1 < *r0 ? *r0 : (a->tile_row1 > gy ? gy : a->tile_row1);
+}
+
 #define MOM_CHECK_LAUNCH(a, s)                                         \
     do {                                                               \
         hipError_t e__ = hipGetLastError();                            \

@@ -16,11 +16,22 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
 static int check_args(const MomRasterArgs* a)
 {
     if (!a || a->P < 0 || a->W <= 0 || a->H <= 0) return MOM_EINVAL;
+    if (a->tile_row0 < 0 || a->tile_row1 < a->tile_row0 || a->tile_row1 > (a->H + MOM_TILE - 1) / MOM_TILE) return MOM_EINVAL;
     if (a->P == 0) return MOM_OK;
     if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background) return MOM_EINVAL;
     if (!a->shs && !a->colors_precomp) return MOM_EINVAL;  // rasterizer_impl.cu:243-246
     if (!a->cov3D_precomp && (!a->scales || !a->rotations)) return MOM_EINVAL;
     if (a->shs && !a->colors_precomp && (a->D < 0 || a->D > 3 || a->M < (a->D + 1) * (a->D + 1))) return MOM_EINVAL;
+    return MOM_OK;
+}
+
+static int check_grads(const MomRasterArgs* a, const MomRasterGrads* gr)
+{
+    if (!gr) return MOM_EINVAL;
+    if (!gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dmeans3D || !gr->dL_dcov3D) return MOM_EINVAL;
+    if (a->M > 0 && !a->colors_precomp && !gr->dL_dsh) return MOM_EINVAL;
+    if (a->shs_rest && !gr->dL_dsh_rest) return MOM_EINVAL;
+    if (a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return MOM_EINVAL;
     return MOM_OK;
 }
 
@@ -114,18 +125,14 @@ int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning,
     return MOM_OK;
 }
 
-int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, void* binning, size_t capacity, void* image,
-                        const float* dL_dout_color, const float* dL_dout_depth, const MomRasterGrads* gr, mom_stream_t stream)
+int mom_raster_backward_render(const MomRasterArgs* a, void* geom, void* binning, size_t capacity, void* image,
+                               const float* dL_dout_color, const float* dL_dout_depth, mom_stream_t stream)
 {
     int rc = check_args(a);
     if (rc) return rc;
     if (a->P == 0) return MOM_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (!geom || !binning || !image || !radii || !dL_dout_color || !gr) return MOM_EINVAL;
-    if (!gr->dL_dmeans2D || !gr->dL_dcolors || !gr->dL_dopacity || !gr->dL_dmeans3D || !gr->dL_dcov3D) return MOM_EINVAL;
-    if (a->M > 0 && !a->colors_precomp && !gr->dL_dsh) return MOM_EINVAL;
-    if (a->shs_rest && !gr->dL_dsh_rest) return MOM_EINVAL;
-    if (a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return MOM_EINVAL;
+    if (!geom || !binning || !image || !dL_dout_color) return MOM_EINVAL;
     GeomView g; ImageView im; BinView b;
     geom_view(mom_align_ptr(geom), a->P, &g);
     image_view(mom_align_ptr(image), a->W, a->H, &im);
@@ -133,10 +140,38 @@ int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, vo
     rc = mom_launch_render_bwd(a, g, b, im, capacity, dL_dout_color, dL_dout_depth, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
+    return MOM_OK;
+}
+
+int mom_raster_backward_geometry(const MomRasterArgs* a, const int* radii, void* geom, const MomRasterGrads* gr, mom_stream_t stream)
+{
+    int rc = check_args(a);
+    if (rc) return rc;
+    if (a->P == 0) return MOM_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (!geom || !radii) return MOM_EINVAL;
+    rc = check_grads(a, gr);
+    if (rc) return rc;
+    GeomView g;
+    geom_view(mom_align_ptr(geom), a->P, &g);
     rc = mom_launch_preprocess_bwd(a, radii, g, gr, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
     return MOM_OK;
+}
+
+int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, void* binning, size_t capacity, void* image,
+                        const float* dL_dout_color, const float* dL_dout_depth, const MomRasterGrads* gr, mom_stream_t stream)
+{
+    int rc = check_args(a);                     // every argument is checked before anything is launched
+    if (rc) return rc;
+    if (a->P == 0) return MOM_OK;
+    if (!geom || !binning || !image || !radii || !dL_dout_color) return MOM_EINVAL;
+    rc = check_grads(a, gr);
+    if (rc) return rc;
+    rc = mom_raster_backward_render(a, geom, binning, capacity, image, dL_dout_color, dL_dout_depth, stream);
+    if (rc) return rc;
+    return mom_raster_backward_geometry(a, radii, geom, gr, stream);
 }
 
 int mom_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,

@@ -54,8 +54,9 @@ __device__ __forceinline__ void for_each_instance(int x0, int y0, int x1, int y1
     }
 }
 
-__device__ __forceinline__ void load_rect(const float4* __restrict__ rec, int g, int P, int gx, int gy, int& x0, int& y0,
-                                          int& x1, int& y1, uint32_t& depth_bits)
+// ry0, ry1: the tile rows this launch bins (tile-row shard); a splat's rectangle is cut to them.
+__device__ __forceinline__ void load_rect(const float4* __restrict__ rec, int g, int P, int gx, int gy, int ry0, int ry1, int& x0,
+                                          int& y0, int& x1, int& y1, uint32_t& depth_bits)
 {
     x0 = y0 = x1 = y1 = 0;
     depth_bits = 0;
@@ -64,13 +65,16 @@ __device__ __forceinline__ void load_rect(const float4* __restrict__ rec, int g,
         const int radius = __float_as_int(rec[3 * (size_t)g + 2].w);
         if (radius > 0) {
             mom_get_rect(r0.x, r0.y, radius, gx, gy, x0, y0, x1, y1);
+            y0 = max(y0, ry0);
+            y1 = min(y1, ry1);
+            if (y1 <= y0) x0 = y0 = x1 = y1 = 0;
             depth_bits = __float_as_uint(r0.z);
         }
     }
 }
 
 template <bool LDS_HIST>
-__global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int gx, int gy, const float4* __restrict__ rec,
+__global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int gx, int gy, int ry0, int ry1, const float4* __restrict__ rec,
                                                        uint32_t* __restrict__ tile_counts)
 {
     extern __shared__ uint32_t s_cnt[];
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int g
         const int g = (blockIdx.x * chunks + c) * 256 + threadIdx.x;
         int x0, y0, x1, y1;
         uint32_t db;
-        load_rect(rec, g, P, gx, gy, x0, y0, x1, y1, db);
+        load_rect(rec, g, P, gx, gy, ry0, ry1, x0, y0, x1, y1, db);
         for_each_instance(x0, y0, x1, y1, gx, 0u, [&](int tile, int, uint32_t) {
             if (LDS_HIST)
                 atomicAdd(&s_cnt[tile], 1u);
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
 }
 
 template <bool LDS_HIST>
-__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, int gx, int gy, const float4* __restrict__ rec,
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, int gx, int gy, int ry0, int ry1, const float4* __restrict__ rec,
                                                           uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
                                                           uint32_t capacity, uint32_t* __restrict__ hdr)
 {
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
             const int g = (blockIdx.x * chunks + c) * 256 + threadIdx.x;
             int x0, y0, x1, y1;
             uint32_t db;
-            load_rect(rec, g, P, gx, gy, x0, y0, x1, y1, db);
+            load_rect(rec, g, P, gx, gy, ry0, ry1, x0, y0, x1, y1, db);
             for_each_instance(x0, y0, x1, y1, gx, 0u, [&](int tile, int, uint32_t) { atomicAdd(&s_cnt[tile], 1u); });
         }
         __syncthreads();
@@ -170,7 +174,7 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
         const int wave_g0 = g - mom_lane();
         int x0, y0, x1, y1;
         uint32_t db;
-        load_rect(rec, g, P, gx, gy, x0, y0, x1, y1, db);
+        load_rect(rec, g, P, gx, gy, ry0, ry1, x0, y0, x1, y1, db);
         for_each_instance(x0, y0, x1, y1, gx, db, [&](int tile, int src, uint32_t sdb) {
             const uint32_t pos = LDS_HIST ? atomicAdd(&s_cnt[tile], 1u) : atomicAdd(&tile_cursor[tile], 1u);
             if (pos < capacity)
@@ -245,6 +249,8 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const int tiles = gx * gy;
+    int ry0, ry1;
+    mom_tile_rows(a, gy, &ry0, &ry1);
     if (hipMemsetAsync(im.hdr, 0, 64 * 4, s) != hipSuccess) return MOM_ELAUNCH;
     if (hipMemsetAsync(im.tile_counts, 0, (size_t)tiles * 4, s) != hipSuccess) return MOM_ELAUNCH;
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
@@ -252,10 +258,10 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
     mom_prof_begin(MOM_P_HIST, s);
     if (tiles <= kMaxLdsTiles)
-        hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy, g.rec,
+        hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy, ry0, ry1, g.rec,
                            im.tile_counts);
     else
-        hipLaunchKernelGGL(tile_hist_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, g.rec, im.tile_counts);
+        hipLaunchKernelGGL(tile_hist_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, ry0, ry1, g.rec, im.tile_counts);
     mom_prof_end(MOM_P_HIST, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SCAN, s);
@@ -269,6 +275,8 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const int tiles = gx * gy;
+    int ry0, ry1;
+    mom_tile_rows(a, gy, &ry0, &ry1);
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
     if (chunks < 1) chunks = 1;
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
@@ -276,9 +284,9 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     mom_prof_begin(MOM_P_SCATTER, s);
     if (tiles <= kMaxLdsTiles)
         hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy,
-                           g.rec, im.tile_cursor, b.keys, cap, im.hdr);
+                           ry0, ry1, g.rec, im.tile_cursor, b.keys, cap, im.hdr);
     else
-        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, g.rec,
+        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, ry0, ry1, g.rec,
                            im.tile_cursor, b.keys, cap, im.hdr);
     mom_prof_end(MOM_P_SCATTER, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;

@@ -108,13 +108,13 @@ __device__ __forceinline__ float splat_power(const float4 r0, const float4 r1, f
 }
 
 __global__ void __launch_bounds__(256)
-render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt,
+render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0,
                   const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
                   uint32_t capacity)
 {
     __shared__ float4 s_rec[256 * 3];
-    const int tile = remap_tile(blockIdx.x, nt);
+    const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
@@ -184,14 +184,14 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
 }
 
 __global__ void __launch_bounds__(256)
-render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt,
+render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0,
                   const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                   const float* __restrict__ dL_dpixel_depths, float* __restrict__ gacc, uint32_t capacity)
 {
     __shared__ float4 s_rec[256 * 3];
     __shared__ uint32_t s_id[256];
-    const int tile = remap_tile(blockIdx.x, nt);
+    const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
@@ -311,7 +311,11 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
     MomProfScope ps(MOM_P_RENDER_FWD, s);
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, gx * gy,
+    int ry0, ry1;
+    mom_tile_rows(a, gy, &ry0, &ry1);
+    const int nt = gx * (ry1 - ry0);
+    if (nt == 0) return MOM_OK;
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0,
                        g.rec, a->background, im.final_T, im.n_contrib, out_color, out_depth, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
@@ -323,7 +327,11 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
     if (hipMemsetAsync(g.gacc, 0, (size_t)a->P * 48, s) != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_RENDER_BWD, s);
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, gx * gy,
+    int ry0, ry1;
+    mom_tile_rows(a, gy, &ry0, &ry1);
+    const int nt = gx * (ry1 - ry0);
+    if (nt == 0) return MOM_OK;
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0,
                        g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

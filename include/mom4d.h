@@ -68,6 +68,11 @@ typedef struct MomRasterArgs {
     float tan_fovx, tan_fovy;
     int prefiltered;
     int debug;             /* !=0: hipStreamSynchronize + error check after every kernel (CHECK_CUDA, auxiliary.h:166-173) */
+    /* Tile-row shard (one image split over several GPUs; the reference has no counterpart): bin, composite and
+     * back-propagate only the 16-pixel tile rows [tile_row0, tile_row1).  0,0 = every row.  Projection is
+     * unaffected (radii, depths, conics are those of the whole image); num_rendered counts the local instances;
+     * pixels of other rows are neither read nor written. */
+    int tile_row0, tile_row1;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
@@ -120,6 +125,17 @@ typedef struct MomRasterGrads {
 int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, void* binning, size_t capacity,
                         void* image, const float* dL_dout_color, const float* dL_dout_depth,
                         const MomRasterGrads* g, mom_stream_t stream);
+
+/* The two halves of mom_raster_backward, for callers that must exchange between them (tile-row shard):
+ * _render runs the compositing backward over this rank's tile rows and leaves, in the geometry scratch at
+ * mom_raster_layout().geom_gacc, one record of 12 floats per Gaussian: the sums over the local pixels of
+ * dL/d{mean2D.x, mean2D.y, conic.x, conic.y, conic.z, opacity, r, g, b, depth} and two zeros.  The
+ * projection backward is linear in that record, so ranks sum it (an all-reduce of 48 bytes per Gaussian) and
+ * then each runs _geometry, which yields identical parameter gradients everywhere. */
+int mom_raster_backward_render(const MomRasterArgs* a, void* geom, void* binning, size_t capacity, void* image,
+                               const float* dL_dout_color, const float* dL_dout_depth, mom_stream_t stream);
+int mom_raster_backward_geometry(const MomRasterArgs* a, const int* radii, void* geom, const MomRasterGrads* grads,
+                                 mom_stream_t stream);
 
 /* checkFrustum (rasterizer_impl.cu:54-66): present[i] = p_view.z > 0.2 */
 int mom_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
