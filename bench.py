@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-mode", default="async", choices=["async", "exact"])
     ap.add_argument("--roofline-kernel", default="render_bwd")
+    ap.add_argument("--shard", default="camera", choices=["camera", "tile-row"],
+                    help="N > 1: camera = one camera per GPU per step (weak scaling, the reference's batch axis); "
+                         "tile-row = one camera per step split over the GPUs by rows of 16-pixel tiles (strong scaling)")
     ap.add_argument("--lambda-dssim", type=float, default=0.0,
                     help="weight of the SSIM loss term in the headline value (0 = the reference's default)")
     ap.add_argument("--no-extra", action="store_true",
@@ -168,12 +171,12 @@ def main():
     par = None
     if world > 1:
         par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
-        par.attach(trainer, rank, world)
+        par.attach(trainer, rank, world, mode=a.shard)
     it0 = 5000  # mid-training iteration numbers: densification statistics on, no densify/reset in the window
 
     def one(i):
         # every rank takes a different camera of the cycle (camera-batch shard); N=1 walks all F+5 cameras
-        cam = cams[(i * world + rank) % len(cams)]
+        cam = cams[(i * world + rank) % len(cams)] if a.shard == "camera" else cams[i % len(cams)]
         return trainer.step(it0 + 1 + (i % 90), cams=[cam])
 
     DGR.set_sync_mode("exact")
@@ -204,13 +207,13 @@ def main():
         dt = float(tt[0])
     assert torch.isfinite(loss).all(), "loss is not finite"
     out = {
-        "metric": metric_name(), "value": a.steps * world / dt,
+        "metric": metric_name(), "value": a.steps * (world if a.shard == "camera" else 1) / dt,
         "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if a.shard == "camera" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "gaussians": cfg["P"], "frames": cfg["F"], "width": cfg["W"],
                    "height": cfg["H"], "instances_R": int((DGR.last_num_rendered() if trainer.fused is None else trainer.fused.nr_host[0]) or 0),
                    "sh_degree": 3, "step_path": a.path, "batch_size": 1,
-                   "lambda_dssim": a.lambda_dssim, "parallelism": f"camera-batch x{world}" if world > 1 else "single",
+                   "lambda_dssim": a.lambda_dssim, "parallelism": (f"camera-batch x{world}" if a.shard == "camera" else f"tile-row x{world}") if world > 1 else "single",
                    "host_sync": a.sync_mode, "final_loss": float(loss)},
     }
     if rank == 0:

@@ -65,6 +65,13 @@ class FusedStep:
         self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
         self.regval = e(1)
 
+    def _gacc_view(self, P, W, H):
+        """The per-Gaussian record of the compositing backward inside the geometry scratch, as a flat fp32 tensor."""
+        lay = N.MomRasterLayout()
+        self.lib.mom_raster_layout(P, W, H, 0, C.byref(lay))
+        base = self.geom[(-self.geom.data_ptr()) % 256:]
+        return base[lay.geom_gacc:lay.geom_gacc + P * 48].view(torch.float32)
+
     def _deform_grads(self):
         """Flat zero-able gradient storage for the deformation field (planes channel-last + live MLP tensors)."""
         dn = self.g._deformation.deformation_net
@@ -133,6 +140,15 @@ class FusedStep:
         a.scale_modifier = 1.0
         a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         a.prefiltered, a.debug = 0, 0
+        dc = self.dist
+        rows = None
+        if dc is not None and dc.mode == "tile-row":
+            # every rank renders this same camera, restricted to its rows of 16-pixel tiles
+            if float(self.opt.lambda_dssim) != 0:
+                raise N.MomError("tile-row sharding does not carry the SSIM term yet (its 11x11 window needs a 5-pixel halo "
+                                 "across row boundaries): use lambda_dssim 0 or the camera-batch shard")
+            rows = dc.rows((H + 15) // 16)
+            a.tile_row0, a.tile_row1 = rows
         # the previous iteration's instance count / overflow flag are long complete: read them without blocking
         prev_R = int(self.nr_host[0])
         if int(self.status_host[0]) & 1:
@@ -155,8 +171,7 @@ class FusedStep:
         N.check(lib.mom_l1_loss(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
         # camera-batch shard: the batch loss is the mean over the ranks' cameras (train_4DGS.py:189-229), so every
         # gradient carries 1/world and the all-reduces below are plain sums (1/2, 1/4, 1/8 are exact in fp32)
-        dc = self.dist
-        inv_world = 1.0 / dc.world if dc is not None else 1.0
+        inv_world = 1.0 / dc.world if (dc is not None and dc.mode == "camera") else 1.0
         lam = float(self.opt.lambda_dssim)
         if lam != 0:
             # loss += lambda_dssim * (1 - ssim(image, gt))  (train_4DGS.py:222-223): its gradient is added into dimg
@@ -168,7 +183,7 @@ class FusedStep:
                                          self.ssim_sum.data_ptr(), s), "ssim_fwd")
             N.check(lib.mom_ssim_backward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
                                           -lam / n, None, self.dimg.data_ptr(), s), "ssim_bwd")
-        if dc is not None:
+        if dc is not None and dc.mode == "camera":
             self.dimg.mul_(inv_world)
         # ---- rasterizer backward
         gr = N.MomRasterGrads()
@@ -176,16 +191,28 @@ class FusedStep:
         gr.dL_dmeans3D, gr.dL_dcov3D = self.gxyz.data_ptr(), self.gcov.data_ptr()
         gr.dL_dsh, gr.dL_dsh_rest = self.gdc.data_ptr(), self.grest.data_ptr()
         gr.dL_dscales, gr.dL_drotations = self.gsc_act.data_ptr(), self.grot_act.data_ptr()
-        N.check(lib.mom_raster_backward(C.byref(a), self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
-                                        self.cap, self.img.data_ptr(), self.dimg.data_ptr(), None, C.byref(gr), s), "raster_bwd")
-        if dc is not None:      # densification statistics (train_4DGS.py:203-204,227-229): largest radius, mean 2-D gradient
+        if rows is None:
+            N.check(lib.mom_raster_backward(C.byref(a), self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
+                                            self.cap, self.img.data_ptr(), self.dimg.data_ptr(), None, C.byref(gr), s), "raster_bwd")
+        else:
+            # tile-row shard: the compositing backward covers this rank's rows only (dimg outside them is never read); the
+            # per-Gaussian record it leaves is summed over the ranks, after which the projection backward -- linear in that
+            # record -- and everything downstream give the same gradients on every rank, with nothing left to exchange
+            N.check(lib.mom_raster_backward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
+                                                   self.img.data_ptr(), self.dimg.data_ptr(), None, s), "raster_bwd_render")
+            dc.start(self._gacc_view(P, W, H), "sum")
+            dc.finish()
+            N.check(lib.mom_raster_backward_geometry(C.byref(a), self.radii.data_ptr(), self.geom.data_ptr(), C.byref(gr), s),
+                    "raster_bwd_geometry")
+        if dc is not None and dc.mode == "camera":
+            # densification statistics (train_4DGS.py:203-204,227-229): largest radius, mean 2-D gradient
             dc.start(self.radii, "max")
             dc.start(self.g2d, "sum")
         N.check(lib.mom_activations_backward(P, self.sc.data_ptr(), self.rot_d.data_ptr(), self.op.data_ptr(),
                                              self.gsc_act.data_ptr(), self.grot_act.data_ptr(), self.gop_act.data_ptr(),
                                              self.gsc.data_ptr(), self.grot.data_ptr(), self.gop.data_ptr(), s), "act_bwd")
         d_sc, d_rot = self.gsc, self.grot       # also the gradients w.r.t. the MLP's scale / rotation outputs
-        if dc is not None:      # 56 of the 59 floats per Gaussian travel underneath the deformation backward
+        if dc is not None and dc.mode == "camera":      # 56 of the 59 floats per Gaussian travel underneath the deformation backward
             # the deformation backward below still reads this rank's own d_sc / d_rot while the bucket is being reduced in
             # place: give it private copies (7 floats per Gaussian)
             if getattr(self, "_loc", None) is None or self._loc[0].shape[0] != P:
@@ -215,7 +242,7 @@ class FusedStep:
                 arr[i].grad_scale = inv_world      # identical on every rank: the sum over ranks restores it
             N.check(lib.mom_plane_regulation(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
             reg = self.regval
-        if dc is not None:
+        if dc is not None and dc.mode == "camera":
             dc.start(self._dg_flat, "sum")     # xyz + deformation field; the caller waits (DistContext.finish) before Adam
         # ---- hand the gradients to the parameters
         for p, gbuf in ((g._xyz, self.gxyz), (g._features_dc, self.gdc), (g._features_rest, self.grest), (g._scaling, self.gsc),
@@ -225,7 +252,24 @@ class FusedStep:
             p.grad = gbuf
         for p, gbuf in zip(mlp, self._dg_mlp):
             p.grad = gbuf
-        l1 = self.sums[0] / n
+        if rows is None:
+            l1 = self.sums[0] / n
+        else:
+            # the image holds this rank's rows only: the logged L1 is the sum of the ranks' row slabs (value only; the
+            # gradient image above is already normalised by the whole image's element count)
+            y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
+            if getattr(self, "_slab_sums", None) is None:
+                self._slab_sums = torch.zeros(3, 2, dtype=torch.float32, device=dev)
+            self._slab_sums.zero_()
+            if y1 > y0:
+                for c in range(3):
+                    N.check(lib.mom_l1_loss((y1 - y0) * W, self.color[c, y0:y1].data_ptr(), gt[c, y0:y1].data_ptr(), None,
+                                            self._slab_sums[c].data_ptr(), s), "l1_slab")
+            tot = self._slab_sums.sum(0)
+            dc.start(tot, "sum")
+            dc.finish()
+            self.sums.copy_(tot)
+            l1 = tot[0] / n
         loss = l1 if reg is None else l1 + reg[0]
         if lam != 0:
             loss = loss + lam * (1.0 - (self.ssim_sum[0] / n).float())

@@ -25,11 +25,55 @@ import torch
 import torch.distributed as dist
 
 
+def split_rows(n_rows, world, weights=None):
+    """Contiguous split of `n_rows` (>= 1) tile rows over `world` ranks: [(row0, row1), ...], one entry per rank,
+    covering [0, n_rows) in order.  `weights[r]` (e.g. the instance count of tile row r) balances the split by work
+    instead of by row count: rank k ends at the first row where the running weight reaches (k+1)/world of the total.
+    Every rank gets at least one row when n_rows >= world (a rank never takes rows the ranks after it need); with fewer
+    rows than ranks the last ranks get the empty range (n_rows, n_rows) -- never (0, 0), which MomRasterArgs reads as
+    "every row"."""
+    if n_rows < 1 or world < 1:
+        raise ValueError("split_rows: need n_rows >= 1 and world >= 1")
+    w = [1.0] * n_rows if weights is None else [max(0.0, float(x)) for x in weights]
+    if len(w) != n_rows:
+        raise ValueError("split_rows: one weight per row")
+    if sum(w) <= 0:
+        w = [1.0] * n_rows
+    total, out, start, run = sum(w), [], 0, 0.0
+    for k in range(world):
+        if start >= n_rows:
+            out.append((n_rows, n_rows))
+            continue
+        if k == world - 1:
+            end = n_rows
+        else:
+            target = total * (k + 1) / world
+            last = max(start + 1, n_rows - (world - k - 1))        # leave one row for each rank still to come
+            end = start
+            while end < last and (end == start or run + w[end] <= target + 1e-9 * total):
+                run += w[end]
+                end += 1
+            run = sum(w[:end])
+        out.append((start, end))
+        start = end
+    return out
+
+
 class DistContext:
-    def __init__(self, rank, world, seed=6666):
-        self.rank, self.world, self.seed = rank, world, seed
+    """mode "camera": every rank renders its own camera of the step (the reference's batch axis).
+    mode "tile-row": every rank renders the SAME camera, restricted to its tile rows; the per-Gaussian record of the
+    compositing backward is summed across ranks and everything after it is replicated (fused step only)."""
+
+    def __init__(self, rank, world, seed=6666, mode="camera"):
+        if mode not in ("camera", "tile-row"):
+            raise ValueError(f"unknown shard mode {mode!r}")
+        self.rank, self.world, self.seed, self.mode = rank, world, seed, mode
         self._flat = None
         self._pending = []
+
+    def rows(self, n_rows):
+        """This rank's tile rows of an image with n_rows rows of tiles (equal split by row count)."""
+        return split_rows(n_rows, self.world)[self.rank]
 
     _OPS = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}
 
@@ -98,8 +142,10 @@ def _storage_order(t):
     return sorted(range(t.dim()), key=lambda i: (-t.stride(i), i))
 
 
-def attach(trainer, rank, world, seed=6666):
-    trainer.dist = DistContext(rank, world, seed)
+def attach(trainer, rank, world, seed=6666, mode="camera"):
+    trainer.dist = DistContext(rank, world, seed, mode)
     if getattr(trainer, "fused", None) is not None:
         trainer.fused.dist = trainer.dist
+    elif mode == "tile-row":
+        raise ValueError("tile-row sharding is implemented by the fused step (Trainer(..., fused=True), fine stage, batch_size 1)")
     return trainer.dist

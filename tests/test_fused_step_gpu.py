@@ -48,6 +48,8 @@ def test_fused_step_matches_autograd_path(lambda_dssim):
 class _VirtualRank:
     """Stands in for parallel.DistContext on one GPU: captures each buffer at start() and then poisons it, which is what
     a concurrent in-place all-reduce does to it from the point of view of any later kernel that still reads it."""
+    mode = "camera"
+
     def __init__(self, world):
         self.world, self.captured = world, []
 
@@ -96,3 +98,67 @@ def test_camera_batch_buckets_of_two_virtual_ranks_sum_to_the_batch_mean():
         assert torch.isfinite(got).all(), k
         scale = float(want.abs().max())
         assert float((got - want).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((got - want).abs().max()), scale)
+
+
+class _RowRank:
+    """Stand-in for parallel.DistContext(mode="tile-row") on one GPU.  Pass 1 (feed=None) captures what the rank hands to
+    start(); pass 2 writes the sum over the ranks back into the buffer, which is what the all-reduce leaves there."""
+    mode = "tile-row"
+
+    def __init__(self, rank, world, feed=None):
+        self.rank, self.world, self.feed, self.captured = rank, world, feed, []
+
+    def rows(self, n_rows):
+        split = importlib.import_module("iclr2025_3d-mom_amd.parallel").split_rows
+        return split(n_rows, self.world)[self.rank]
+
+    def start(self, tensor, op="sum"):
+        assert op == "sum" and tensor.is_contiguous()
+        self.captured.append(tensor.clone())
+        if self.feed is not None:
+            tensor.copy_(self.feed[len(self.captured) - 1])
+
+    def finish(self):
+        pass
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world):
+    """BASELINE config 4 on one GPU: `world` virtual ranks render the same camera, each its own tile rows, exchange the
+    per-Gaussian record of the compositing backward (and the L1 slab sums), and must all end with the unsharded step's
+    gradients, statistics and loss."""
+    import bench
+    cfg = dict(P=6000, F=4, W=160, H=96, time_res=10, name="tiny")            # 6 tile rows
+    scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=True)
+    fs, cam = trainer.fused, trainer.cams[2]
+
+    def run(dist):
+        fs.dist = dist
+        loss, radii, g2d = fs.forward_backward(cam, 1)
+        torch.cuda.synchronize()
+        return {"loss": float(loss), "radii": radii.clone(), "g2d": g2d.clone(), "early": fs.early.clone(),
+                "late": fs._dg_flat.clone(), "mse": float(fs.last["mse_sum"])}
+
+    want = run(None)
+    first = [_RowRank(r, world) for r in range(world)]
+    for d in first:
+        run(d)
+        assert len(d.captured) == 2                                   # the record, then the L1 slab sums
+    feed = [sum(d.captured[i] for d in first) for i in range(2)]
+    rows = [d.rows(6) for d in first]
+    assert rows[0][0] == 0 and rows[-1][1] == 6 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    for r in range(world):
+        got = run(_RowRank(r, world, feed))
+        assert abs(got["loss"] - want["loss"]) <= 1e-6 * max(1.0, abs(want["loss"])), (got["loss"], want["loss"])
+        assert abs(got["mse"] - want["mse"]) <= 1e-5 * abs(want["mse"])
+        torch.testing.assert_close(got["radii"], want["radii"], rtol=0, atol=0)
+        for k in ("g2d", "early", "late"):
+            scale = float(want[k].abs().max())
+            err = float((got[k] - want[k]).abs().max())
+            assert torch.isfinite(got[k]).all() and err <= 3e-5 * scale + 1e-9, (r, k, err, scale)
+    fs.dist = None
+    op.lambda_dssim = 0.2                                               # refused, not silently wrong
+    with pytest.raises(Exception, match="tile-row"):
+        run(_RowRank(0, 2))
+    op.lambda_dssim = 0.0
+    fs.dist = None

@@ -111,3 +111,30 @@ def test_async_bucket_all_reduce_world2(tmp_path):
         np.testing.assert_array_equal(a[k], b[k])                                   # every rank holds the same sum
         np.testing.assert_allclose(a[k], a["mine_" + k] + b["mine_" + k], rtol=0, atol=0)
     np.testing.assert_array_equal(a["radii"], b["radii"])
+
+
+def test_split_rows_partitions():
+    """parallel.split_rows: contiguous, ordered, complete; balanced by weight; never (0, 0) for an empty range."""
+    split = importlib.import_module("iclr2025_3d-mom_amd.parallel").split_rows
+    assert split(34, 8) == [(0, 4), (4, 8), (8, 12), (12, 17), (17, 21), (21, 25), (25, 29), (29, 34)]   # 960x540, 8 GPUs
+    assert split(34, 2) == [(0, 17), (17, 34)]
+    assert split(7, 1) == [(0, 7)]
+    assert split(5, 8) == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 5), (5, 5), (5, 5)]              # more ranks than rows
+    assert split(1, 3) == [(0, 1), (1, 1), (1, 1)]
+    assert split(6, 3, [10, 0, 0, 0, 0, 10]) == [(0, 1), (1, 5), (5, 6)]                               # by work, not by count
+    assert split(6, 3, [1, 1, 1, 1, 1, 100]) == [(0, 4), (4, 5), (5, 6)]                               # no rank starved
+    assert split(4, 4, [0, 0, 0, 0]) == [(0, 1), (1, 2), (2, 3), (3, 4)]
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n, w = int(rng.integers(1, 70)), int(rng.integers(1, 10))
+        weights = None if rng.random() < 0.3 else rng.integers(0, 1000, n).tolist()
+        parts = split(n, w, weights)
+        assert len(parts) == w and [r for a, b in parts for r in range(a, b)] == list(range(n))
+        assert all(a <= b for a, b in parts) and all(p != (0, 0) for p in parts)
+        if n >= w:
+            assert all(b > a for a, b in parts)
+    for bad in ((0, 3), (3, 0)):
+        with pytest.raises(ValueError):
+            split(*bad)
+    with pytest.raises(ValueError):
+        split(3, 2, [1, 2])
