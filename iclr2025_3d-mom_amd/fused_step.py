@@ -115,14 +115,20 @@ class FusedStep:
         optr = None if order is None else order.data_ptr()
 
         # ---- deformation field
-        levels = [list(lv) for lv in field.grids]
-        gl, k = [], 0
-        for lv in levels:
-            gl.append(self._dg_planes[k:k + 6])
-            k += 6
-        hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in levels], field.aabb, gl, aabb_host=field.aabb_host())
+        # the descriptors only hold pointers and shapes: rebuilt when a parameter or the aabb moves, not every iteration
+        dkey = (self._dg_key, tuple(field.aabb_host()))
+        if getattr(self, "_desc_key", None) != dkey:
+            levels = [list(lv) for lv in field.grids]
+            gl, k = [], 0
+            for lv in levels:
+                gl.append(self._dg_planes[k:k + 6])
+                k += 6
+            hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in levels], field.aabb, gl, aabb_host=field.aabb_host())
+            md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], self._dg_mlp)
+            self._desc = (hp, keep, md)
+            self._desc_key, self._reg_arr = dkey, None
+        hp, keep, md = self._desc
         N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.feat.data_ptr(), s), "hexplane_fwd")
-        md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], self._dg_mlp)
         coef = float(delta_scale * cam.frame_num)
         N.check(lib.mom_deform_forward(C.byref(md), P, self.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
                                        flow.data_ptr(), coef, self.pts.data_ptr(), self.sc_d.data_ptr(),
@@ -231,15 +237,19 @@ class FusedStep:
         hy = self.hyper
         reg = None
         if hy.time_smoothness_weight != 0:
-            arr = (N.MomRegPlane * len(planes))()
-            for i, p in enumerate(planes):
-                st, gs = ops.plane_storage(p.detach()), ops.plane_storage(self._dg_planes[i])
-                arr[i].plane, arr[i].grad = st.data_ptr(), gs.data_ptr()
-                arr[i].H, arr[i].W = st.shape[0], st.shape[1]
-                tplane = (i % 6) in (2, 4, 5)
-                arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
-                arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
-                arr[i].grad_scale = inv_world      # identical on every rank: the sum over ranks restores it
+            rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, inv_world)
+            if self._reg_arr is None or self._reg_arr[0] != rkey:
+                arr = (N.MomRegPlane * len(planes))()
+                for i, p in enumerate(planes):
+                    st, gs = ops.plane_storage(p.detach()), ops.plane_storage(self._dg_planes[i])
+                    arr[i].plane, arr[i].grad = st.data_ptr(), gs.data_ptr()
+                    arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+                    tplane = (i % 6) in (2, 4, 5)
+                    arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
+                    arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
+                    arr[i].grad_scale = inv_world      # identical on every rank: the sum over ranks restores it
+                self._reg_arr = (rkey, arr)
+            arr = self._reg_arr[1]
             N.check(lib.mom_plane_regulation(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
             reg = self.regval
         if dc is not None and dc.mode == "camera":

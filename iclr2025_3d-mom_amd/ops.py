@@ -336,6 +336,30 @@ class FusedAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._plan = None
+
+    def _build_plan(self, live, key):
+        """Validate every (param, grad, state) once and lay the MomAdamTensor arrays out; reused until a pointer moves
+        (densify / prune / reset_opacity replace parameters and state, load_state_dict replaces state)."""
+        by_cfg, entries, steps = {}, [], []
+        for group, p in live:
+            _need_cuda(p, "FusedAdam")
+            st = self.state[p]
+            g = p.grad
+            if not _same_layout(g, p) or not _dense(p):
+                raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
+            b1, b2 = group["betas"]
+            cfg = (b1, b2, group["eps"])
+            slot = by_cfg.setdefault(cfg, [])
+            t = N.MomAdamTensor()
+            t.param, t.grad = p.data_ptr(), g.data_ptr()
+            t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
+            t.n = p.numel()
+            entries.append((group, b1, b2, cfg, len(slot)))
+            slot.append(t)
+            steps.append(st["step"])
+        arrs = {cfg: (N.MomAdamTensor * len(ts))(*ts) for cfg, ts in by_cfg.items()}
+        return {"key": key, "entries": entries, "steps": steps, "arrs": arrs}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -343,34 +367,30 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        by_cfg = {}
-        for group in self.param_groups:
-            b1, b2 = group["betas"]
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                _need_cuda(p, "FusedAdam")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                step = float(st["step"])
-                g = p.grad
-                if not _same_layout(g, p) or not _dense(p):
-                    raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
-                t = N.MomAdamTensor()
-                t.param, t.grad = p.data_ptr(), g.data_ptr()
-                t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-                t.n = p.numel()
-                t.lr = float(group["lr"])
-                t.bias_correction1 = 1.0 - b1 ** step
-                t.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
-                by_cfg.setdefault((b1, b2, group["eps"]), []).append(t)
-        for (b1, b2, eps), ts in by_cfg.items():
-            arr = (N.MomAdamTensor * len(ts))(*ts)
-            N.check(N.lib().mom_adam_step(arr, len(ts), b1, b2, eps, N.current_stream()), "mom_adam_step")
+        live = [(group, p) for group in self.param_groups for p in group["params"] if p.grad is not None]
+        if not live:
+            return loss
+        for _, p in live:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                     id(self.state[p]["step"])) for _, p in live)
+        plan = self._plan
+        if plan is None or plan["key"] != key:
+            plan = self._plan = self._build_plan(live, key)
+        torch._foreach_add_(plan["steps"], 1)
+        arrs = plan["arrs"]
+        for (group, b1, b2, cfg, i), st_step in zip(plan["entries"], plan["steps"]):
+            step = float(st_step)
+            t = arrs[cfg][i]
+            t.lr = float(group["lr"])
+            t.bias_correction1 = 1.0 - b1 ** step
+            t.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
+        for (b1, b2, eps), arr in arrs.items():
+            N.check(N.lib().mom_adam_step(arr, len(arr), b1, b2, eps, N.current_stream()), "mom_adam_step")
         return loss
 
 

@@ -9,6 +9,9 @@ import ctypes as C
 from . import _native as N
 
 HBM_PEAK_GBS = 8000.0
+FP32_VALU_PEAK_TFLOPS = 157.0      # MI355X fp32 vector peak (MI355X_MICROARCH.md)
+# SURVEY 8d, "Raster VALU": FLOP per evaluated (pixel, splat) pair, with one exp each; Q = 256 R pairs per launch
+VALU_FLOP_PER_PAIR = {"render_fwd": 20, "render_bwd": 70}
 
 SLOTS = {n: i for i, n in enumerate(
     ["preprocess_fwd", "tile_hist", "tile_scan", "tile_scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd",
@@ -51,6 +54,16 @@ def roofline(kernel, P, R, Npix, traffic=None):
     avg_s = ms / cnt * 1e-3
     b = algorithmic_bytes(kernel, P, R, Npix)
     achieved = b / avg_s / 1e9
-    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
-            "algorithmic_bytes_per_launch": b}
+    out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
+           "algorithmic_bytes_per_launch": b}
+    if kernel in VALU_FLOP_PER_PAIR:
+        # secondary ceiling: the compositing loops are bound by fp32 VALU issue, not by HBM.  Nominal work:
+        # every one of the 256 pixels of a tile evaluates every splat of the tile's list.
+        flop = 256.0 * R * VALU_FLOP_PER_PAIR[kernel]
+        tf = flop / avg_s / 1e12
+        out["valu"] = {"achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS,
+                       "flop_per_pair": VALU_FLOP_PER_PAIR[kernel], "pairs_per_launch": 256 * R,
+                       "note": "nominal pair count; the kernels skip pairs that cannot contribute, so this can exceed what "
+                               "is executed"}
+    return out

@@ -2,6 +2,10 @@
 final synchronize (host time per step) and with it (wall time per step).  If the two are close, the step is bound by
 the host's launch rate, not by the GPU.
 
+Use a SHORT run (--steps 10..50) to read the host's own cost: once more work is queued than the launch queue holds,
+further launches block until the GPU catches up and "host enqueue" just tracks the GPU step (long runs still tell
+host-bound from GPU-bound correctly through the work left in flight at the end).
+
     python tools/host_rate.py [--config c2] [--steps 200]
 """
 import argparse
