@@ -26,6 +26,7 @@
 // 64x64 results live in 256 accumulator registers for the wave's whole range, and the bias gradients fall out of
 // the A operands for free.  No atomics until one float atomic per weight per workgroup at the very end.
 #include "mom_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -335,6 +336,13 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
 }
 
 // (B) weight gradients: dW_L[o][i] = sum_g dH_L[g][o] X_L[g][i], db_L[o] = sum_g dH_L[g][o];  X_0 = feat, X_1..3 = a0
+//
+// The kernel streams 12 dwords per lane per K-step and is bound by how many cache misses a CU keeps in flight, not by
+// the matrix pipe (SQ counters: MFMA busy 30 % of the time, the rest issue stalls on VMEM).  With all four layers per
+// wave the 256 accumulators allow one wave per SIMD; NL layers per wave (blockIdx.y picks which: layers [NL*y, NL*y+NL))
+// need 64*NL accumulators, so 4/NL waves fit per SIMD and the CU has that many times more loads in flight.  dH is still read
+// exactly once overall; a0 is read once per workgroup row that holds one of the layers 1..3.
+template <int NL>
 __global__ void __launch_bounds__(256)
 deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat, const float* __restrict__ a0g,
                      const float* __restrict__ dH)
@@ -342,58 +350,88 @@ deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat,
     extern __shared__ float lds[];                     // [64][64] reduction scratch
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int L0 = NL * blockIdx.y;                    // first layer of this workgroup row
     const size_t PH = (size_t)P * kHid;
     const int g_begin = wave * chunk, g_end = min(P, g_begin + chunk);   // chunk is even
 
-    f32x16 dW[4][2][2];
-    float db[4][2];
+    f32x16 dW[NL][2][2];
+    float db[NL][2];
 #pragma unroll
-    for (int L = 0; L < 4; L++) {
-        zero_tile(dW[L][0]);
-        zero_tile(dW[L][1]);
-        db[L][0] = db[L][1] = 0.f;
+    for (int l = 0; l < NL; l++) {
+        zero_tile(dW[l][0]);
+        zero_tile(dW[l][1]);
+        db[l][0] = db[l][1] = 0.f;
     }
-    // UNR K-steps (2 gaussians each) per trip: all 12*UNR operand loads are issued before the first MFMA needs one
+    // Operand loads are double buffered by hand.  A trip is UNR K-steps (2 gaussians each); the loads of trip t+1 are issued
+    // before the MFMAs of trip t.  They are issued UNCONDITIONALLY (rows past the end are clamped and masked by `ok`): vmcnt
+    // retires in order, and a prefetch behind a branch would make the compiler wait for it too.
     constexpr int UNR = 4;
-    for (int g0 = g_begin; g0 < g_end; g0 += 2 * UNR) {
-        float xb[UNR][2][2], da[UNR][4][2];
-        bool okv[UNR];
+    constexpr bool kNeedFeat = true, kNeedA0 = NL > 1;   // which X a row needs is uniform per workgroup: see x_of()
+    struct Operands {
+        float x[UNR][2], da[UNR][NL][2];
+        float x2[UNR][2];                               // second X (a0) when the row spans layer 0 and later layers
+        bool ok[UNR];
+    };
+    // layer L reads X = feat (L == 0) or a0 (L >= 1).  Rows with NL > 1 that start at layer 0 need both.
+    const bool first_is_feat = L0 == 0;
+    const float* __restrict__ xa = first_is_feat ? feat : a0g;
+    auto load = [&](Operands& o, int g0) {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             const int g = g0 + 2 * u + h;               // K slot of this lane half
             const bool ok = g < g_end;
-            okv[u] = ok;
+            o.ok[u] = ok;
             const size_t row = (size_t)(ok ? g : g_begin) * kHid;
 #pragma unroll
             for (int kt = 0; kt < 2; kt++) {
-                xb[u][0][kt] = feat[row + 32 * kt + col];
-                xb[u][1][kt] = a0g[row + 32 * kt + col];
+                o.x[u][kt] = xa[row + 32 * kt + col];
+                if (kNeedA0) o.x2[u][kt] = a0g[row + 32 * kt + col];
             }
 #pragma unroll
-            for (int L = 0; L < 4; L++) {
-                const float* __restrict__ d = dH + (size_t)L * PH + row;
-                da[u][L][0] = d[col];
-                da[u][L][1] = d[32 + col];
+            for (int l = 0; l < NL; l++) {
+                const float* __restrict__ d = dH + (size_t)(L0 + l) * PH + row;
+                o.da[u][l][0] = d[col];
+                o.da[u][l][1] = d[32 + col];
             }
         }
+    };
+    auto compute = [&](const Operands& o) {
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
 #pragma unroll
-            for (int L = 0; L < 4; L++) {
-                const float a_lo = okv[u] ? da[u][L][0] : 0.f, a_hi = okv[u] ? da[u][L][1] : 0.f;
-                db[L][0] += a_lo;
-                db[L][1] += a_hi;
-                const int x = L == 0 ? 0 : 1;
-                dW[L][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, xb[u][x][0], dW[L][0][0], 0, 0, 0);
-                dW[L][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, xb[u][x][1], dW[L][0][1], 0, 0, 0);
-                dW[L][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, xb[u][x][0], dW[L][1][0], 0, 0, 0);
-                dW[L][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, xb[u][x][1], dW[L][1][1], 0, 0, 0);
+            for (int l = 0; l < NL; l++) {
+                const float a_lo = o.ok[u] ? o.da[u][l][0] : 0.f, a_hi = o.ok[u] ? o.da[u][l][1] : 0.f;
+                db[l][0] += a_lo;
+                db[l][1] += a_hi;
+                // l == 0 uses the row's first X; later layers of the row always read a0
+                const float x0 = (l == 0 || !kNeedA0) ? o.x[u][0] : o.x2[u][0];
+                const float x1 = (l == 0 || !kNeedA0) ? o.x[u][1] : o.x2[u][1];
+                dW[l][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, x0, dW[l][0][0], 0, 0, 0);
+                dW[l][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo, x1, dW[l][0][1], 0, 0, 0);
+                dW[l][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, x0, dW[l][1][0], 0, 0, 0);
+                dW[l][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi, x1, dW[l][1][1], 0, 0, 0);
             }
+        }
+    };
+    (void)kNeedFeat;
+    if (g_begin < g_end) {
+        // single rotation (compute(cur); cur = nxt): the two-phase form (A/B alternating in one body) made the register
+        // allocator spill a whole operand buffer to scratch
+        Operands cur, nxt;
+        load(cur, g_begin);
+        for (int g0 = g_begin; g0 < g_end; g0 += 2 * UNR) {
+            load(nxt, g0 + 2 * UNR);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
         }
     }
     // combine the four waves in LDS, then one float atomic per weight per workgroup
     float* R = lds;
-    for (int L = 0; L < 4; L++) {
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+        const int L = L0 + l;
         __syncthreads();
         for (int i = threadIdx.x; i < kHid * kHid + kHid; i += 256) R[i] = 0.f;
         __syncthreads();
@@ -403,8 +441,8 @@ deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat,
             for (int kt = 0; kt < 2; kt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++)           // tile row = out feature 32mt+fmap(r,h), column = in feature 32kt+col
-                    atomicAdd(&R[(32 * mt + fmap(r, h)) * kHid + 32 * kt + col], dW[L][mt][kt][r]);
-            atomicAdd(&R[kHid * kHid + 32 * mt + col], db[L][mt]);   // both lane halves add their K slots
+                    atomicAdd(&R[(32 * mt + fmap(r, h)) * kHid + 32 * kt + col], dW[l][mt][kt][r]);
+            atomicAdd(&R[kHid * kHid + 32 * mt + col], db[l][mt]);   // both lane halves add their K slots
         }
         __syncthreads();
         float* dst = L == 0 ? m.dW0 : m.dW1[L - 1];
@@ -497,6 +535,19 @@ extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* fe
     const int waves = 1024;
     int chunk = (P + waves - 1) / waves;
     chunk += chunk & 1;
-    hipLaunchKernelGGL(deform_bwd_dw_kernel, dim3(waves / 4), dim3(256), lds_b, (hipStream_t)stream, d, P, chunk, feat, a0, dH);
+    // layers per wave (MOM_DW_NL = 4, 2 or 1): fewer layers -> fewer accumulators -> more waves and more loads in flight per CU
+    static int nl = 0;
+    if (!nl) {
+        const char* e = getenv("MOM_DW_NL");
+        nl = e ? atoi(e) : 1;                 // measured: dx + dW 344 / 339 / 326 us for 4 / 2 / 1 layers per wave
+        if (nl != 1 && nl != 2 && nl != 4) nl = 1;
+    }
+    const dim3 grid(waves / 4, 4 / nl);
+    if (nl == 4)
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<4>, grid, dim3(256), lds_b, (hipStream_t)stream, d, P, chunk, feat, a0, dH);
+    else if (nl == 2)
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<2>, grid, dim3(256), lds_b, (hipStream_t)stream, d, P, chunk, feat, a0, dH);
+    else
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, grid, dim3(256), lds_b, (hipStream_t)stream, d, P, chunk, feat, a0, dH);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

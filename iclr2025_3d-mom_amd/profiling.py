@@ -12,6 +12,10 @@ HBM_PEAK_GBS = 8000.0
 FP32_VALU_PEAK_TFLOPS = 157.0      # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 # SURVEY 8d, "Raster VALU": FLOP per evaluated (pixel, splat) pair, with one exp each; Q = 256 R pairs per launch
 VALU_FLOP_PER_PAIR = {"render_fwd": 20, "render_bwd": 70}
+# the deformation MLP is the MFMA-bound part of the path: 34 048 FLOP per Gaussian forward (trunk 64x64, three
+# head hidden layers 64x64, heads 64x{3,3,4}); the backward (dX and dW, both kernels inside one timed scope) is twice that
+FP32_MFMA_PEAK_TFLOPS = 157.0
+MFMA_FLOP_PER_GAUSSIAN = {"mlp_fwd": 34_048, "mlp_bwd": 68_096}
 
 SLOTS = {n: i for i, n in enumerate(
     ["preprocess_fwd", "tile_hist", "tile_scan", "tile_scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd",
@@ -52,6 +56,12 @@ def roofline(kernel, P, R, Npix, traffic=None):
     if cnt == 0:
         return None
     avg_s = ms / cnt * 1e-3
+    if kernel in MFMA_FLOP_PER_GAUSSIAN:
+        flop = float(P) * MFMA_FLOP_PER_GAUSSIAN[kernel]
+        tf = flop / avg_s / 1e12
+        return {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
+                "algorithmic_flop_per_launch": flop, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
     b = algorithmic_bytes(kernel, P, R, Npix)
     achieved = b / avg_s / 1e9
     out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -27,20 +27,45 @@ def _run(fused, steps=3, lambda_dssim=0.0):
            "opacity": g._opacity, "plane_xy": dn.grid.grids[1][0], "plane_zt": dn.grid.grids[0][5],
            "w0": dn.feature_out[0].weight, "b_rot": dn.rotations_deform[3].bias, "w_pos1": dn.pos_deform[1].weight,
            "accum": g.xyz_gradient_accum, "denom": g.denom, "maxr": g.max_radii2D}
-    return losses, {k: v.detach().float().cpu().numpy().copy() for k, v in out.items()}
+    params = {k: v.detach().float().cpu().numpy().copy() for k, v in out.items()}
+    # Adam's first moment after ONE step is (1 - beta1) * gradient exactly (it starts at zero), so it is the gradient the
+    # step computed, read without Adam's normalisation in the way
+    moments, lr_max = {}, max(grp["lr"] for grp in g.optimizer.param_groups)
+    if steps == 1:
+        for k in ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "plane_xy", "plane_zt", "w0", "b_rot", "w_pos1"):
+            moments[k] = g.optimizer.state[out[k]]["exp_avg"].detach().float().cpu().numpy().copy()
+    return losses, params, moments, lr_max
 
 
 @pytest.mark.parametrize("lambda_dssim", [0.0, 0.2])
 def test_fused_step_matches_autograd_path(lambda_dssim):
-    """lambda_dssim 0 is the reference's default loss, 0.2 adds the SSIM term (train_4DGS.py:222-223)."""
-    la, pa = _run(False, lambda_dssim=lambda_dssim)
-    lf, pf = _run(True, lambda_dssim=lambda_dssim)
+    """lambda_dssim 0 is the reference's default loss, 0.2 adds the SSIM term (train_4DGS.py:222-223).
+
+    What must agree is the GRADIENT (both paths run the same kernels; only the order of their float atomics differs), so
+    that is compared directly, through Adam's first moment after one step.  Parameters after three steps are compared too,
+    but Adam divides by sqrt(v) + 1e-15: an element whose tiny gradient changes sign under a different summation order
+    moves by a full learning rate (as it does between two runs of the reference itself), so a handful of elements may
+    differ by up to 2 * lr per step while all the others agree tightly."""
+    la, _, ma, _ = _run(False, steps=1, lambda_dssim=lambda_dssim)
+    lf, _, mf, _ = _run(True, steps=1, lambda_dssim=lambda_dssim)
+    np.testing.assert_allclose(lf, la, rtol=2e-5)
+    for k in ma:
+        scale = max(1e-30, float(np.abs(ma[k]).max()))
+        err = float(np.abs(mf[k] - ma[k]).max())
+        assert err <= 5e-5 * scale, ("gradient", k, err, scale)
+
+    steps = 3
+    la, pa, _, lr_max = _run(False, steps=steps, lambda_dssim=lambda_dssim)
+    lf, pf, _, _ = _run(True, steps=steps, lambda_dssim=lambda_dssim)
     np.testing.assert_allclose(lf, la, rtol=2e-5)
     for k in pa:
         a, b = pf[k], pa[k]
         scale = max(1e-12, float(np.abs(b).max()))
-        # Adam normalises every update to ~lr, so a gradient that differs by rounding moves a parameter by at most ~lr
-        assert np.abs(a - b).max() <= 2e-4 * scale + 1e-6, (k, float(np.abs(a - b).max()), scale)
+        diff = np.abs(a - b)
+        tight = 2e-4 * scale + 1e-6
+        outliers = float((diff > tight).mean())
+        assert outliers <= 1e-4, (k, "fraction of elements outside the tight tolerance", outliers)
+        assert float(diff.max()) <= 2.0 * steps * lr_max * 1.01 + tight, (k, float(diff.max()), lr_max)
     np.testing.assert_array_equal(pf["denom"], pa["denom"])
     np.testing.assert_array_equal(pf["maxr"], pa["maxr"])
 
