@@ -104,6 +104,7 @@ def _sig(lib):
     lib.mom_deform_backward_scratch_bytes.restype = sz
     lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
     lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     lib.mom_ssim_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.mom_ssim_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.mom_activations_forward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
@@ -129,6 +130,7 @@ EXPORTS = [
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
     "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward",
     "mom_ssim_forward", "mom_ssim_backward", "mom_raster_backward_render", "mom_raster_backward_geometry",
+    "mom_densify_stats",
 ]
 
 

@@ -217,6 +217,36 @@ extern "C" int mom_l1_loss(size_t n, const float* img, const float* gt, float* d
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
+// Per-iteration densification statistics (train_4DGS.py:266, scene/gaussian_model.py:713-715) in one pass, in place:
+// for the Gaussians the frame saw (radius > 0) the running maximum radius, the accumulated norm of the screen-space
+// gradient and its count.  The reference does this with boolean-mask indexing (a nonzero() and its host sync per line).
+namespace {
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int P, const int* __restrict__ radii, const float* __restrict__ vsp_grad, float* __restrict__ max_radii2D,
+                     float* __restrict__ grad_accum, float* __restrict__ denom)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    const float gx = vsp_grad[3 * i], gy = vsp_grad[3 * i + 1];
+    grad_accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+}
+}  // namespace
+
+extern "C" int mom_densify_stats(int P, const int* radii, const float* viewspace_grad, float* max_radii2D, float* xyz_gradient_accum,
+                                 float* denom, mom_stream_t stream)
+{
+    if (P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom) return MOM_EINVAL;
+    hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, radii, viewspace_grad,
+                       max_radii2D, xyz_gradient_accum, denom);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
 extern "C" int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom_stream_t stream)
 {
     if (count < 0 || count > MOM_REG_MAX_PLANES || !value || (count && !planes)) return MOM_EINVAL;

@@ -212,6 +212,24 @@ def l1_loss_with_sums(img, gt):
     return L1LossFunction.apply(img, gt)
 
 
+# --------------------------------------------------------------------------- densification statistics
+def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):
+    """In place, for the Gaussians with radii > 0: running maximum radius, accumulated |dL/d mean2D| and its count
+    (train_4DGS.py:266, scene/gaussian_model.py:713-715)."""
+    _need_cuda(radii, "densify_stats")
+    P = radii.shape[0]
+    for t_, n_ in ((max_radii2D, P), (xyz_gradient_accum, P), (denom, P)):
+        if t_.numel() != n_ or not t_.is_contiguous() or t_.dtype != torch.float32:
+            raise N.MomError("densify_stats: accumulators must be contiguous float32 tensors with one element per Gaussian")
+    if radii.dtype != torch.int32 or not radii.is_contiguous():
+        raise N.MomError("densify_stats: radii must be a contiguous int32 tensor")
+    g = viewspace_grad
+    if g.shape != (P, 3) or g.dtype != torch.float32 or not g.is_contiguous():
+        raise N.MomError("densify_stats: viewspace gradient must be a contiguous float32 [P,3] tensor")
+    N.check(N.lib().mom_densify_stats(P, radii.data_ptr(), g.data_ptr(), max_radii2D.data_ptr(), xyz_gradient_accum.data_ptr(),
+                                      denom.data_ptr(), N.current_stream()), "mom_densify_stats")
+
+
 # --------------------------------------------------------------------------- SSIM
 def ssim_window():
     """The 11 taps of the reference's gaussian(11, 1.5) (utils/loss_utils.py:29-31), computed the way it computes them
@@ -404,6 +422,7 @@ class _HipBackend:
     deform_mlp = staticmethod(deform_mlp)
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
     ssim = staticmethod(ssim)
+    densify_stats = staticmethod(densify_stats)
     plane_regulation = staticmethod(plane_regulation)
     Adam = FusedAdam
 

@@ -109,8 +109,7 @@ class Trainer:
             if iteration < opt.densify_until_iter:
                 # same values as the reference's boolean-mask indexing (train_4DGS.py:266), without the host sync a
                 # nonzero() costs: invisible entries keep their old value
-                g.max_radii2D = torch.where(visibility, torch.max(g.max_radii2D, radii.float()), g.max_radii2D)
-                g.add_densification_stats(vsp_grad, visibility)
+                g.update_densification_stats(radii, vsp_grad)
                 if self.stage == "coarse":
                     op_thr, de_thr = opt.opacity_threshold_coarse, opt.densify_grad_threshold_coarse
                 else:

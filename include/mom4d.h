@@ -226,6 +226,13 @@ int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double 
  * dimg (may be null) = sign(img-gt)/n = d mean|img-gt| / d img. */
 int mom_l1_loss(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream);
 
+/* ---- Densification statistics of one iteration (train_4DGS.py:266; scene/gaussian_model.py:713-715
+ * add_densification_stats), in place, for the Gaussians with radii[i] > 0:
+ *   max_radii2D[i] = max(max_radii2D[i], radii[i]);  xyz_gradient_accum[i] += |viewspace_grad[i, :2]|;  denom[i] += 1.
+ * viewspace_grad is [P,3] (dL/d mean2D; the third column is unused), the three accumulators are [P] floats. */
+int mom_densify_stats(int P, const int* radii, const float* viewspace_grad, float* max_radii2D, float* xyz_gradient_accum,
+                      float* denom, mom_stream_t stream);
+
 /* ---- SSIM term of the loss (utils/loss_utils.py:29-92: ssim / _ssim / create_window / gaussian) ----
  * 11x11 Gaussian window = outer product of the 11 taps in window11 (host pointer; the reference's
  * gaussian(11, 1.5)), zero padding 5, C1 = 0.01^2, C2 = 0.03^2.  Images are [C][H][W] (any leading batch

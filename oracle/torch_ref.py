@@ -102,12 +102,21 @@ def ssim(img1, img2, window_size=11):
     return (((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))).mean()
 
 
+def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):
+    """train_4DGS.py:266 + scene/gaussian_model.py:713-715 (boolean-mask indexing), in place."""
+    vis = radii > 0
+    max_radii2D[vis] = torch.max(max_radii2D[vis], radii[vis].to(max_radii2D.dtype))
+    xyz_gradient_accum[vis] += torch.norm(viewspace_grad[vis, :2], dim=-1, keepdim=True).reshape(xyz_gradient_accum[vis].shape)
+    denom[vis] += 1
+
+
 class TorchBackend:
     """Oracle backend for host-logic tests on machines without a GPU (installed explicitly by tests)."""
     name = "torch-oracle"
     hexplane_features = staticmethod(hexplane_features)
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
     ssim = staticmethod(ssim)
+    densify_stats = staticmethod(densify_stats)
     plane_regulation = staticmethod(plane_regulation)
     Adam = torch.optim.Adam
 

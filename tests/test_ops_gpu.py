@@ -280,3 +280,33 @@ def test_loss_utils_ssim_runs_the_hip_kernels_and_refuses_other_windows():
         L.ssim(img.cuda(), gt.cuda(), window_size=7)
     with pytest.raises(N.MomError):
         L.ssim(img, gt)                                  # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------------- densification statistics (survey a17)
+@pytest.mark.parametrize("P", [1, 257, 20000])
+def test_densify_stats_matches_the_mask_indexing_reference(P):
+    """ops.densify_stats (one HIP kernel, in place) against the reference's boolean-mask sequence on the CPU
+    (oracle/torch_ref.densify_stats = train_4DGS.py:266 + gaussian_model.py:713-715), over several frames so that the
+    accumulators carry state; Gaussians a frame did not see (radius 0) must keep their values bit for bit."""
+    g = torch.Generator().manual_seed(P)
+    max_r, accum, denom = torch.rand(P, generator=g) * 5, torch.rand(P, 1, generator=g), torch.randint(0, 4, (P, 1), generator=g).float()
+    ref = [t_.clone() for t_ in (max_r, accum, denom)]
+    dev = [t_.cuda() for t_ in (max_r, accum, denom)]
+    for frame in range(3):
+        radii = (torch.randint(0, 40, (P,), generator=g) * (torch.rand(P, generator=g) > 0.4)).to(torch.int32)
+        grad = torch.randn(P, 3, generator=g) * 1e-3
+        before = [t_.clone() for t_ in ref]
+        tr.densify_stats(radii, grad, *ref)
+        ops.densify_stats(radii.cuda(), grad.cuda(), *dev)
+        unseen = radii == 0
+        for b, r in zip(before, ref):
+            assert torch.equal(b.reshape(P)[unseen], r.reshape(P)[unseen])
+    for d, r in zip(dev, ref):
+        np.testing.assert_allclose(d.cpu().numpy(), r.numpy(), rtol=1e-6, atol=0)       # sqrt(x^2 + y^2): fma vs mul+add
+    np.testing.assert_array_equal(dev[0].cpu().numpy(), ref[0].numpy())                 # radii and counts are exact
+    np.testing.assert_array_equal(dev[2].cpu().numpy(), ref[2].numpy())
+    N = importlib.import_module("iclr2025_3d-mom_amd._native")
+    with pytest.raises(N.MomError):
+        ops.densify_stats(radii, grad, *ref)                                            # CPU tensors: no fallback
+    with pytest.raises(N.MomError):
+        ops.densify_stats(radii.cuda().long(), grad.cuda(), *dev)
