@@ -180,11 +180,15 @@ def test_dropin_autograd_matches_oracle():
     np.testing.assert_array_equal(vis.cpu().numpy(), s["means3D"][:, 2] > 0.2)
 
 
-def test_full_size_properties_config2():
-    """BASELINE configs[1] size (200k Gaussians, 960x540): size-independent properties instead of the oracle."""
-    from hip_helpers import hip_forward
-    P, W, H = 200_000, 960, 540
-    s = random_gaussians(P, seed=33, W=W, H=H, scale=(-6.0, -4.5))
+@pytest.mark.parametrize("P,W,H,seed", [(200_000, 960, 540, 33), (1_000_000, 1920, 1080, 34)],
+                         ids=["config2_200k_960x540", "config3_1M_1920x1080"])
+def test_full_size_properties(P, W, H, seed):
+    """BASELINE configs[1] and configs[2] sizes: size-independent properties instead of the oracle (which would need
+    minutes per frame there).  Binning: the instance counts agree three ways, the tile ranges partition the list and
+    every tile's list is strictly sorted by (depth bits, index).  Compositing: weights + final transmittance = 1.
+    Determinism: same inputs, same bits.  Backward: every gradient is linear in dL/dpixels."""
+    from hip_helpers import hip_backward, hip_forward
+    s = random_gaussians(P, seed=seed, W=W, H=H, scale=(-6.0, -4.5))
     fw = hip_forward(s)
     R = fw["R"]
     assert int(fw["tiles_touched"].sum()) == R == int(fw["tile_counts"].sum())
@@ -208,3 +212,12 @@ def test_full_size_properties_config2():
     fw2 = hip_forward(s)
     np.testing.assert_array_equal(fw2["point_list"], pl)
     np.testing.assert_array_equal(fw2["color"], fw["color"])
+    # backward linearity: doubling dL/dpixels doubles every gradient (a power of two: exact up to the order of the atomics)
+    rng = np.random.default_rng(seed)
+    dcol = rng.standard_normal((3, H, W)).astype(np.float32)
+    g1 = hip_backward(fw, dcol)
+    g2 = hip_backward(fw, 2.0 * dcol)
+    for k in g1:
+        scale = float(np.abs(g1[k]).max())
+        assert np.isfinite(g1[k]).all() and scale > 0, k
+        assert np.abs(g2[k] - 2.0 * g1[k]).max() <= 2e-5 * scale, (k, float(np.abs(g2[k] - 2.0 * g1[k]).max()), scale)
