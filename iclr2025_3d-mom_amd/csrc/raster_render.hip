@@ -107,6 +107,62 @@ __device__ __forceinline__ float splat_power(const float4 r0, const float4 r1, f
     return __builtin_fmaf(-0.5f, quad, -(bx * dy));             // -0.5 quad - conic.y dx dy
 }
 
+// ---- per-wave splat lists ------------------------------------------------------------------------------------------
+// A wave owns a 16x4 strip of the tile, and about four fifths of the tile's splats cannot reach alpha >= 1/255 anywhere
+// in a given strip.  While a splat is staged into LDS its staging thread decides, per strip, whether ANY point of the
+// strip's rectangle can reach the splat's power bound: the exponent is concave, so its maximum over a rectangle is 0 if
+// the centre is inside and otherwise lies on an edge, at the clamped stationary point of the edge's 1-D quadratic.  Each
+// wave then compacts the indices of its reachable splats (ballot + rank) and loops over those only.  The test works on the
+// continuous rectangle with a margin, so it keeps every pair the exact per-pixel tests could accept, and those tests
+// still run: results are bit-identical.  Anything degenerate (non-positive conic diagonal, NaN) counts as reachable.
+__device__ __forceinline__ float edge_max(float fixed, float lo, float hi, float q_fixed, float q_free, float b)
+{
+    // max over t in [lo, hi] of  -0.5 (q_fixed fixed^2 + q_free t^2) - b fixed t
+    const float t = fminf(fmaxf(-b * fixed / q_free, lo), hi);
+    return -0.5f * (q_fixed * fixed * fixed + q_free * t * t) - b * fixed * t;
+}
+__device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const float4 r1, float x0, float y0)
+{
+    const float cx = r0.x, cy = r0.y, a = r1.x, b = r1.y, c = r1.z, bound = r0.w - 1e-3f;
+    if (!(a > 0.f) || !(c > 0.f)) return 0xFu;
+    const float x1 = x0 + 15.f;
+    const float dxl = cx - x1, dxh = cx - x0;            // dx = cx - px over the strip's columns
+    const bool in_x = cx >= x0 && cx <= x1;
+    uint32_t m = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const float ya = y0 + 4.f * w, yb = ya + 3.f;
+        const float dyl = cy - yb, dyh = cy - ya;
+        float best;
+        if (in_x && cy >= ya && cy <= yb) {
+            best = 0.f;
+        } else {
+            best = fmaxf(fmaxf(edge_max(dxl, dyl, dyh, a, c, b), edge_max(dxh, dyl, dyh, a, c, b)),
+                         fmaxf(edge_max(dyl, dxl, dxh, c, a, b), edge_max(dyh, dxl, dxh, c, a, b)));
+        }
+        m |= (!(best < bound)) ? (1u << w) : 0u;
+    }
+    return m;
+}
+// Compacts, for wave `wv`, the indices j < 256 whose mask has bit wv: afterwards lane k of list[c] holds entry 64 c + k of the
+// wave's list (in increasing j, so the compositing order is kept); returns the list length.
+__device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint8_t* s_list, int wv, int lane, int (&list)[4])
+{
+    int n = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int j = 64 * c + lane;
+        const bool bit = (s_mask[j] >> wv) & 1;
+        const uint64_t bal = __ballot(bit);
+        const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (bit) s_list[n + rank] = (uint8_t)j;
+        n += __popcll(bal);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) list[c] = s_list[64 * c + lane];
+    return n;
+}
+
 __global__ void __launch_bounds__(256)
 render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0,
                   const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
@@ -114,12 +170,15 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                   uint32_t capacity)
 {
     __shared__ float4 s_rec[256 * 3];
+    __shared__ uint8_t s_mask[256];
+    __shared__ uint8_t s_lists[4][256];
     const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     bool done = !inside;
 
     uint2 range = ranges[tile];
@@ -129,46 +188,57 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     const int rounds = (toDo + 255) / 256;
 
     float T = 1.0f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
 
     for (int i = 0; i < rounds; i++, toDo -= 256) {
         if (__syncthreads_count(done) == 256) break;
         const int progress = i * 256 + threadIdx.x;
+        uint32_t reach = 0;
         if (range.x + progress < range.y) {
             const size_t id = point_list[range.x + progress];
             float4 q0 = rec[3 * id + 0];
             const float4 q1 = rec[3 * id + 1];
             q0.w = power_bound(q1.w);
+            reach = strip_reach_mask(q0, q1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
             s_rec[threadIdx.x * 3 + 0] = q0;
             s_rec[threadIdx.x * 3 + 1] = q1;
             s_rec[threadIdx.x * 3 + 2] = rec[3 * id + 2];
         }
+        s_mask[threadIdx.x] = (uint8_t)reach;               // slots past the end of the list: unreachable
         __syncthreads();
-        const int nb = min(256, toDo);
-        for (int j = 0; !done && j < nb; j++) {
-            contributor++;
-            const float4 r0 = s_rec[j * 3 + 0];
-            const float4 r1 = s_rec[j * 3 + 1];
-            float dx, dy;
-            const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
-            if (!__any(!(power < r0.w))) continue;   // no lane of the wave can reach 1/255 (power_bound)
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, r1.w * mom_exp(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1.f - alpha);
-            if (test_T < 0.0001f) {
-                done = true;
-                continue;
+        int list[4];
+        const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int nk = min(64, n_w - 64 * c);
+            for (int k = 0; k < nk; k++) {
+                if (__all(done)) break;
+                const int j = __builtin_amdgcn_readlane(list[c], k);
+                const float4 r0 = s_rec[j * 3 + 0];
+                const float4 r1 = s_rec[j * 3 + 1];
+                float dx, dy;
+                const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
+                bool valid = !done && !(power < r0.w) && !(power > 0.0f);
+                if (!__any(valid)) continue;                // no lane of the wave can reach 1/255 (power_bound)
+                const float alpha = fminf(0.99f, r1.w * mom_exp(power));
+                valid = valid && !(alpha < 1.0f / 255.0f);
+                const float test_T = T * (1.f - alpha);
+                if (valid && test_T < 0.0001f) {
+                    done = true;
+                    valid = false;
+                }
+                if (valid) {
+                    const float4 r2 = s_rec[j * 3 + 2];
+                    const float w = alpha * T;
+                    C0 += r2.x * w;
+                    C1 += r2.y * w;
+                    C2 += r2.z * w;
+                    D += r0.z * w;
+                    T = test_T;
+                    last_contributor = (uint32_t)(i * 256 + j + 1);     // position in the tile's list, counted from 1
+                }
             }
-            const float4 r2 = s_rec[j * 3 + 2];
-            const float w = alpha * T;
-            C0 += r2.x * w;
-            C1 += r2.y * w;
-            C2 += r2.z * w;
-            D += r0.z * w;
-            T = test_T;
-            last_contributor = contributor;
         }
     }
     if (inside) {
