@@ -261,13 +261,15 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
 {
     __shared__ float4 s_rec[256 * 3];
     __shared__ uint32_t s_id[256];
+    __shared__ uint8_t s_mask[256];
+    __shared__ uint8_t s_lists[4][256];
     const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
     uint2 range = ranges[tile];
     if (range.y > capacity) range.y = capacity;
@@ -302,20 +304,29 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     for (int i = 0; i < rounds; i++, toDo -= 256) {
         __syncthreads();
         const int progress = i * 256 + threadIdx.x;
+        uint32_t reach = 0;
         if (range.x + progress < range.y) {
             const uint32_t id = point_list[range.y - progress - 1];
             s_id[threadIdx.x] = id;
             float4 q0 = rec[3 * (size_t)id + 0];
             const float4 q1 = rec[3 * (size_t)id + 1];
             q0.w = power_bound(q1.w);
+            reach = strip_reach_mask(q0, q1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
             s_rec[threadIdx.x * 3 + 0] = q0;
             s_rec[threadIdx.x * 3 + 1] = q1;
             s_rec[threadIdx.x * 3 + 2] = rec[3 * (size_t)id + 2];
         }
+        s_mask[threadIdx.x] = (uint8_t)reach;               // slots past the end of the list: unreachable
         __syncthreads();
-        const int nb = min(256, toDo);
-        for (int j = 0; j < nb; j++) {
-            contributor--;
+        // this wave's splats of the round, still back to front (render_fwd explains the lists)
+        int list[4];
+        const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int nk = min(64, n_w - 64 * c);
+          for (int k = 0; k < nk; k++) {
+            const int j = __builtin_amdgcn_readlane(list[c], k);
+            contributor = (uint32_t)(toDo - j - 1);        // position of splat j in the tile's list, counted from 0
             if ((int)contributor >= wave_last) continue;   // wave-uniform: occluded for all 64 pixels
             const float4 r0 = s_rec[j * 3 + 0];
             const float4 r1 = s_rec[j * 3 + 1];
@@ -369,6 +380,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};
             const float v = reduce_scatter10(gv, lane);
             if (lane < 10) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
+          }
         }
     }
 }
