@@ -121,20 +121,24 @@ __device__ __forceinline__ float edge_max(float fixed, float lo, float hi, float
     const float t = fminf(fmaxf(-b * fixed / q_free, lo), hi);
     return -0.5f * (q_fixed * fixed * fixed + q_free * t * t) - b * fixed * t;
 }
+// Footprint of a wave inside the 16x16 tile: kFW x kFH pixels, kWX footprints across.  (16x4 strips: 16,4,1; 8x8 blocks: 8,8,2.)
+#ifndef MOM_FOOT_W
+#define MOM_FOOT_W 16
+#endif
+constexpr int kFW = MOM_FOOT_W, kFH = 64 / kFW, kWX = 16 / kFW;
 __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const float4 r1, float x0, float y0)
 {
     const float cx = r0.x, cy = r0.y, a = r1.x, b = r1.y, c = r1.z, bound = r0.w - 1e-3f;
     if (!(a > 0.f) || !(c > 0.f)) return 0xFu;
-    const float x1 = x0 + 15.f;
-    const float dxl = cx - x1, dxh = cx - x0;            // dx = cx - px over the strip's columns
-    const bool in_x = cx >= x0 && cx <= x1;
     uint32_t m = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        const float ya = y0 + 4.f * w, yb = ya + 3.f;
+        const float xa = x0 + (float)(kFW * (w % kWX)), xb = xa + (float)(kFW - 1);
+        const float ya = y0 + (float)(kFH * (w / kWX)), yb = ya + (float)(kFH - 1);
+        const float dxl = cx - xb, dxh = cx - xa;        // dx = cx - px over the footprint's columns
         const float dyl = cy - yb, dyh = cy - ya;
         float best;
-        if (in_x && cy >= ya && cy <= yb) {
+        if (cx >= xa && cx <= xb && cy >= ya && cy <= yb) {
             best = 0.f;
         } else {
             best = fmaxf(fmaxf(edge_max(dxl, dyl, dyh, a, c, b), edge_max(dxh, dyl, dyh, a, c, b)),
@@ -174,7 +178,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     __shared__ uint8_t s_lists[4][256];
     const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
+    const int ly = kFH * ((threadIdx.x >> 6) / kWX) + (threadIdx.x & 63) / kFW;
     const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
@@ -265,7 +270,8 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     __shared__ uint8_t s_lists[4][256];
     const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
-    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
+    const int ly = kFH * ((threadIdx.x >> 6) / kWX) + (threadIdx.x & 63) / kFW;
     const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
