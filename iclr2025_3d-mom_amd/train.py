@@ -94,7 +94,7 @@ class Trainer:
                 # back reduced in place (largest radius over the ranks, mean screen-space gradient)
                 self.dist.finish()
                 self.dist.seed_for(iteration)
-            visibility = radii > 0
+            visibility = None          # the statistics kernel derives it from the radii (update_densification_stats)
             if self.sync_every_step:
                 if torch.isnan(loss).any():
                     raise FloatingPointError("loss is nan")
