@@ -190,33 +190,50 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
 // Bitonic network in the "flip then disperse" form: every compare-exchange puts
 // the smaller key at the lower index, so virtual +inf padding above n never moves
 // and is simply skipped.
-template <class KeyPtr>
+//
+// All strides are powers of two: indices come from shifts and masks (a division by a run-time stride costs ~40
+// instructions per compare-exchange).  Thread t works on the compare-exchanges i = t, t + nthreads, ...; a wave's 64
+// consecutive i touch one aligned block of 128 keys whenever the stage's span (kk for a flip, 2j for a disperse step)
+// is at most 128, so two such stages in a row exchange data inside the wave only and need no workgroup barrier --
+// for 1024 keys that leaves 6 of 55.  A barrier is kept wherever either neighbour stage is wider.  With BLOCK_SYNC
+// false (the global-memory path of oversized buckets) every stage keeps its barrier.
+template <bool LOCAL_STAGES, class KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int nthreads, int tid)
 {
-    int m = 1;
-    while (m < n) m <<= 1;
-    for (int kk = 2; kk <= m; kk <<= 1) {
-        const int half = kk >> 1;
-        for (int i = tid; i < (m >> 1); i += nthreads) {
-            const int blk = i / half, off = i - blk * half;
-            const int a = blk * kk + off, b = blk * kk + kk - 1 - off;
+    int lm = 0;
+    while ((1 << lm) < n) lm++;
+    const int half_m = (1 << lm) >> 1;
+    bool prev_wide = true;                                   // the loads before the first stage came from all waves
+    auto sync_before = [&](int span) {
+        const bool wide = !LOCAL_STAGES || span > 128;
+        if (wide || prev_wide) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
+        prev_wide = wide;
+    };
+    for (int lk = 1; lk <= lm; lk++) {
+        const int kk = 1 << lk, lh = lk - 1, half = kk >> 1;
+        sync_before(kk);
+        for (int i = tid; i < half_m; i += nthreads) {
+            const int blk = i >> lh, off = i & (half - 1);
+            const int a = (blk << lk) + off, b = (blk << lk) + kk - 1 - off;
             if (b < n) {
                 const uint64_t ka = k[a], kb = k[b];
                 if (ka > kb) { k[a] = kb; k[b] = ka; }
             }
         }
-        __syncthreads();
-        for (int j = kk >> 2; j >= 1; j >>= 1) {
-            for (int i = tid; i < (m >> 1); i += nthreads) {
-                const int a = ((i / j) * 2 * j) + (i % j), b = a + j;
+        for (int lj = lk - 2; lj >= 0; lj--) {
+            const int j = 1 << lj;
+            sync_before(2 * j);
+            for (int i = tid; i < half_m; i += nthreads) {
+                const int a = ((i >> lj) << (lj + 1)) + (i & (j - 1)), b = a + j;
                 if (b < n) {
                     const uint64_t ka = k[a], kb = k[b];
                     if (ka > kb) { k[a] = kb; k[b] = ka; }
                 }
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 }
 
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
@@ -231,12 +248,12 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
     if (n <= kSortLdsCap) {
         for (int i = threadIdx.x; i < n; i += 256) s_keys[i] = gk[i];
         __syncthreads();
-        if (n > 1) bitonic_sort(s_keys, n, 256, threadIdx.x);
+        if (n > 1) bitonic_sort<true>(s_keys, n, 256, threadIdx.x);
         for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)s_keys[i];
     } else {
         // oversized bucket: same network directly on the (L2-resident) global bucket
         __syncthreads();
-        bitonic_sort(gk, n, 256, threadIdx.x);
+        bitonic_sort<false>(gk, n, 256, threadIdx.x);
         __threadfence_block();
         for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)gk[i];
     }
