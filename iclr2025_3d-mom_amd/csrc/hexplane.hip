@@ -350,7 +350,7 @@ hexplane_bwd_agg_kernel(HexArgs a, int chunk, const float* __restrict__ xyz, con
 //
 // Record of one (point, plane): {off00 | flags, bx, by, x0} with off00 = texel (y0, x0) in floats (a multiple of 32,
 // so the low bits are free): bit0 = x0+1 is inside, bit1 = y0+1 is inside, bit2 / bit3 = the x / y coordinate was
-// NOT clipped at the border (its gradient multiplier is (size-1)/2, else 0).  bx = ix - x0 and by = iy - y0 are
+// NOT clipped at the border (its gradient multiplier is (size-1)/2, else 0), bit4 = y0 is odd.  bx = ix - x0 and by = iy - y0 are
 // exact; ax = 1 - bx, ay = 1 - by are bit-identical to ATen's (x0+1) - ix (Sterbenz), so the four weights are
 // ATen's.  A corner that is outside gets weight exactly 0 and is redirected to the texel next to it.
 // =================================================================================================================
@@ -386,6 +386,7 @@ __device__ __forceinline__ float4 make_rec4(float cx, float cy, int Wd, int Hd)
     off |= (y0 + 1 < Hd) ? 2 : 0;
     off |= (gxm != 0.f) ? 4 : 0;
     off |= (gym != 0.f) ? 8 : 0;
+    off |= (y0 & 1) ? 16 : 0;          // parity of y0 (that of x0 is in .w): the backward's pending-row slots
     return make_float4(__int_as_float(off), ix - (float)x0, iy - (float)y0, __int_as_float(x0));
 }
 
@@ -553,8 +554,13 @@ hexplane_bwd4_kernel(HexArgs a, int chunks_per_wave, int nchunks, const float* _
                     // touch LDS only when the row changes
                     const int li = p == 2 ? 0 : (p == 4 ? 1 : 2);
                     const int x0 = __float_as_int(r[p].w);
-                    const int lid[2] = {x0, has_x1 ? x0 + 1 : -2};
-                    const float lw[2] = {gv * c[p].ax, gv * c[p].bx};
+                    // a pending row sits in the slot of its PARITY, so it keeps its slot when the walk moves to the next column
+                    // (rows x0 and x0 + 1 always have different parities): slot k takes corner k ^ (x0 & 1)
+                    const bool odd_x = x0 & 1;
+                    const int id_a = x0, id_b = has_x1 ? x0 + 1 : -2;
+                    const float w_a = gv * c[p].ax, w_b = gv * c[p].bx;
+                    const int lid[2] = {odd_x ? id_b : id_a, odd_x ? id_a : id_b};
+                    const float lw[2] = {odd_x ? w_b : w_a, odd_x ? w_a : w_b};
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         if (lid[k] == lpid[li][k]) {
@@ -568,8 +574,20 @@ hexplane_bwd4_kernel(HexArgs a, int chunks_per_wave, int nchunks, const float* _
                 } else {
                     const int si = p == 0 ? 0 : (p == 1 ? 1 : 2);
                     // corners outside the plane carry weight 0: give them id -2 so that they never start a row
-                    const int ids[4] = {c[p].o00, has_x1 ? c[p].o01 : -2, has_y1 ? c[p].o10 : -2, (has_x1 && has_y1) ? c[p].o11 : -2};
-                    const float ws[4] = {c[p].w00, c[p].w01, c[p].w10, c[p].w11};
+                    // A pending row sits in the slot (parity of its y, parity of its x).  The four corners of a texel always take
+                    // four different slots, and a row keeps its slot when the walk moves to a neighbouring texel, so e.g. after
+                    // x0 -> x0 + 1 the two rows of column x0 + 1 stay pending instead of being flushed and restarted: exactly the
+                    // flush count of a 4-way associative set (tools/sim_hexplane_runs.py: 40 % fewer rows than one slot per
+                    // corner).  Slot k takes corner k ^ s, s = 2 (y0 & 1) + (x0 & 1): two conditional swap stages.
+                    int ids[4] = {c[p].o00, has_x1 ? c[p].o01 : -2, has_y1 ? c[p].o10 : -2, (has_x1 && has_y1) ? c[p].o11 : -2};
+                    float ws[4] = {c[p].w00, c[p].w01, c[p].w10, c[p].w11};
+                    {
+                        const bool sx1 = __float_as_int(r[p].w) & 1, sy1 = raw & 16;
+                        const int i0 = sx1 ? ids[1] : ids[0], i1 = sx1 ? ids[0] : ids[1], i2 = sx1 ? ids[3] : ids[2], i3 = sx1 ? ids[2] : ids[3];
+                        const float f0 = sx1 ? ws[1] : ws[0], f1 = sx1 ? ws[0] : ws[1], f2 = sx1 ? ws[3] : ws[2], f3 = sx1 ? ws[2] : ws[3];
+                        ids[0] = sy1 ? i2 : i0; ids[1] = sy1 ? i3 : i1; ids[2] = sy1 ? i0 : i2; ids[3] = sy1 ? i1 : i3;
+                        ws[0] = sy1 ? f2 : f0; ws[1] = sy1 ? f3 : f1; ws[2] = sy1 ? f0 : f2; ws[3] = sy1 ? f1 : f3;
+                    }
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (ids[k] == pid[si][k]) {
