@@ -121,6 +121,8 @@ def _sig(lib):
     return lib
 
 
+SSIM_SUM_SLOTS = 64      # MOM_SSIM_SUM_SLOTS in include/mom4d.h
+
 # every symbol include/mom4d.h declares (tests/test_abi.py checks this list against the header)
 EXPORTS = [
     "mom_version", "mom_raster_geom_bytes", "mom_raster_image_bytes", "mom_raster_binning_bytes", "mom_raster_layout",

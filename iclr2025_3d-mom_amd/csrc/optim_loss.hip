@@ -7,6 +7,7 @@
 // gradient).  All are streaming passes: 16-byte accesses where the layout allows, grid-stride,
 // one atomic per workgroup for reductions.
 #include "mom_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -65,11 +66,26 @@ l1_kernel(size_t n, const float* __restrict__ img, const float* __restrict__ gt,
 {
     __shared__ float s[4];
     float a1 = 0.f, a2 = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float d = img[i] - gt[i];
+    auto one = [&](float x, float y) {
+        const float d = x - y;
         a1 += fabsf(d);
         a2 += d * d;
-        if (dimg) dimg[i] = d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);  // sign(d)/n, torch.abs' subgradient
+        return d > 0.f ? inv_n : (d < 0.f ? -inv_n : 0.f);              // sign(d)/n, torch.abs' subgradient
+    };
+    // 16 bytes per lane when the three pointers allow it; the last n % 4 elements (and everything, otherwise) go one by one
+    const bool vec = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(gt) | reinterpret_cast<uintptr_t>(dimg)) & 15) == 0;
+    const size_t n4 = vec ? n / 4 : 0;
+    const float4* __restrict__ img4 = reinterpret_cast<const float4*>(img);
+    const float4* __restrict__ gt4 = reinterpret_cast<const float4*>(gt);
+    float4* __restrict__ dimg4 = reinterpret_cast<float4*>(dimg);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 x = img4[i], y = gt4[i];
+        const float4 g = make_float4(one(x.x, y.x), one(x.y, y.y), one(x.z, y.z), one(x.w, y.w));
+        if (dimg) dimg4[i] = g;
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float g = one(img[i], gt[i]);
+        if (dimg) dimg[i] = g;
     }
     const float t1 = block_sum(a1, s);
     const float t2 = block_sum(a2, s);
@@ -210,8 +226,16 @@ extern "C" int mom_l1_loss(size_t n, const float* img, const float* gt, float* d
     if (!img || !gt || !sums2) return MOM_EINVAL;
     if (hipMemsetAsync(sums2, 0, 8, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
     if (n == 0) return MOM_OK;
-    size_t blocks = (n + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 2048) blocks = 2048;
+    // every block ends with two atomics on the same two floats, and same-address atomics serialise in the L2: with 760
+    // blocks that tail cost more than streaming the images.  A few hundred fat blocks keep every CU busy and the tail short.
+    static size_t cap = 0;
+    if (!cap) {
+        const char* e = getenv("MOM_L1_BLOCKS");
+        cap = e ? (size_t)atoi(e) : 256;
+        if (cap < 1) cap = 1;
+    }
+    size_t blocks = (n + 256 * 4 - 1) / (256 * 4);
+    if (blocks > cap) blocks = cap;
     MomProfScope ps(MOM_P_L1, (hipStream_t)stream);
     hipLaunchKernelGGL(l1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, img, gt, dimg, 1.0f / (float)n, sums2);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;

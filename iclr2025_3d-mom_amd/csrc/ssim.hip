@@ -22,6 +22,7 @@ constexpr int kT = 16;             // tile edge
 constexpr int kR = 5;              // window radius
 constexpr int kE = kT + 2 * kR;    // staged edge (26)
 constexpr int kES = kE + 1;        // LDS row stride
+constexpr int kSsimSlots = MOM_SSIM_SUM_SLOTS;   // doubles behind `sum`: [0] the total, the rest partial sums
 
 struct Window { float w[2 * kR + 1]; };
 
@@ -91,8 +92,21 @@ ssim_fwd_kernel(Window win, int H, int W, const float* __restrict__ img1, const 
         dm[n + p] = -map / B;
         dm[2 * n + p] = 2.f * Cn * inv_AB;
     }
+    // 6120 blocks at 960x540 adding into ONE double serialise in the L2 (it cost more than the rest of the kernel): spread
+    // the partial sums over the slots sum[1..kSsimSlots-1]; ssim_sum_kernel folds them into sum[0]
     const float tot = block_sum_256(in ? map : 0.f, s_part);
-    if (threadIdx.x == 0) atomicAdd(sum, (double)tot);
+    if (threadIdx.x == 0) {
+        const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        atomicAdd(&sum[1 + b % (kSsimSlots - 1)], (double)tot);
+    }
+}
+
+__global__ void __launch_bounds__(64) ssim_sum_kernel(double* __restrict__ sum)
+{
+    double v = threadIdx.x + 1 < kSsimSlots ? sum[threadIdx.x + 1] : 0.0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (threadIdx.x == 0) sum[0] = v;
 }
 
 __global__ void __launch_bounds__(256)
@@ -147,13 +161,15 @@ extern "C" int mom_ssim_forward(int C, int H, int W, const float* window11, cons
 {
     if (C < 0 || H < 0 || W < 0 || !window11 || !sum) return MOM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sum, 0, sizeof(double), s) != hipSuccess) return MOM_ELAUNCH;
+    if (hipMemsetAsync(sum, 0, sizeof(double) * kSsimSlots, s) != hipSuccess) return MOM_ELAUNCH;
     if (C == 0 || H == 0 || W == 0) return MOM_OK;
     if (!img1 || !img2) return MOM_EINVAL;
     Window win;
     for (int k = 0; k <= 2 * kR; k++) win.w[k] = window11[k];
     hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + kT - 1) / kT, (H + kT - 1) / kT, C), dim3(256), 0, s, win, H, W, img1, img2, dm,
                        sum);
+    if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    hipLaunchKernelGGL(ssim_sum_kernel, dim3(1), dim3(64), 0, s, sum);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

@@ -184,7 +184,7 @@ class FusedStep:
             win = ops._ssim_window()
             if self.ssim_dm is None:         # derivative maps and the map sum (mom_ssim_forward)
                 self.ssim_dm = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev)
-                self.ssim_sum = torch.empty(1, dtype=torch.float64, device=dev)
+                self.ssim_sum = torch.empty(N.SSIM_SUM_SLOTS, dtype=torch.float64, device=dev)   # [0] = the sum
             N.check(lib.mom_ssim_forward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
                                          self.ssim_sum.data_ptr(), s), "ssim_fwd")
             N.check(lib.mom_ssim_backward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),

@@ -264,14 +264,14 @@ class SSIMFunction(torch.autograd.Function):
         Cn = a.numel() // max(1, H * W)
         need_grad = ctx.needs_input_grad[0]
         dm = torch.empty((3,) + tuple(a.shape), dtype=torch.float32, device=a.device) if need_grad else None
-        total = torch.empty(1, dtype=torch.float64, device=a.device)
+        total = torch.empty(N.SSIM_SUM_SLOTS, dtype=torch.float64, device=a.device)      # [0] = the sum, the rest scratch
         N.check(N.lib().mom_ssim_forward(Cn, H, W, _ssim_window(), a.data_ptr(), b.data_ptr(),
                                          None if dm is None else dm.data_ptr(), total.data_ptr(), N.current_stream()),
                 "mom_ssim_forward")
         if need_grad:
             ctx.save_for_backward(a, b, dm)
         ctx.dims = (Cn, H, W)
-        return (total / max(1, a.numel())).float().reshape(())
+        return (total[0] / max(1, a.numel())).float().reshape(())
 
     @staticmethod
     def backward(ctx, g):

@@ -237,12 +237,14 @@ int mom_densify_stats(int P, const int* radii, const float* viewspace_grad, floa
  * 11x11 Gaussian window = outer product of the 11 taps in window11 (host pointer; the reference's
  * gaussian(11, 1.5)), zero padding 5, C1 = 0.01^2, C2 = 0.03^2.  Images are [C][H][W] (any leading batch
  * dimension folded into C: the reference's conv2d is depthwise and its mean runs over every element).
- * forward:  *sum (device, zeroed by the call) = sum over all C*H*W elements of the SSIM map, so that
- *           ssim = *sum / (C*H*W); dm (device, [3][C][H][W], or null when no gradient is wanted) receives the
+ * forward:  sum points at MOM_SSIM_SUM_SLOTS doubles on the device (zeroed by the call): sum[0] receives the sum over
+ *           all C*H*W elements of the SSIM map, so that ssim = sum[0] / (C*H*W); the other slots hold the partial
+ *           sums the blocks spread their atomics over (one shared accumulator serialises in the L2).  dm (device, [3][C][H][W], or null when no gradient is wanted) receives the
  *           map's partial derivatives with respect to the blurred mu1, E[img1^2], E[img1*img2].
  * backward: dimg1 += scale * (scale_dev ? *scale_dev : 1) * d(*sum)/d img1, computed from dm.  For the loss
  *           term lambda * (1 - ssim) pass scale = -lambda / (C*H*W); scale_dev (device scalar, may be null)
  *           lets an autograd caller apply its upstream gradient without reading it back. */
+#define MOM_SSIM_SUM_SLOTS 64
 int mom_ssim_forward(int C, int H, int W, const float* window11, const float* img1, const float* img2, float* dm,
                      double* sum, mom_stream_t stream);
 int mom_ssim_backward(int C, int H, int W, const float* window11, const float* img1, const float* img2, const float* dm,
