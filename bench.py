@@ -160,7 +160,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmom4d has no CPU path)")
     torch.cuda.set_device(local)
-    if world > 1:
+    # MOM_FORCE_DIST=1: run the multi-GPU code path (RCCL process group, DistContext, the step's all-reduces) even with one
+    # rank -- the only way to exercise it on a box with a single GPU.  Launch under torch.distributed.run as usual.
+    force_dist = world == 1 and os.environ.get("MOM_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         dist.init_process_group("nccl")
     dev = torch.device("cuda", local)
     DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
@@ -169,7 +172,7 @@ def main():
     for c in cams:                       # inputs resident in HBM before the timed region: the cameras' matrices and
         c.device_tensors(dev)            # ground-truth images are uploaded here, not on first use inside it
     par = None
-    if world > 1:
+    if world > 1 or force_dist:
         par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
         par.attach(trainer, rank, world, mode=a.shard)
     it0 = 5000  # mid-training iteration numbers: densification statistics on, no densify/reset in the window
@@ -236,7 +239,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -268,8 +268,8 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     const int tiles = gx * gy;
     int ry0, ry1;
     mom_tile_rows(a, gy, &ry0, &ry1);
-    if (hipMemsetAsync(im.hdr, 0, 64 * 4, s) != hipSuccess) return MOM_ELAUNCH;
-    if (hipMemsetAsync(im.tile_counts, 0, (size_t)tiles * 4, s) != hipSuccess) return MOM_ELAUNCH;
+    // the header and the tile counters are adjacent in the image scratch (image_view): one memset for both
+    if (hipMemsetAsync(im.hdr, 0, (size_t)((char*)(im.tile_counts + tiles) - (char*)im.hdr), s) != hipSuccess) return MOM_ELAUNCH;
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
     if (chunks < 1) chunks = 1;
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
