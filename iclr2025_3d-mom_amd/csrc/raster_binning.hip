@@ -26,7 +26,11 @@
 namespace {
 
 constexpr int kSmallRect = 8;          // splats touching <= 8 tiles are enumerated by their own lane
-constexpr int kSortLdsCap = 8192;      // 64 KiB of 64-bit keys per workgroup
+constexpr int kSortLdsCap = 8192;      // 64 KiB of 64-bit keys per workgroup: the largest tile sorted in LDS
+#ifndef MOM_SORT_SMALL
+#define MOM_SORT_SMALL 2048
+#endif
+constexpr int kSortSmallCap = MOM_SORT_SMALL;   // tiles up to this size go to the launch with the small LDS footprint
 constexpr int kMaxLdsTiles = 16384;    // 64 KiB LDS histogram
 
 // Calls f(tile, src_lane, src_payload) once for every (Gaussian, tile) instance of this wave's 64
@@ -236,16 +240,21 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int nthreads, int 
     __syncthreads();
 }
 
+// CAP: keys this instantiation sorts in LDS; it handles the tiles with LO < n <= CAP (n > kSortLdsCap: in global memory) and
+// leaves the others to the sibling launch.  A single kernel sized for the worst case reserved 64 KB of LDS for every tile
+// and fitted two workgroups per CU, while the average tile at 960x540 has ~650 keys.
+template <int LO, int CAP>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
                                                        uint32_t* __restrict__ point_list, uint32_t capacity)
 {
-    __shared__ uint64_t s_keys[kSortLdsCap];
+    __shared__ uint64_t s_keys[CAP];
     const uint2 r = ranges[blockIdx.x];
     uint32_t end = r.y < capacity ? r.y : capacity;
     if (r.x >= end) return;
     const int n = (int)(end - r.x);
+    if (n <= LO || (n > CAP && CAP < kSortLdsCap)) return;          // the sibling launch's tile
     uint64_t* gk = keys + r.x;
-    if (n <= kSortLdsCap) {
+    if (n <= CAP) {
         for (int i = threadIdx.x; i < n; i += 256) s_keys[i] = gk[i];
         __syncthreads();
         if (n > 1) bitonic_sort<true>(s_keys, n, 256, threadIdx.x);
@@ -308,6 +317,9 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     mom_prof_end(MOM_P_SCATTER, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SORT, s);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(tiles), dim3(256), 0, s, im.ranges, b.keys, b.point_list, cap);
+    hipLaunchKernelGGL((tile_sort_kernel<0, kSortSmallCap>), dim3(tiles), dim3(256), 0, s, im.ranges, b.keys, b.point_list, cap);
+    if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    hipLaunchKernelGGL((tile_sort_kernel<kSortSmallCap, kSortLdsCap>), dim3(tiles), dim3(256), 0, s, im.ranges, b.keys, b.point_list,
+                       cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
