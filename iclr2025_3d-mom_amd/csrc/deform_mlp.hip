@@ -57,17 +57,18 @@ struct MlpDev {
 // cooperative load of all weights into LDS (workgroup of 256 threads)
 __device__ __forceinline__ void load_weights(const MlpDev& m, float* __restrict__ lds)
 {
+    const int nth = (int)blockDim.x;                             // 256 (backward) or the forward kernel's block size
     const float* Ws[4] = {m.W0, m.W1[0], m.W1[1], m.W1[2]};
     const float* bs[4] = {m.b0, m.b1[0], m.b1[1], m.b1[2]};
 #pragma unroll
     for (int L = 0; L < 4; L++) {
-        for (int i = threadIdx.x; i < kHid * kHid; i += 256) {
+        for (int i = threadIdx.x; i < kHid * kHid; i += nth) {
             const int o = i >> 6, k = i & 63;                       // W[out][in] row-major: coalesced along `in`
             lds[kLW + L * kWFloats + k * kWStride + o] = Ws[L][i];
         }
         if (threadIdx.x < kHid) lds[kLB + L * kHid + threadIdx.x] = bs[L][threadIdx.x];
     }
-    for (int i = threadIdx.x; i < 3 * 4 * kHid; i += 256) {
+    for (int i = threadIdx.x; i < 3 * 4 * kHid; i += nth) {
         const int head = i >> 8, n = (i >> 6) & 3, f = i & 63;
         const int nout = head == 2 ? 4 : 3;
         lds[kLW2 + i] = n < nout ? m.W2[head][n * kHid + f] : 0.f;
@@ -165,7 +166,10 @@ __device__ __forceinline__ void out_layer(const float* __restrict__ W2l, const f
     }
 }
 
-__global__ void __launch_bounds__(256, 2)
+// BLOCK threads share ONE copy of the weights in LDS (70 KB).  With 256 threads two workgroups = 8 waves fit per CU although
+// the registers allow 16: a 1024-thread workgroup gets those 16 waves for the same LDS.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ xyz,
                   const float* __restrict__ scaling, const float* __restrict__ rotation, const float* __restrict__ flow,
                   float flow_coef, float* __restrict__ pts, float* __restrict__ scales, float* __restrict__ rots,
@@ -175,7 +179,7 @@ deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
     load_weights(m, lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const int wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLOCK) >> 6;
     for (int t = wave; t < tiles; t += nwaves) {
         const int g = t * 32 + col;
         const bool ok = g < P;
@@ -498,19 +502,38 @@ extern "C" int mom_deform_forward(const MomDeformMLP* w, int P, const float* fea
     int rc = fill_dev(w, &d);
     if (rc) return rc;
     const int tiles = (P + 31) / 32;
-    int blocks = (tiles + 3) / 4;
-    if (blocks > 512) blocks = 512;                    // persistent: two workgroups per CU, weights LDS-resident
+    static int block = 0;
+    if (!block) {
+        const char* e = getenv("MOM_MLP_FWD_BLOCK");
+        block = e ? atoi(e) : 1024;
+        if (block != 256 && block != 512 && block != 1024) block = 1024;
+    }
+    const int waves_per_block = block / 64;
+    int blocks = (tiles + waves_per_block - 1) / waves_per_block;
+    const int per_cu = block == 256 ? 2 : 1;           // persistent: the weights stay in LDS; 70 KB per workgroup
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     static bool attr_set = false;
     const size_t lds_bytes = sizeof(float) * kLFwdTotal;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return MOM_ELAUNCH;
         attr_set = true;
     }
     MomProfScope ps(MOM_P_MLP_FWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(deform_fwd_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz, scaling,
-                       rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
+    if (block == 256)
+        hipLaunchKernelGGL(deform_fwd_kernel<256>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz,
+                           scaling, rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
+    else if (block == 512)
+        hipLaunchKernelGGL(deform_fwd_kernel<512>, dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz,
+                           scaling, rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
+    else
+        hipLaunchKernelGGL(deform_fwd_kernel<1024>, dim3(blocks), dim3(1024), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz,
+                           scaling, rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
