@@ -23,6 +23,9 @@ CONFIGS = {
     "c2": dict(P=200_000, F=60, W=960, H=540, time_res=50, name="200k Gaussians, 60 frames, 960x540, HexPlane on"),
     "c3": dict(P=1_000_000, F=120, W=1920, H=1080, time_res=100, name="1M Gaussians, 120 frames, 1920x1080"),
     "c1": dict(P=5_000, F=8, W=256, H=256, time_res=50, name="5k Gaussians, 8 frames, 256x256"),
+    # BASELINE configs[4]'s per-GPU model size (the camera-batch shard replicates the model); few frames keep the host's
+    # share of the ground-truth images small.  A scale check, not a bench line.
+    "c5": dict(P=4_000_000, F=8, W=1920, H=1080, time_res=100, name="4M Gaussians, 8 frames, 1920x1080"),
 }
 
 
