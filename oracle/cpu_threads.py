@@ -1,5 +1,14 @@
-import sys, time, os
-sys.path.insert(0, '.')
+"""Thread scaling of the CPU baseline (the oracle timed by bench.py's cpu_baseline leg): prints the step time of the same
+fine-stage step at 8..128 threads on this host.  It chose the 16 threads bench.py uses (8: 2.4 s, 16: 1.4 s, 32: 1.6 s,
+64: 2.5 s, 128: 4.5 s per step on the GPU box's 2 x EPYC 9575F).  Part of the oracle, like everything that runs it.
+
+    python oracle/cpu_threads.py
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from oracle import cpu_backend, raster_oracle as ro
 import bench

@@ -8,6 +8,7 @@ Policies: "slot" = the kernel's (corner k of a plane has one pending row; flushe
 Orders: morton3d (the kernel's), xy-major, and the identity.
 """
 import argparse
+import importlib
 import importlib.util
 import os
 import sys
@@ -83,14 +84,12 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--blocks", type=int, default=768)
     a = ap.parse_args()
-    import torch
     cfg = bench.CONFIGS[a.config]
-    from oracle import cpu_backend
-    with cpu_backend.installed():
-        scene, g, trainer, op = bench.build_state(cfg, "cpu")
-    xyz = g._xyz.detach().numpy().astype(np.float64)
-    field = g._deformation.deformation_net.grid
-    aabb = field.aabb.detach().numpy().astype(np.float64)
+    # only the scene's point cloud and its bounding box are needed: no model, no backend
+    S = importlib.import_module("iclr2025_3d-mom_amd.scene")
+    scene = S.SyntheticScene(cfg["P"], cfg["F"], cfg["W"], cfg["H"], seed=6666)
+    xyz = np.asarray(scene.point_cloud.points, dtype=np.float64)
+    aabb = np.array([scene.xyz_max, scene.xyz_min], dtype=np.float64)     # HexPlaneField.set_aabb(xyz_max, xyz_min)
     P = len(xyz)
     nchunks = (P + 63) // 64
     waves = a.blocks * 4
