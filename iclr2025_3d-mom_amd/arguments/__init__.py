@@ -7,132 +7,91 @@ from argparse import ArgumentParser, Namespace
 
 
 class GroupParams:
-    pass
+    """Plain attribute bag returned by ParamGroup.extract()."""
+
+
+# Defaults of the four parameter groups, as data: option name -> default value (reference arguments/__init__.py:47-174).
+# A leading underscore marks the options that also get a one-letter flag (-s, -m, -i, -r, -w), as in the reference.
+_MODEL = {
+    "sh_degree": 3, "_source_path": "", "_model_path": "", "_images": "images", "_resolution": -1, "_white_background": False,
+    "data_device": "cuda", "eval": True, "render_process": False, "add_points": False, "extension": ".png", "llffhold": 8,
+}
+_PIPELINE = {"convert_SHs_python": False, "compute_cov3D_python": False, "debug": False}
+_HIDDEN = {
+    "net_width": 64, "timebase_pe": 4, "defor_depth": 1, "posebase_pe": 10, "scale_rotation_pe": 2, "opacity_pe": 2,
+    "timenet_width": 64, "timenet_output": 32, "bounds": 1.6,
+    "plane_tv_weight": 0.0001, "time_smoothness_weight": 0.01, "l1_time_planes": 0.0001,
+    "kplanes_config": {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32, "resolution": [64, 64, 64, 25]},
+    "multires": [1, 2, 4, 8],
+    "no_dx": False, "no_grid": False, "no_ds": False, "no_dr": False, "no_do": True, "no_dshs": True,
+    "empty_voxel": False, "grid_pe": 0, "static_mlp": False, "apply_rotation": False,
+}
+_OPTIM = {
+    "dataloader": False, "zerostamp_init": False, "custom_sampler": None,
+    "iterations": 30_000, "coarse_iterations": 3000,
+    "position_lr_init": 0.00016, "position_lr_final": 0.0000016, "position_lr_delay_mult": 0.01, "position_lr_max_steps": 20_000,
+    "deformation_lr_init": 0.00016, "deformation_lr_final": 0.000016, "deformation_lr_delay_mult": 0.01,
+    "grid_lr_init": 0.0016, "grid_lr_final": 0.00016,
+    "feature_lr": 0.0025, "opacity_lr": 0.05, "scaling_lr": 0.005, "rotation_lr": 0.001,
+    "percent_dense": 0.01, "lambda_dssim": 0, "lambda_lpips": 0,
+    "weight_constraint_init": 1, "weight_constraint_after": 0.2, "weight_decay_iteration": 5000,
+    "opacity_reset_interval": 3000, "densification_interval": 100, "densify_from_iter": 500, "densify_until_iter": 15_000,
+    "densify_grad_threshold_coarse": 0.0002, "densify_grad_threshold_fine_init": 0.0002, "densify_grad_threshold_after": 0.0002,
+    "pruning_from_iter": 500, "pruning_interval": 100,
+    "opacity_threshold_coarse": 0.005, "opacity_threshold_fine_init": 0.005, "opacity_threshold_fine_after": 0.005,
+    "batch_size": 1, "add_point": False,
+}
 
 
 class ParamGroup:
-    def __init__(self, parser: ArgumentParser, name: str, fill_none=False):
-        group = parser.add_argument_group(name)
-        for key, value in vars(self).items():
-            shorthand = key.startswith("_")
-            key = key[1:] if shorthand else key
-            t = type(value)
-            value = value if not fill_none else None
-            flags = ["--" + key] + (["-" + key[0:1]] if shorthand else [])
-            if t == bool:
-                group.add_argument(*flags, default=value, action="store_true")
+    """One argparse group built from a table of defaults.  Booleans become store_true flags, everything else takes the type
+    of its default; with `fill_none` every default is None (the render scripts use that to tell "not given" apart)."""
+    TITLE, TABLE = "", {}
+
+    def __init__(self, parser: ArgumentParser, fill_none=False):
+        self._names = set()
+        group = parser.add_argument_group(self.TITLE)
+        for raw, default in self.TABLE.items():
+            name = raw.lstrip("_")
+            self._names.add(name)
+            setattr(self, raw, default)                      # the defaults stay readable as attributes
+            flags = ["--" + name] + (["-" + name[0]] if raw.startswith("_") else [])
+            shown = None if fill_none else default
+            if isinstance(default, bool):
+                group.add_argument(*flags, default=shown, action="store_true")
             else:
-                group.add_argument(*flags, default=value, type=t)
+                group.add_argument(*flags, default=shown, type=type(default))
 
     def extract(self, args):
-        g = GroupParams()
-        for k, v in vars(args).items():
-            if k in vars(self) or ("_" + k) in vars(self):
-                setattr(g, k, v)
-        return g
+        out = GroupParams()
+        for name, value in vars(args).items():
+            if name in self._names:
+                setattr(out, name, value)
+        return out
 
 
 class ModelParams(ParamGroup):
+    TITLE, TABLE = "Loading Parameters", _MODEL
+
     def __init__(self, parser, sentinel=False):
-        self.sh_degree = 3
-        self._source_path = ""
-        self._model_path = ""
-        self._images = "images"
-        self._resolution = -1
-        self._white_background = False
-        self.data_device = "cuda"
-        self.eval = True
-        self.render_process = False
-        self.add_points = False
-        self.extension = ".png"
-        self.llffhold = 8
-        super().__init__(parser, "Loading Parameters", sentinel)
+        super().__init__(parser, fill_none=sentinel)
 
     def extract(self, args):
-        g = super().extract(args)
-        g.source_path = os.path.abspath(g.source_path)
-        return g
+        out = super().extract(args)
+        out.source_path = os.path.abspath(out.source_path)
+        return out
 
 
 class PipelineParams(ParamGroup):
-    def __init__(self, parser):
-        self.convert_SHs_python = False
-        self.compute_cov3D_python = False
-        self.debug = False
-        super().__init__(parser, "Pipeline Parameters")
+    TITLE, TABLE = "Pipeline Parameters", _PIPELINE
 
 
 class ModelHiddenParams(ParamGroup):
-    def __init__(self, parser):
-        self.net_width = 64
-        self.timebase_pe = 4
-        self.defor_depth = 1
-        self.posebase_pe = 10
-        self.scale_rotation_pe = 2
-        self.opacity_pe = 2
-        self.timenet_width = 64
-        self.timenet_output = 32
-        self.bounds = 1.6
-        self.plane_tv_weight = 0.0001
-        self.time_smoothness_weight = 0.01
-        self.l1_time_planes = 0.0001
-        self.kplanes_config = {'grid_dimensions': 2, 'input_coordinate_dim': 4, 'output_coordinate_dim': 32,
-                               'resolution': [64, 64, 64, 25]}
-        self.multires = [1, 2, 4, 8]
-        self.no_dx = False
-        self.no_grid = False
-        self.no_ds = False
-        self.no_dr = False
-        self.no_do = True
-        self.no_dshs = True
-        self.empty_voxel = False
-        self.grid_pe = 0
-        self.static_mlp = False
-        self.apply_rotation = False
-        super().__init__(parser, "ModelHiddenParams")
+    TITLE, TABLE = "ModelHiddenParams", _HIDDEN
 
 
 class OptimizationParams(ParamGroup):
-    def __init__(self, parser):
-        self.dataloader = False
-        self.zerostamp_init = False
-        self.custom_sampler = None
-        self.iterations = 30_000
-        self.coarse_iterations = 3000
-        self.position_lr_init = 0.00016
-        self.position_lr_final = 0.0000016
-        self.position_lr_delay_mult = 0.01
-        self.position_lr_max_steps = 20_000
-        self.deformation_lr_init = 0.00016
-        self.deformation_lr_final = 0.000016
-        self.deformation_lr_delay_mult = 0.01
-        self.grid_lr_init = 0.0016
-        self.grid_lr_final = 0.00016
-        self.feature_lr = 0.0025
-        self.opacity_lr = 0.05
-        self.scaling_lr = 0.005
-        self.rotation_lr = 0.001
-        self.percent_dense = 0.01
-        self.lambda_dssim = 0
-        self.lambda_lpips = 0
-        self.weight_constraint_init = 1
-        self.weight_constraint_after = 0.2
-        self.weight_decay_iteration = 5000
-        self.opacity_reset_interval = 3000
-        self.densification_interval = 100
-        self.densify_from_iter = 500
-        self.densify_until_iter = 15_000
-        self.densify_grad_threshold_coarse = 0.0002
-        self.densify_grad_threshold_fine_init = 0.0002
-        self.densify_grad_threshold_after = 0.0002
-        self.pruning_from_iter = 500
-        self.pruning_interval = 100
-        self.opacity_threshold_coarse = 0.005
-        self.opacity_threshold_fine_init = 0.005
-        self.opacity_threshold_fine_after = 0.005
-        self.batch_size = 1
-        self.add_point = False
-        super().__init__(parser, "Optimization Parameters")
+    TITLE, TABLE = "Optimization Parameters", _OPTIM
 
 
 # arguments/dnerf/dnerf_default.py:3-33 overlaid by arguments/dnerf/hellwarrior.py:3-10 (train_4DGS.py:432 default)
@@ -174,20 +133,19 @@ def default_args(time_resolution=None, **overrides):
 
 
 def get_combined_args(parser: ArgumentParser):
-    cmdlne_string = sys.argv[1:]
-    cfgfile_string = "Namespace()"
-    args_cmdline = parser.parse_args(cmdlne_string)
+    """Command line merged over the `cfg_args` file a training run left in its model directory (a printed Namespace): what
+    the render scripts start from.  A command-line value wins whenever it was actually given (is not None)."""
+    given = parser.parse_args(sys.argv[1:])
+    stored = Namespace()
     try:
-        cfgfilepath = os.path.join(args_cmdline.input_dir, "cfg_args")
-        print("Looking for config file in", cfgfilepath)
-        with open(cfgfilepath) as cfg_file:
-            print("Config file found: {}".format(cfgfilepath))
-            cfgfile_string = cfg_file.read()
+        path = os.path.join(given.input_dir, "cfg_args")
+        print("Looking for config file in", path)
+        with open(path) as fh:
+            text = fh.read()
+        print("Config file found: {}".format(path))
+        stored = eval(text)                                   # the file holds repr(Namespace(...)), as the reference writes it
     except TypeError:
         print("Config file not found at")
-    args_cfgfile = eval(cfgfile_string)
-    merged = vars(args_cfgfile).copy()
-    for k, v in vars(args_cmdline).items():
-        if v is not None:
-            merged[k] = v
+    merged = dict(vars(stored))
+    merged.update({k: v for k, v in vars(given).items() if v is not None})
     return Namespace(**merged)
