@@ -115,10 +115,11 @@ __device__ __forceinline__ float splat_power(const float4 r0, const float4 r1, f
 // wave then compacts the indices of its reachable splats (ballot + rank) and loops over those only.  The test works on the
 // continuous rectangle with a margin, so it keeps every pair the exact per-pixel tests could accept, and those tests
 // still run: results are bit-identical.  Anything degenerate (non-positive conic diagonal, NaN) counts as reachable.
-__device__ __forceinline__ float edge_max(float fixed, float lo, float hi, float q_fixed, float q_free, float b)
+__device__ __forceinline__ float edge_max(float fixed, float lo, float hi, float q_fixed, float q_free, float inv_q_free, float b)
 {
-    // max over t in [lo, hi] of  -0.5 (q_fixed fixed^2 + q_free t^2) - b fixed t
-    const float t = fminf(fmaxf(-b * fixed / q_free, lo), hi);
+    // max over t in [lo, hi] of  -0.5 (q_fixed fixed^2 + q_free t^2) - b fixed t.  The stationary point uses a hardware
+    // reciprocal (1 ulp): the quadratic is flat there, so its error is second order and far inside the caller's margin.
+    const float t = fminf(fmaxf(-b * fixed * inv_q_free, lo), hi);
     return -0.5f * (q_fixed * fixed * fixed + q_free * t * t) - b * fixed * t;
 }
 // Footprint of a wave inside the 16x16 tile: kFW x kFH pixels, kWX footprints across.  (16x4 strips: 16,4,1; 8x8 blocks: 8,8,2.)
@@ -130,6 +131,7 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
 {
     const float cx = r0.x, cy = r0.y, a = r1.x, b = r1.y, c = r1.z, bound = r0.w - 1e-3f;
     if (!(a > 0.f) || !(c > 0.f)) return 0xFu;
+    const float inv_a = __builtin_amdgcn_rcpf(a), inv_c = __builtin_amdgcn_rcpf(c);     // two reciprocals serve all 16 edges
     uint32_t m = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -141,8 +143,8 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
         if (cx >= xa && cx <= xb && cy >= ya && cy <= yb) {
             best = 0.f;
         } else {
-            best = fmaxf(fmaxf(edge_max(dxl, dyl, dyh, a, c, b), edge_max(dxh, dyl, dyh, a, c, b)),
-                         fmaxf(edge_max(dyl, dxl, dxh, c, a, b), edge_max(dyh, dxl, dxh, c, a, b)));
+            best = fmaxf(fmaxf(edge_max(dxl, dyl, dyh, a, c, inv_c, b), edge_max(dxh, dyl, dyh, a, c, inv_c, b)),
+                         fmaxf(edge_max(dyl, dxl, dxh, c, a, inv_a, b), edge_max(dyh, dxl, dxh, c, a, inv_a, b)));
         }
         m |= (!(best < bound)) ? (1u << w) : 0u;
     }
