@@ -166,10 +166,9 @@ __device__ __forceinline__ void out_layer(const float* __restrict__ W2l, const f
     }
 }
 
-// BLOCK threads share ONE copy of the weights in LDS (70 KB).  With 256 threads two workgroups = 8 waves fit per CU although
-// the registers allow 16: a 1024-thread workgroup gets those 16 waves for the same LDS.
-template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+// All threads of a workgroup share ONE copy of the weights in LDS (70 KB).  With 256 threads two workgroups = 8 waves fit per
+// CU although the registers allow 16: a workgroup of up to 1024 threads gets up to 16 waves for the same LDS.
+__global__ void __launch_bounds__(1024)
 deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ xyz,
                   const float* __restrict__ scaling, const float* __restrict__ rotation, const float* __restrict__ flow,
                   float flow_coef, float* __restrict__ pts, float* __restrict__ scales, float* __restrict__ rots,
@@ -179,7 +178,7 @@ deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
     load_weights(m, lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-    const int wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = (gridDim.x * BLOCK) >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (int t = wave; t < tiles; t += nwaves) {
         const int g = t * 32 + col;
         const bool ok = g < P;
@@ -502,38 +501,28 @@ extern "C" int mom_deform_forward(const MomDeformMLP* w, int P, const float* fea
     int rc = fill_dev(w, &d);
     if (rc) return rc;
     const int tiles = (P + 31) / 32;
+    // one workgroup per CU, any multiple of 64 threads up to 1024 (MOM_MLP_FWD_BLOCK); the weights stay in LDS (70 KB)
     static int block = 0;
     if (!block) {
         const char* e = getenv("MOM_MLP_FWD_BLOCK");
         block = e ? atoi(e) : 1024;
-        if (block != 256 && block != 512 && block != 1024) block = 1024;
+        if (block < 64 || block > 1024 || (block & 63)) block = 1024;
     }
     const int waves_per_block = block / 64;
     int blocks = (tiles + waves_per_block - 1) / waves_per_block;
-    const int per_cu = block == 256 ? 2 : 1;           // persistent: the weights stay in LDS; 70 KB per workgroup
+    const int per_cu = block <= 256 ? 2 : 1;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     static bool attr_set = false;
     const size_t lds_bytes = sizeof(float) * kLFwdTotal;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_bytes) != hipSuccess)
             return MOM_ELAUNCH;
         attr_set = true;
     }
     MomProfScope ps(MOM_P_MLP_FWD, (hipStream_t)stream);
-    if (block == 256)
-        hipLaunchKernelGGL(deform_fwd_kernel<256>, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz,
-                           scaling, rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
-    else if (block == 512)
-        hipLaunchKernelGGL(deform_fwd_kernel<512>, dim3(blocks), dim3(512), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz,
-                           scaling, rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
-    else
-        hipLaunchKernelGGL(deform_fwd_kernel<1024>, dim3(blocks), dim3(1024), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz,
-                           scaling, rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3(blocks), dim3(block), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz, scaling,
+                       rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
