@@ -105,6 +105,10 @@ def _sig(lib):
     lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
     lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    lib.mom_select_scratch_bytes.restype = sz
+    lib.mom_select_scratch_bytes.argtypes = [i32]
+    lib.mom_select_plan.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    lib.mom_select_apply.argtypes = [i32, vp, C.POINTER(MomRowSelect), i32, vp]
     lib.mom_ssim_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.mom_ssim_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.mom_activations_forward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
@@ -122,6 +126,12 @@ def _sig(lib):
 
 
 SSIM_SUM_SLOTS = 64      # MOM_SSIM_SUM_SLOTS in include/mom4d.h
+SELECT_MAX_TENSORS = 32  # MOM_SELECT_MAX_TENSORS
+
+
+class MomRowSelect(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("row_bytes", C.c_uint)]
+
 
 # every symbol include/mom4d.h declares (tests/test_abi.py checks this list against the header)
 EXPORTS = [
@@ -132,7 +142,7 @@ EXPORTS = [
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
     "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward",
     "mom_ssim_forward", "mom_ssim_backward", "mom_raster_backward_render", "mom_raster_backward_geometry",
-    "mom_densify_stats",
+    "mom_densify_stats", "mom_select_scratch_bytes", "mom_select_plan", "mom_select_apply",
 ]
 
 

@@ -212,6 +212,44 @@ def l1_loss_with_sums(img, gt):
     return L1LossFunction.apply(img, gt)
 
 
+# --------------------------------------------------------------------------- row selection (densify / prune)
+def select_rows(mask, tensors):
+    """[t[mask] for t in tensors] -- the selection the reference's optimizer surgery does per tensor (scene/gaussian_model.py:
+    409-482, 511-581) -- through ONE compaction plan: the mask is scanned once, one host synchronisation reads the number of
+    kept rows (the outputs have to be allocated), and one kernel gathers the rows of every tensor."""
+    _need_cuda(mask, "select_rows")
+    n = mask.shape[0]
+    if mask.dim() != 1 or mask.dtype != torch.bool:
+        raise N.MomError("select_rows: the mask must be a 1-D bool tensor")
+    srcs = []
+    for t_ in tensors:
+        if t_.shape[0] != n or not t_.is_cuda:
+            raise N.MomError("select_rows: every tensor needs one row per mask element, on the GPU")
+        srcs.append(t_.detach().contiguous())
+    lib, s = N.lib(), N.current_stream()
+    dev = mask.device
+    keep = mask.contiguous().view(torch.uint8)
+    dst_index = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    count_dev = torch.empty(1, dtype=torch.int32, device=dev)
+    count_host = torch.empty(1, dtype=torch.int32).pin_memory()
+    scratch = torch.empty(lib.mom_select_scratch_bytes(n), dtype=torch.uint8, device=dev)
+    N.check(lib.mom_select_plan(n, keep.data_ptr(), dst_index.data_ptr(), count_dev.data_ptr(), count_host.data_ptr(),
+                                scratch.data_ptr(), s), "mom_select_plan")
+    torch.cuda.current_stream().synchronize()          # the one sync of the round: sizes of the outputs
+    m = int(count_host[0])
+    outs = [torch.empty((m,) + tuple(t_.shape[1:]), dtype=t_.dtype, device=dev) for t_ in srcs]
+    if m == 0:                                           # nothing kept: empty outputs (their data pointers are null)
+        return outs
+    for lo in range(0, len(srcs), N.SELECT_MAX_TENSORS):
+        part = list(zip(srcs, outs))[lo:lo + N.SELECT_MAX_TENSORS]
+        arr = (N.MomRowSelect * len(part))()
+        for i, (a, b) in enumerate(part):
+            rb = (a.numel() // max(n, 1)) * a.element_size() if n else 0
+            arr[i].src, arr[i].dst, arr[i].row_bytes = a.data_ptr(), b.data_ptr(), rb
+        N.check(lib.mom_select_apply(n, dst_index.data_ptr(), arr, len(part), s), "mom_select_apply")
+    return outs
+
+
 # --------------------------------------------------------------------------- densification statistics
 def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):
     """In place, for the Gaussians with radii > 0: running maximum radius, accumulated |dL/d mean2D| and its count
@@ -423,6 +461,7 @@ class _HipBackend:
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
     ssim = staticmethod(ssim)
     densify_stats = staticmethod(densify_stats)
+    select_rows = staticmethod(select_rows)
     plane_regulation = staticmethod(plane_regulation)
     Adam = FusedAdam
 

@@ -282,8 +282,23 @@ class GaussianModel:
             out[g["name"]] = new
         return out
 
-    def _prune_optimizer(self, mask):
-        return self._rebuild(lambda n, p: p[mask], lambda n, s: s[mask])
+    def _prune_optimizer(self, mask, extra=()):
+        """Keep the rows with mask set in every per-point parameter and both of its Adam moments (reference :409-440), plus in
+        the `extra` tensors, all through ONE backend selection; returns (new parameters by group name, selected extras)."""
+        groups = self._single_groups()
+        flat = []
+        for g in groups:
+            old = g["params"][0]
+            st = self.optimizer.state.get(old, None)
+            flat.append(old.detach())
+            if st is not None:
+                flat += [st["exp_avg"], st["exp_avg_sq"]]
+        sel = iter(ops.BACKEND.select_rows(mask, flat + list(extra)))
+
+        def take(n, t):
+            return next(sel)
+        out = self._rebuild(take, take)
+        return out, [next(sel) for _ in extra]
 
     def cat_tensors_to_optimizer(self, tensors_dict):
         return self._rebuild(lambda n, p: torch.cat((p, tensors_dict[n]), dim=0),
@@ -295,13 +310,11 @@ class GaussianModel:
 
     def prune_points(self, mask):
         keep = ~mask
-        self._adopt(self._prune_optimizer(keep))
-        self._deformation_accum = self._deformation_accum[keep]
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self._deformation_table = self._deformation_table[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
-        self._scene_flow = self._scene_flow[keep]
+        params, extra = self._prune_optimizer(keep, (self._deformation_accum, self.xyz_gradient_accum, self._deformation_table,
+                                                      self.denom, self.max_radii2D, self._scene_flow))
+        self._adopt(params)
+        (self._deformation_accum, self.xyz_gradient_accum, self._deformation_table, self.denom, self.max_radii2D,
+         self._scene_flow) = extra
 
     def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation,
                               new_deformation_table, new_sceneflow):
@@ -325,23 +338,29 @@ class GaussianModel:
         sel = (padded >= grad_threshold) & (torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
         if not sel.any():
             return
-        stds = self.get_scaling[sel].repeat(N, 1)
+        # the selected rows of every tensor the split needs, through one backend selection (the reference indexes each with the
+        # mask: scaling twice, rotation twice, xyz, both SH parts, opacity, the deformation table, the flow)
+        xyz_s, fdc_s, frest_s, opac_s, scal_raw_s, rot_s, table_s, flow_s = ops.BACKEND.select_rows(
+            sel, [self._xyz.detach(), self._features_dc.detach(), self._features_rest.detach(), self._opacity.detach(),
+                  self._scaling.detach(), self._rotation.detach(), self._deformation_table, self.get_flow])
+        scal_s = self.scaling_activation(scal_raw_s)
+        stds = scal_s.repeat(N, 1)
         samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
-        rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
-        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[sel].repeat(N, 1)
-        new_scaling = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
-        self.densification_postfix(new_xyz, self._features_dc[sel].repeat(N, 1, 1), self._features_rest[sel].repeat(N, 1, 1),
-                                   self._opacity[sel].repeat(N, 1), new_scaling, self._rotation[sel].repeat(N, 1),
-                                   self._deformation_table[sel].repeat(N), self.get_flow[sel].repeat(N, 1))
-        self.prune_points(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=dev, dtype=bool))))
+        rots = build_rotation(rot_s).repeat(N, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + xyz_s.repeat(N, 1)
+        new_scaling = self.scaling_inverse_activation(scal_s.repeat(N, 1) / (0.8 * N))
+        self.densification_postfix(new_xyz, fdc_s.repeat(N, 1, 1), frest_s.repeat(N, 1, 1), opac_s.repeat(N, 1), new_scaling,
+                                   rot_s.repeat(N, 1), table_s.repeat(N), flow_s.repeat(N, 1))
+        self.prune_points(torch.cat((sel, torch.zeros(N * xyz_s.shape[0], device=dev, dtype=bool))))
 
     def densify_and_clone(self, grads, grad_threshold, scene_extent, density_threshold=20, displacement_scale=20,
                           model_path=None, iteration=None, stage=None):
         sel = (torch.norm(grads, dim=-1) >= grad_threshold) & \
               (torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
-        self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel], self._opacity[sel],
-                                   self._scaling[sel], self._rotation[sel], self._deformation_table[sel],
-                                   self._scene_flow[sel])
+        picked = ops.BACKEND.select_rows(sel, [self._xyz.detach(), self._features_dc.detach(), self._features_rest.detach(),
+                                               self._opacity.detach(), self._scaling.detach(), self._rotation.detach(),
+                                               self._deformation_table, self._scene_flow])
+        self.densification_postfix(*picked)
 
     def prune(self, max_grad, min_opacity, extent, max_screen_size):
         mask = (self.get_opacity < min_opacity).squeeze()

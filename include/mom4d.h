@@ -226,6 +226,24 @@ int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double 
  * dimg (may be null) = sign(img-gt)/n = d mean|img-gt| / d img. */
 int mom_l1_loss(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream);
 
+/* ---- Row selection for densify / prune (scene/gaussian_model.py:409-482 _prune_optimizer, cat_tensors_to_optimizer,
+ * prune_points; :511-581 densify_and_split, densify_and_clone, prune: `tensor[mask]` once per parameter, per Adam moment and
+ * per auxiliary tensor, each with its own nonzero() and host synchronisation) ----
+ * plan:  dst_index[i] (device, [n]) = position of row i among the rows with keep[i] != 0, or -1; *count_dev (device) and, if
+ *        count_host != null (pinned host memory, copied on the stream), *count_host = the number of kept rows.
+ * apply: for each of the `count` tensors, dst[dst_index[i]] = src[i] for the kept rows i; a row is row_bytes bytes (any size;
+ *        4-byte words when size and alignment allow).  dst must hold *count rows. */
+#define MOM_SELECT_MAX_TENSORS 32
+typedef struct {
+    const void* src;
+    void* dst;
+    unsigned row_bytes;
+} MomRowSelect;
+size_t mom_select_scratch_bytes(int n);
+int mom_select_plan(int n, const uint8_t* keep, int* dst_index, int* count_dev, int* count_host, void* scratch,
+                    mom_stream_t stream);
+int mom_select_apply(int n, const int* dst_index, const MomRowSelect* tensors, int count, mom_stream_t stream);
+
 /* ---- Densification statistics of one iteration (train_4DGS.py:266; scene/gaussian_model.py:713-715
  * add_densification_stats), in place, for the Gaussians with radii[i] > 0:
  *   max_radii2D[i] = max(max_radii2D[i], radii[i]);  xyz_gradient_accum[i] += |viewspace_grad[i, :2]|;  denom[i] += 1.

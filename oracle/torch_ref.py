@@ -110,6 +110,11 @@ def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom)
     denom[vis] += 1
 
 
+def select_rows(mask, tensors):
+    """scene/gaussian_model.py:409-482,511-581: boolean-mask indexing, one tensor at a time."""
+    return [t[mask] for t in tensors]
+
+
 class TorchBackend:
     """Oracle backend for host-logic tests on machines without a GPU (installed explicitly by tests)."""
     name = "torch-oracle"
@@ -117,6 +122,7 @@ class TorchBackend:
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)
     ssim = staticmethod(ssim)
     densify_stats = staticmethod(densify_stats)
+    select_rows = staticmethod(select_rows)
     plane_regulation = staticmethod(plane_regulation)
     Adam = torch.optim.Adam
 
