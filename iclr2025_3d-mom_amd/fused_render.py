@@ -1,0 +1,105 @@
+"""Forward-only rendering of one camera as a fixed launch sequence: HexPlane -> deformation MLP -> activations ->
+projection / binning / sort / compositing.  gaussian_renderer.render() takes this path when gradients are disabled and the
+model has the shipped configuration (the case of render_4DGS.py and of every evaluation render): the same kernels as the
+fused training step, no SH concatenation (the rasterizer reads the DC and the rest coefficients through two pointers), no
+gradient holder, no per-op allocation of intermediates.  Only the returned image, depth and radii are fresh tensors --
+callers keep them.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+from . import ops
+from .diff_gaussian_rasterization import _C as RC
+
+
+class FusedRender:
+    def __init__(self, gaussians):
+        self.g = gaussians
+        self.lib = N.lib()
+        self.key = None
+        self.cap = 0
+        self.binning = None
+        self._desc_key = None
+
+    def _ensure(self, P, W, H, dev):
+        if self.key == (P, W, H, dev):
+            return
+        self.key = (P, W, H, dev)
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        self.feat = e(P, 64)
+        self.pts, self.sc_d, self.rot_d = e(P, 3), e(P, 3), e(P, 4)
+        self.sc, self.rot, self.op = e(P, 3), e(P, 4), e(P, 1)
+        self.geom = torch.empty(self.lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
+        self.img = torch.empty(self.lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
+        self.nr_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.cap, self.binning = 0, None
+
+    def render(self, cam, bg, delta_scale, scaling_modifier=1.0, debug=False):
+        g, lib, s = self.g, self.lib, N.current_stream()
+        dev = g._xyz.device
+        P = g._xyz.shape[0]
+        W, H = int(cam.image_width), int(cam.image_height)
+        self._ensure(P, W, H, dev)
+        view, proj, campos, _ = cam.device_tensors(dev)
+        dn = g._deformation.deformation_net
+        field = dn.grid
+        xyz, scal, rot, opac = g._xyz.detach(), g._scaling.detach(), g._rotation.detach(), g._opacity.detach()
+        flow = g._scene_flow if g._scene_flow.is_contiguous() else g._scene_flow.contiguous()
+        order = field._processing_order(xyz)
+        planes = [p for lv in field.grids for p in lv]
+        mlp = dn._fused_params()
+        dkey = (tuple(p.data_ptr() for p in planes + mlp), tuple(field.aabb_host()))
+        if self._desc_key != dkey:
+            hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in field.grids], field.aabb, None,
+                                          aabb_host=field.aabb_host())
+            md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], None)
+            self._desc, self._desc_key = (hp, keep, md), dkey
+        hp, keep, md = self._desc
+        N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, float(cam.time),
+                                         None if order is None else order.data_ptr(), self.feat.data_ptr(), s), "hexplane_fwd")
+        N.check(lib.mom_deform_forward(C.byref(md), P, self.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                       flow.data_ptr(), float(delta_scale * cam.frame_num), self.pts.data_ptr(),
+                                       self.sc_d.data_ptr(), self.rot_d.data_ptr(), None, s), "deform_fwd")
+        N.check(lib.mom_activations_forward(P, self.sc_d.data_ptr(), self.rot_d.data_ptr(), opac.data_ptr(), self.sc.data_ptr(),
+                                            self.rot.data_ptr(), self.op.data_ptr(), s), "act_fwd")
+        a = N.MomRasterArgs()
+        a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H
+        a.background, a.means3D = bg.data_ptr(), self.pts.data_ptr()
+        a.shs, a.shs_rest = g._features_dc.data_ptr(), g._features_rest.data_ptr()
+        a.colors_precomp, a.opacities = None, self.op.data_ptr()
+        a.scales, a.rotations, a.cov3D_precomp = self.sc.data_ptr(), self.rot.data_ptr(), None
+        a.viewmatrix, a.projmatrix, a.campos = view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+        a.scale_modifier = float(scaling_modifier)
+        a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        a.prefiltered, a.debug = 0, int(bool(debug))
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)
+        # Binning capacity, as diff_gaussian_rasterization._C does it.  "exact" (the reference's own synchronisation point,
+        # rasterizer_impl.cu:282): wait for this frame's instance count.  "async": size from the previous frames' counts with
+        # headroom and do not wait; an overflow sets a flag that is read back asynchronously and raised at the next call.
+        prev_R = int(self.nr_host[0])
+        if int(self.status_host[0]) & 1:
+            self.status_host.zero_()
+            raise N.MomError(f"binning capacity {self.cap} overflowed in the previous async render (count {prev_R}); "
+                             "render that frame again or use set_sync_mode('exact')")
+        N.check(lib.mom_raster_forward_geometry(C.byref(a), self.geom.data_ptr(), self.img.data_ptr(), radii.data_ptr(),
+                                                self.nr_dev.data_ptr(), self.nr_host.data_ptr(), s), "raster_geometry")
+        if RC._state["mode"] == "exact" or self.cap == 0:
+            torch.cuda.current_stream().synchronize()
+            want = int(self.nr_host[0]) + (0 if RC._state["mode"] == "exact" else int(self.nr_host[0]) // 2 + 65536)
+        else:
+            want = max(self.cap, int(prev_R * 1.5) + 65536)
+        if self.binning is None or want > self.cap or want < self.cap // 4:
+            self.cap = want
+            self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, self.cap), dtype=torch.uint8, device=dev)
+        N.check(lib.mom_raster_forward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
+                                              self.img.data_ptr(), color.data_ptr(), depth.data_ptr(),
+                                              self.nr_dev[1:].data_ptr(), s), "raster_render")
+        self.status_host.copy_(self.nr_dev[1:], non_blocking=True)
+        return color, depth, radii

@@ -6,8 +6,22 @@ import math
 
 import torch
 
+from .. import ops
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from ..utils.sh_utils import eval_sh
+
+
+def _nograd_fast_path_applies(cam, pc, pipe, stage, override_color, cam_type):
+    """Forward-only launch sequence (fused_render.py): no gradients wanted, fine stage, the shipped deformation configuration,
+    SH colours and covariances computed by the rasterizer, an ordinary camera, everything on the GPU."""
+    if torch.is_grad_enabled() or stage != "fine" or override_color is not None or cam_type == "PanopticSports":
+        return False
+    if pipe.compute_cov3D_python or pipe.convert_SHs_python or not hasattr(cam, "device_tensors"):
+        return False
+    if not pc.get_xyz.is_cuda or pc.get_xyz.shape[0] == 0 or ops.BACKEND.name != "hip":
+        return False
+    dn = getattr(pc._deformation, "deformation_net", None)
+    return dn is not None and hasattr(dn, "_fusable") and dn._fusable() and pc._features_rest.shape[1] == 15
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None, stage="fine",
@@ -15,6 +29,15 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     """Background tensor (bg_color) must be on the GPU."""
     means3D = pc.get_xyz
     dev = means3D.device
+    if _nograd_fast_path_applies(viewpoint_camera, pc, pipe, stage, override_color, cam_type):
+        fr = getattr(pc, "_fused_render", None)
+        if fr is None:
+            from ..fused_render import FusedRender
+            fr = pc._fused_render = FusedRender(pc)
+        image, depth, radii = fr.render(viewpoint_camera, bg_color, 1 if delta_scale is None else delta_scale, scaling_modifier,
+                                        pipe.debug)
+        return {"render": image, "viewspace_points": torch.zeros_like(means3D), "visibility_filter": radii > 0, "radii": radii,
+                "depth": depth, "flow_loss": 0}
     # gradient holder for the 2D means (read back by the densification statistics, train_4DGS.py:227-229)
     screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev) + 0
     try:
