@@ -110,6 +110,8 @@ def _sig(lib):
     lib.mom_select_plan.argtypes = [i32, vp, vp, vp, vp, vp, vp]
     lib.mom_select_apply.argtypes = [i32, vp, C.POINTER(MomRowSelect), i32, vp]
     lib.mom_ssim_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.mom_ssim_forward_slab.argtypes = [i32, i32, i32, sz, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    lib.mom_ssim_backward_slab.argtypes = [i32, i32, i32, sz, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.mom_ssim_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.mom_activations_forward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_activations_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -143,6 +145,7 @@ EXPORTS = [
     "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward",
     "mom_ssim_forward", "mom_ssim_backward", "mom_raster_backward_render", "mom_raster_backward_geometry",
     "mom_densify_stats", "mom_select_scratch_bytes", "mom_select_plan", "mom_select_apply",
+    "mom_ssim_forward_slab", "mom_ssim_backward_slab",
 ]
 
 

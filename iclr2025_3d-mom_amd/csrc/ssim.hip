@@ -37,13 +37,16 @@ __device__ __forceinline__ float block_sum_256(float v, float* s_part)
 }
 
 __global__ void __launch_bounds__(256)
-ssim_fwd_kernel(Window win, int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
-                float* __restrict__ dm, double* __restrict__ sum)
+ssim_fwd_kernel(Window win, int H, int W, size_t chan_stride, int sum_row0, int sum_row1, int dm_row0, int dm_row1,
+                const float* __restrict__ img1, const float* __restrict__ img2, float* __restrict__ dm, double* __restrict__ sum)
 {
+    // The images are H rows of W pixels per channel, channels chan_stride elements apart (a row slab of a taller image has
+    // chan_stride > H W).  Map rows in [sum_row0, sum_row1) count toward the sum; derivative maps are written for rows in
+    // [dm_row0, dm_row1) and are zero elsewhere.
     __shared__ float s_x[kE][kES], s_y[kE][kES];
     __shared__ float s_h[5][kE][kT + 1];
     __shared__ float s_part[4];
-    const size_t HW = (size_t)H * W, base = (size_t)blockIdx.z * HW;
+    const size_t base = (size_t)blockIdx.z * chan_stride;
     const int x0 = blockIdx.x * kT - kR, y0 = blockIdx.y * kT - kR;
     for (int i = threadIdx.x; i < kE * kE; i += 256) {
         const int ly = i / kE, lx = i % kE, gx = x0 + lx, gy = y0 + ly;
@@ -87,14 +90,15 @@ ssim_fwd_kernel(Window win, int H, int W, const float* __restrict__ img1, const 
     const float inv_AB = 1.f / (A * B);
     const float map = Cn * D * inv_AB;
     if (in && dm) {
-        const size_t p = base + (size_t)gy * W + gx, n = (size_t)gridDim.z * HW;
-        dm[p] = 2.f * mu2 * (D - Cn) * inv_AB - 2.f * mu1 * map * (B - A) * inv_AB;
-        dm[n + p] = -map / B;
-        dm[2 * n + p] = 2.f * Cn * inv_AB;
+        const size_t p = base + (size_t)gy * W + gx, n = (size_t)gridDim.z * chan_stride;
+        const bool w = gy >= dm_row0 && gy < dm_row1;
+        dm[p] = w ? 2.f * mu2 * (D - Cn) * inv_AB - 2.f * mu1 * map * (B - A) * inv_AB : 0.f;
+        dm[n + p] = w ? -map / B : 0.f;
+        dm[2 * n + p] = w ? 2.f * Cn * inv_AB : 0.f;
     }
     // 6120 blocks at 960x540 adding into ONE double serialise in the L2 (it cost more than the rest of the kernel): spread
     // the partial sums over the slots sum[1..kSsimSlots-1]; ssim_sum_kernel folds them into sum[0]
-    const float tot = block_sum_256(in ? map : 0.f, s_part);
+    const float tot = block_sum_256((in && gy >= sum_row0 && gy < sum_row1) ? map : 0.f, s_part);
     if (threadIdx.x == 0) {
         const unsigned b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         atomicAdd(&sum[1 + b % (kSsimSlots - 1)], (double)tot);
@@ -110,12 +114,12 @@ __global__ void __launch_bounds__(64) ssim_sum_kernel(double* __restrict__ sum)
 }
 
 __global__ void __launch_bounds__(256)
-ssim_bwd_kernel(Window win, int H, int W, const float* __restrict__ img1, const float* __restrict__ img2,
+ssim_bwd_kernel(Window win, int H, int W, size_t chan_stride, const float* __restrict__ img1, const float* __restrict__ img2,
                 const float* __restrict__ dm, float scale, const float* __restrict__ scale_dev, float* __restrict__ dimg1)
 {
     __shared__ float s_d[3][kE][kES];
     __shared__ float s_h[3][kE][kT + 1];
-    const size_t HW = (size_t)H * W, base = (size_t)blockIdx.z * HW, n = (size_t)gridDim.z * HW;
+    const size_t base = (size_t)blockIdx.z * chan_stride, n = (size_t)gridDim.z * chan_stride;
     const int x0 = blockIdx.x * kT - kR, y0 = blockIdx.y * kT - kR;
     for (int i = threadIdx.x; i < kE * kE; i += 256) {
         const int ly = i / kE, lx = i % kE, gx = x0 + lx, gy = y0 + ly;
@@ -156,32 +160,48 @@ ssim_bwd_kernel(Window win, int H, int W, const float* __restrict__ img1, const 
 
 }  // namespace
 
-extern "C" int mom_ssim_forward(int C, int H, int W, const float* window11, const float* img1, const float* img2, float* dm,
-                                double* sum, mom_stream_t stream)
+extern "C" int mom_ssim_forward_slab(int C, int H, int W, size_t chan_stride, int sum_row0, int sum_row1, int dm_row0, int dm_row1,
+                                     const float* window11, const float* img1, const float* img2, float* dm, double* sum,
+                                     mom_stream_t stream)
 {
-    if (C < 0 || H < 0 || W < 0 || !window11 || !sum) return MOM_EINVAL;
+    if (C < 0 || H < 0 || W < 0 || !window11 || !sum || chan_stride < (size_t)H * (size_t)W) return MOM_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (hipMemsetAsync(sum, 0, sizeof(double) * kSsimSlots, s) != hipSuccess) return MOM_ELAUNCH;
     if (C == 0 || H == 0 || W == 0) return MOM_OK;
     if (!img1 || !img2) return MOM_EINVAL;
     Window win;
     for (int k = 0; k <= 2 * kR; k++) win.w[k] = window11[k];
-    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + kT - 1) / kT, (H + kT - 1) / kT, C), dim3(256), 0, s, win, H, W, img1, img2, dm,
-                       sum);
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3((W + kT - 1) / kT, (H + kT - 1) / kT, C), dim3(256), 0, s, win, H, W, chan_stride,
+                       sum_row0, sum_row1, dm_row0, dm_row1, img1, img2, dm, sum);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     hipLaunchKernelGGL(ssim_sum_kernel, dim3(1), dim3(64), 0, s, sum);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+extern "C" int mom_ssim_forward(int C, int H, int W, const float* window11, const float* img1, const float* img2, float* dm,
+                                double* sum, mom_stream_t stream)
+{
+    return mom_ssim_forward_slab(C, H, W, (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0), 0, H, 0, H, window11, img1, img2, dm,
+                                 sum, stream);
+}
+
+extern "C" int mom_ssim_backward_slab(int C, int H, int W, size_t chan_stride, const float* window11, const float* img1,
+                                      const float* img2, const float* dm, float scale, const float* scale_dev, float* dimg1,
+                                      mom_stream_t stream)
+{
+    if (C < 0 || H < 0 || W < 0 || !window11 || chan_stride < (size_t)H * (size_t)W) return MOM_EINVAL;
+    if (C == 0 || H == 0 || W == 0) return MOM_OK;
+    if (!img1 || !img2 || !dm || !dimg1) return MOM_EINVAL;
+    Window win;
+    for (int k = 0; k <= 2 * kR; k++) win.w[k] = window11[k];
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + kT - 1) / kT, (H + kT - 1) / kT, C), dim3(256), 0, (hipStream_t)stream, win, H, W,
+                       chan_stride, img1, img2, dm, scale, scale_dev, dimg1);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
 extern "C" int mom_ssim_backward(int C, int H, int W, const float* window11, const float* img1, const float* img2, const float* dm,
                                  float scale, const float* scale_dev, float* dimg1, mom_stream_t stream)
 {
-    if (C < 0 || H < 0 || W < 0 || !window11) return MOM_EINVAL;
-    if (C == 0 || H == 0 || W == 0) return MOM_OK;
-    if (!img1 || !img2 || !dm || !dimg1) return MOM_EINVAL;
-    Window win;
-    for (int k = 0; k <= 2 * kR; k++) win.w[k] = window11[k];
-    hipLaunchKernelGGL(ssim_bwd_kernel, dim3((W + kT - 1) / kT, (H + kT - 1) / kT, C), dim3(256), 0, (hipStream_t)stream, win, H, W,
-                       img1, img2, dm, scale, scale_dev, dimg1);
-    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+    return mom_ssim_backward_slab(C, H, W, (size_t)(H > 0 ? H : 0) * (size_t)(W > 0 ? W : 0), window11, img1, img2, dm, scale,
+                                  scale_dev, dimg1, stream);
 }

@@ -147,14 +147,17 @@ class FusedStep:
         a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         a.prefiltered, a.debug = 0, 0
         dc = self.dist
-        rows = None
+        rows = fwd_rows = None
         if dc is not None and dc.mode == "tile-row":
-            # every rank renders this same camera, restricted to its rows of 16-pixel tiles
-            if float(self.opt.lambda_dssim) != 0:
-                raise N.MomError("tile-row sharding does not carry the SSIM term yet (its 11x11 window needs a 5-pixel halo "
-                                 "across row boundaries): use lambda_dssim 0 or the camera-batch shard")
-            rows = dc.rows((H + 15) // 16)
-            a.tile_row0, a.tile_row1 = rows
+            # every rank renders this same camera, restricted to its rows of 16-pixel tiles.  With the SSIM term the forward
+            # also renders one tile row of halo on each side: the 11x11 window makes an owned pixel depend on map pixels up to
+            # 5 rows outside, and those on image pixels up to 10 rows outside -- all inside the 16-row halo, so nothing is
+            # exchanged (the neighbour composites the same rows to the same bits).  The backward covers the own rows only.
+            gy = (H + 15) // 16
+            rows = dc.rows(gy)
+            halo = 1 if (float(self.opt.lambda_dssim) != 0 and rows[1] > rows[0]) else 0
+            fwd_rows = (max(rows[0] - halo, 0), min(rows[1] + halo, gy))
+            a.tile_row0, a.tile_row1 = fwd_rows
         # the previous iteration's instance count / overflow flag are long complete: read them without blocking
         prev_R = int(self.nr_host[0])
         if int(self.status_host[0]) & 1:
@@ -185,10 +188,26 @@ class FusedStep:
             if self.ssim_dm is None:         # derivative maps and the map sum (mom_ssim_forward)
                 self.ssim_dm = torch.empty((3, 3, H, W), dtype=torch.float32, device=dev)
                 self.ssim_sum = torch.empty(N.SSIM_SUM_SLOTS, dtype=torch.float64, device=dev)   # [0] = the sum
-            N.check(lib.mom_ssim_forward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
-                                         self.ssim_sum.data_ptr(), s), "ssim_fwd")
-            N.check(lib.mom_ssim_backward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
-                                          -lam / n, None, self.dimg.data_ptr(), s), "ssim_bwd")
+            if rows is None:
+                N.check(lib.mom_ssim_forward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
+                                             self.ssim_sum.data_ptr(), s), "ssim_fwd")
+                N.check(lib.mom_ssim_backward(3, H, W, win, self.color.data_ptr(), gt.data_ptr(), self.ssim_dm.data_ptr(),
+                                              -lam / n, None, self.dimg.data_ptr(), s), "ssim_bwd")
+            elif rows[1] > rows[0]:
+                # the slab this rank rendered (own rows + halo), as a pitched view of the full buffers: map rows of the own
+                # tile rows count toward the sum; derivative maps are kept 5 rows beyond them (up to the image's own edges,
+                # where zero padding is the reference's behaviour) and are zero elsewhere
+                ys0, ys1 = fwd_rows[0] * 16, min(H, fwd_rows[1] * 16)
+                y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
+                off = ys0 * W * 4
+                N.check(lib.mom_ssim_forward_slab(3, ys1 - ys0, W, H * W, y0 - ys0, y1 - ys0, max(0, y0 - 5) - ys0,
+                                                  min(H, y1 + 5) - ys0, win, self.color.data_ptr() + off, gt.data_ptr() + off,
+                                                  self.ssim_dm.data_ptr() + off, self.ssim_sum.data_ptr(), s), "ssim_fwd_slab")
+                N.check(lib.mom_ssim_backward_slab(3, ys1 - ys0, W, H * W, win, self.color.data_ptr() + off, gt.data_ptr() + off,
+                                                   self.ssim_dm.data_ptr() + off, -lam / n, None, self.dimg.data_ptr() + off, s),
+                        "ssim_bwd_slab")
+            else:
+                self.ssim_sum.zero_()
         if dc is not None and dc.mode == "camera":
             self.dimg.mul_(inv_world)
         # ---- rasterizer backward
@@ -204,6 +223,7 @@ class FusedStep:
             # tile-row shard: the compositing backward covers this rank's rows only (dimg outside them is never read); the
             # per-Gaussian record it leaves is summed over the ranks, after which the projection backward -- linear in that
             # record -- and everything downstream give the same gradients on every rank, with nothing left to exchange
+            a.tile_row0, a.tile_row1 = rows          # own rows only (the forward may have covered a halo)
             N.check(lib.mom_raster_backward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                                    self.img.data_ptr(), self.dimg.data_ptr(), None, s), "raster_bwd_render")
             dc.start(self._gacc_view(P, W, H), "sum")
@@ -275,10 +295,12 @@ class FusedStep:
                 for c in range(3):
                     N.check(lib.mom_l1_loss((y1 - y0) * W, self.color[c, y0:y1].data_ptr(), gt[c, y0:y1].data_ptr(), None,
                                             self._slab_sums[c].data_ptr(), s), "l1_slab")
-            tot = self._slab_sums.sum(0)
-            dc.start(tot, "sum")
+            tot = torch.cat((self._slab_sums.sum(0), self.ssim_sum[:1].float() if lam != 0 else self._slab_sums.new_zeros(1)))
+            dc.start(tot, "sum")                    # [sum |d|, sum d^2, sum of the SSIM map], over the ranks' own rows
             dc.finish()
-            self.sums.copy_(tot)
+            self.sums.copy_(tot[:2])
+            if lam != 0:
+                self.ssim_sum[0] = tot[2].double()
             l1 = tot[0] / n
         loss = l1 if reg is None else l1 + reg[0]
         if lam != 0:

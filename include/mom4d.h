@@ -267,6 +267,16 @@ int mom_ssim_forward(int C, int H, int W, const float* window11, const float* im
                      double* sum, mom_stream_t stream);
 int mom_ssim_backward(int C, int H, int W, const float* window11, const float* img1, const float* img2, const float* dm,
                       float scale, const float* scale_dev, float* dimg1, mom_stream_t stream);
+/* The same on a ROW SLAB of taller images (tile-row shard: a rank holds its own rows plus a halo): the pointers address the
+ * slab's first row, H is the slab's height, channels (and the three derivative maps' channels) are chan_stride elements
+ * apart (>= H*W; the full image's H*W).  The window is zero-padded at the slab's edges like at an image's, so only map rows
+ * at least 5 pixels inside the slab are those of the full image: map rows in [sum_row0, sum_row1) (slab coordinates) are
+ * summed, derivative maps are written for rows in [dm_row0, dm_row1) and zeroed elsewhere. */
+int mom_ssim_forward_slab(int C, int H, int W, size_t chan_stride, int sum_row0, int sum_row1, int dm_row0, int dm_row1,
+                          const float* window11, const float* img1, const float* img2, float* dm, double* sum,
+                          mom_stream_t stream);
+int mom_ssim_backward_slab(int C, int H, int W, size_t chan_stride, const float* window11, const float* img1, const float* img2,
+                           const float* dm, float scale, const float* scale_dev, float* dimg1, mom_stream_t stream);
 
 /* ---- HexPlane regularisers (scene/gaussian_model.py:730-769, scene/regulation.py:22-28) ----
  * value = sum over planes of w_smooth * mean((p[h+2]-2p[h+1]+p[h])^2) + w_l1 * mean|1-p|
