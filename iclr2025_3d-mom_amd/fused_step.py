@@ -223,6 +223,18 @@ class FusedStep:
             # tile-row shard: the compositing backward covers this rank's rows only (dimg outside them is never read); the
             # per-Gaussian record it leaves is summed over the ranks, after which the projection backward -- linear in that
             # record -- and everything downstream give the same gradients on every rank, with nothing left to exchange
+            if hasattr(dc, "rebalance_due") and dc.rebalance_due():
+                # instance counts per tile row of the rows this rank owns -> agreed weights for the next splits; after a
+                # re-split the local instance count can jump, so the next step sizes its binning buffer exactly again
+                gx_ = (W + 15) // 16
+                lay = N.MomRasterLayout()
+                lib.mom_raster_layout(P, W, H, 0, C.byref(lay))
+                base = self.img[(-self.img.data_ptr()) % 256:]
+                per_row = base[lay.img_tile_counts:lay.img_tile_counts + gx_ * gy * 4].view(torch.int32).view(gy, gx_).sum(1).float()
+                own = torch.zeros_like(per_row)
+                own[rows[0]:rows[1]] = per_row[rows[0]:rows[1]]
+                if dc.rebalance_rows(own):
+                    self.cap = 0
             a.tile_row0, a.tile_row1 = rows          # own rows only (the forward may have covered a halo)
             N.check(lib.mom_raster_backward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                                    self.img.data_ptr(), self.dimg.data_ptr(), None, s), "raster_bwd_render")

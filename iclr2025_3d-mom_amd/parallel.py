@@ -70,10 +70,32 @@ class DistContext:
         self.rank, self.world, self.seed, self.mode = rank, world, seed, mode
         self._flat = None
         self._pending = []
+        self.row_weights = None          # per-tile-row work estimate agreed by all ranks (rebalance_rows)
+        self.steps_since_rebalance = 0
+
+    REBALANCE_EVERY = 16
 
     def rows(self, n_rows):
-        """This rank's tile rows of an image with n_rows rows of tiles (equal split by row count)."""
-        return split_rows(n_rows, self.world)[self.rank]
+        """This rank's tile rows of an image with n_rows rows of tiles: split by the agreed per-row weights when there are
+        some for this image height, else by row count."""
+        w = self.row_weights if (self.row_weights is not None and len(self.row_weights) == n_rows) else None
+        return split_rows(n_rows, self.world, w)[self.rank]
+
+    def rebalance_due(self):
+        self.steps_since_rebalance += 1
+        return self.steps_since_rebalance >= self.REBALANCE_EVERY
+
+    def rebalance_rows(self, own_row_counts):
+        """own_row_counts[r] = instances this rank binned in tile row r, zero for the rows it does not own (float tensor, one
+        entry per tile row).  Sums them over the ranks and adopts the result as the weights of the next splits.  Every rank
+        gets the same vector, so every rank derives the same split.  Returns True when this rank's rows changed."""
+        n_rows = own_row_counts.shape[0]
+        before = self.rows(n_rows)
+        total = own_row_counts.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        self.row_weights = [float(x) + 1.0 for x in total.tolist()]     # +1: an empty row still costs a launch slot
+        self.steps_since_rebalance = 0
+        return self.rows(n_rows) != before
 
     _OPS = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}
 

@@ -130,10 +130,12 @@ class _RowRank:
     start(); pass 2 writes the sum over the ranks back into the buffer, which is what the all-reduce leaves there."""
     mode = "tile-row"
 
-    def __init__(self, rank, world, feed=None):
-        self.rank, self.world, self.feed, self.captured = rank, world, feed, []
+    def __init__(self, rank, world, feed=None, split=None):
+        self.rank, self.world, self.feed, self.captured, self.split = rank, world, feed, [], split
 
     def rows(self, n_rows):
+        if self.split is not None:                           # an uneven split, as a rebalance would produce
+            return self.split[self.rank]
         split = importlib.import_module("iclr2025_3d-mom_amd.parallel").split_rows
         return split(n_rows, self.world)[self.rank]
 
@@ -147,12 +149,14 @@ class _RowRank:
         pass
 
 
-@pytest.mark.parametrize("world,lambda_dssim", [(2, 0.0), (3, 0.0), (2, 0.2), (3, 0.2), (6, 0.2)])
-def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world, lambda_dssim):
+@pytest.mark.parametrize("world,lambda_dssim,split", [(2, 0.0, None), (3, 0.0, None), (2, 0.2, None), (3, 0.2, None), (6, 0.2, None),
+                                                      (3, 0.2, [(0, 1), (1, 5), (5, 6)]), (3, 0.0, [(0, 4), (4, 6), (6, 6)])])
+def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world, lambda_dssim, split):
     """BASELINE config 4 on one GPU: `world` virtual ranks render the same camera, each its own tile rows, exchange the
     per-Gaussian record of the compositing backward (and the loss sums), and must all end with the unsharded step's
     gradients, statistics and loss.  With the SSIM term every rank also renders a one-tile-row halo and evaluates SSIM on
-    that slab (no pixels are exchanged); world 6 gives every rank a single tile row, so every boundary has a halo."""
+    that slab (no pixels are exchanged); world 6 gives every rank a single tile row, so every boundary has a halo.  The
+    uneven splits are what a rebalance produces, one of them leaving the last rank without rows."""
     import bench
     cfg = dict(P=6000, F=4, W=160, H=96, time_res=10, name="tiny")            # 6 tile rows
     scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=True, lambda_dssim=lambda_dssim)
@@ -166,7 +170,7 @@ def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world, l
                 "late": fs._dg_flat.clone(), "mse": float(fs.last["mse_sum"])}
 
     want = run(None)
-    first = [_RowRank(r, world) for r in range(world)]
+    first = [_RowRank(r, world, split=split) for r in range(world)]
     for d in first:
         run(d)
         assert len(d.captured) == 2                                   # the record, then the L1 slab sums
@@ -174,7 +178,7 @@ def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world, l
     rows = [d.rows(6) for d in first]
     assert rows[0][0] == 0 and rows[-1][1] == 6 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
     for r in range(world):
-        got = run(_RowRank(r, world, feed))
+        got = run(_RowRank(r, world, feed, split=split))
         assert abs(got["loss"] - want["loss"]) <= 1e-6 * max(1.0, abs(want["loss"])), (got["loss"], want["loss"])
         assert abs(got["mse"] - want["mse"]) <= 1e-5 * abs(want["mse"])
         torch.testing.assert_close(got["radii"], want["radii"], rtol=0, atol=0)

@@ -138,3 +138,52 @@ def test_split_rows_partitions():
             split(*bad)
     with pytest.raises(ValueError):
         split(3, 2, [1, 2])
+
+
+def _run_rebalance(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    dc = P.DistContext(rank, world, mode="tile-row")
+    n_rows = 9
+    before = dc.rows(n_rows)
+    counts = torch.tensor([5000., 4000., 3000., 200., 100., 50., 20., 10., 5.])      # the work sits in the top rows
+    own = torch.zeros(n_rows)
+    own[before[0]:before[1]] = counts[before[0]:before[1]]                             # a rank only knows its own rows
+    due = [dc.rebalance_due() for _ in range(P.DistContext.REBALANCE_EVERY)]
+    changed = dc.rebalance_rows(own)
+    after = dc.rows(n_rows)
+    dist.barrier()
+    dist.destroy_process_group()
+    np.savez(out, before=np.array(before), after=np.array(after), weights=np.array(dc.row_weights), changed=np.array(changed),
+             due=np.array(due), other=np.array(dc.rows(7)))
+
+
+@pytest.mark.timeout(300)
+def test_tile_row_rebalance_agrees_across_ranks(tmp_path):
+    """DistContext.rebalance_rows: every rank contributes the instance counts of its own tile rows, all ranks end with the same
+    weights and therefore the same split, which moves rows towards the ranks with less work; an image with another number of
+    tile rows keeps the plain split."""
+    world, port = 3, 32500 + os.getpid() % 2000
+    outs = [str(tmp_path / f"b{r}.npz") for r in range(world)]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run_rebalance, args=(r, world, port, outs[r])) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=250)
+        assert p.exitcode == 0
+    res = [np.load(o) for o in outs]
+    for r in res[1:]:
+        np.testing.assert_array_equal(r["weights"], res[0]["weights"])
+    np.testing.assert_allclose(res[0]["weights"], np.array([5000., 4000., 3000., 200., 100., 50., 20., 10., 5.]) + 1.0)
+    assert [tuple(r["before"]) for r in res] == [(0, 3), (3, 6), (6, 9)]
+    after = [tuple(r["after"]) for r in res]
+    assert after[0][0] == 0 and after[-1][1] == 9 and all(a[1] == b[0] for a, b in zip(after, after[1:]))
+    assert after == [(0, 1), (1, 2), (2, 9)], after                       # 5001 | 4001 | the rest
+    assert all(bool(r["changed"]) for r in res)
+    for k, r in enumerate(res):
+        assert list(r["due"]) == [False] * 15 + [True]
+        assert tuple(r["other"]) == ((0, 2), (2, 4), (4, 7))[k]          # 7 rows: no weights for that height, plain split
