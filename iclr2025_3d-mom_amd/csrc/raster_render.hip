@@ -150,22 +150,27 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
     }
     return m;
 }
-// Compacts, for wave `wv`, the indices j < 256 whose mask has bit wv: afterwards lane k of list[c] holds entry 64 c + k of the
-// wave's list (in increasing j, so the compositing order is kept); returns the list length.
-__device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint8_t* s_list, int wv, int lane, int (&list)[4])
+// Splats staged per round (a multiple of 256; each thread stages kRound / 256 of them).
+#ifndef MOM_ROUND
+#define MOM_ROUND 256
+#endif
+constexpr int kRound = MOM_ROUND, kRoundChunks = kRound / 64;
+// Compacts, for wave `wv`, the indices j < kRound whose mask has bit wv: afterwards lane k of list[c] holds entry 64 c + k of
+// the wave's list (in increasing j, so the compositing order is kept); returns the list length.
+__device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* s_list, int wv, int lane, int (&list)[kRoundChunks])
 {
     int n = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < kRoundChunks; c++) {
         const int j = 64 * c + lane;
         const bool bit = (s_mask[j] >> wv) & 1;
         const uint64_t bal = __ballot(bit);
         const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (bit) s_list[n + rank] = (uint8_t)j;
+        if (bit) s_list[n + rank] = (uint16_t)j;
         n += __popcll(bal);
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++) list[c] = s_list[64 * c + lane];
+    for (int c = 0; c < kRoundChunks; c++) list[c] = s_list[64 * c + lane];
     return n;
 }
 
@@ -175,9 +180,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
                   uint32_t capacity)
 {
-    __shared__ float4 s_rec[256 * 3];
-    __shared__ uint8_t s_mask[256];
-    __shared__ uint8_t s_lists[4][256];
+    __shared__ float4 s_rec[kRound * 3];
+    __shared__ uint8_t s_mask[kRound];
+    __shared__ uint16_t s_lists[4][kRound];
     const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
     const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
@@ -192,32 +197,35 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     if (range.y > capacity) range.y = capacity;
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
-    const int rounds = (toDo + 255) / 256;
+    const int rounds = (toDo + kRound - 1) / kRound;
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
 
-    for (int i = 0; i < rounds; i++, toDo -= 256) {
+    for (int i = 0; i < rounds; i++, toDo -= kRound) {
         if (__syncthreads_count(done) == 256) break;
-        const int progress = i * 256 + threadIdx.x;
-        uint32_t reach = 0;
-        if (range.x + progress < range.y) {
-            const size_t id = point_list[range.x + progress];
-            float4 q0 = rec[3 * id + 0];
-            const float4 q1 = rec[3 * id + 1];
-            q0.w = power_bound(q1.w);
-            reach = strip_reach_mask(q0, q1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
-            s_rec[threadIdx.x * 3 + 0] = q0;
-            s_rec[threadIdx.x * 3 + 1] = q1;
-            s_rec[threadIdx.x * 3 + 2] = rec[3 * id + 2];
+#pragma unroll
+        for (int sl = 0; sl < kRound / 256; sl++) {
+            const int slot = threadIdx.x + 256 * sl, progress = i * kRound + slot;
+            uint32_t reach = 0;
+            if (range.x + progress < range.y) {
+                const size_t id = point_list[range.x + progress];
+                float4 q0 = rec[3 * id + 0];
+                const float4 q1 = rec[3 * id + 1];
+                q0.w = power_bound(q1.w);
+                reach = strip_reach_mask(q0, q1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
+                s_rec[slot * 3 + 0] = q0;
+                s_rec[slot * 3 + 1] = q1;
+                s_rec[slot * 3 + 2] = rec[3 * id + 2];
+            }
+            s_mask[slot] = (uint8_t)reach;                  // slots past the end of the list: unreachable
         }
-        s_mask[threadIdx.x] = (uint8_t)reach;               // slots past the end of the list: unreachable
         __syncthreads();
-        int list[4];
+        int list[kRoundChunks];
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < kRoundChunks; c++) {
             const int nk = min(64, n_w - 64 * c);
             for (int k = 0; k < nk; k++) {
                 if (__all(done)) break;
@@ -243,7 +251,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                     C2 += r2.z * w;
                     D += r0.z * w;
                     T = test_T;
-                    last_contributor = (uint32_t)(i * 256 + j + 1);     // position in the tile's list, counted from 1
+                    last_contributor = (uint32_t)(i * kRound + j + 1);  // position in the tile's list, counted from 1
                 }
             }
         }
@@ -266,10 +274,10 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                   const float* __restrict__ dL_dpixel_depths, float* __restrict__ gacc, uint32_t capacity)
 {
-    __shared__ float4 s_rec[256 * 3];
-    __shared__ uint32_t s_id[256];
-    __shared__ uint8_t s_mask[256];
-    __shared__ uint8_t s_lists[4][256];
+    __shared__ float4 s_rec[kRound * 3];
+    __shared__ uint32_t s_id[kRound];
+    __shared__ uint8_t s_mask[kRound];
+    __shared__ uint16_t s_lists[4][kRound];
     const int tile = t0 + remap_tile(blockIdx.x, nt);      // t0: first tile of this launch's rows (tile-row shard)
     const int tx = tile % gx, ty = tile / gx;
     const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
@@ -283,7 +291,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     if (range.y > capacity) range.y = capacity;
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
-    const int rounds = (toDo + 255) / 256;
+    const int rounds = (toDo + kRound - 1) / kRound;
 
     const int pix = inside ? py * W + px : 0;
     const size_t HW = (size_t)H * W;
@@ -309,28 +317,31 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);
 
-    for (int i = 0; i < rounds; i++, toDo -= 256) {
+    for (int i = 0; i < rounds; i++, toDo -= kRound) {
         __syncthreads();
-        const int progress = i * 256 + threadIdx.x;
-        uint32_t reach = 0;
-        if (range.x + progress < range.y) {
-            const uint32_t id = point_list[range.y - progress - 1];
-            s_id[threadIdx.x] = id;
-            float4 q0 = rec[3 * (size_t)id + 0];
-            const float4 q1 = rec[3 * (size_t)id + 1];
-            q0.w = power_bound(q1.w);
-            reach = strip_reach_mask(q0, q1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
-            s_rec[threadIdx.x * 3 + 0] = q0;
-            s_rec[threadIdx.x * 3 + 1] = q1;
-            s_rec[threadIdx.x * 3 + 2] = rec[3 * (size_t)id + 2];
+#pragma unroll
+        for (int sl = 0; sl < kRound / 256; sl++) {
+            const int slot = threadIdx.x + 256 * sl, progress = i * kRound + slot;
+            uint32_t reach = 0;
+            if (range.x + progress < range.y) {
+                const uint32_t id = point_list[range.y - progress - 1];
+                s_id[slot] = id;
+                float4 q0 = rec[3 * (size_t)id + 0];
+                const float4 q1 = rec[3 * (size_t)id + 1];
+                q0.w = power_bound(q1.w);
+                reach = strip_reach_mask(q0, q1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
+                s_rec[slot * 3 + 0] = q0;
+                s_rec[slot * 3 + 1] = q1;
+                s_rec[slot * 3 + 2] = rec[3 * (size_t)id + 2];
+            }
+            s_mask[slot] = (uint8_t)reach;                  // slots past the end of the list: unreachable
         }
-        s_mask[threadIdx.x] = (uint8_t)reach;               // slots past the end of the list: unreachable
         __syncthreads();
         // this wave's splats of the round, still back to front (render_fwd explains the lists)
-        int list[4];
+        int list[kRoundChunks];
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < kRoundChunks; c++) {
           const int nk = min(64, n_w - 64 * c);
           for (int k = 0; k < nk; k++) {
             const int j = __builtin_amdgcn_readlane(list[c], k);
