@@ -6,8 +6,11 @@ LR update, render (HexPlane + MLP deformation -> rasterizer), L1 + plane regular
 statistics, Adam on every Gaussian parameter and the deformation field.
 
     python bench.py --gpus N --steps K --warmup W
-prints ONE JSON line (rank 0).  N > 1 (torchrun): camera-batch shard -- every rank renders a different camera
-of the same step and the parameter gradients are all-reduced over RCCL (weak scaling: per-GPU work fixed).
+prints ONE JSON line (rank 0).  N > 1: one process per GPU -- started by `python -m torch.distributed.run`, or, when no
+launcher set RANK / WORLD_SIZE, by this script itself (launch.py: the parent spawns N ranks before anything touches the GPU
+and relays rank 0's line).  --shard camera (default): every rank renders a different camera of the same step and the parameter
+gradients are all-reduced over RCCL (weak scaling: per-GPU work fixed); --shard tile-row: one camera split by tile rows
+(strong scaling).
 """
 import argparse
 import importlib
@@ -68,7 +71,27 @@ def cpu_baseline(cfg, budget_s=15.0):
                 break
         dt = (time.time() - t0) / n
     return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fine-stage steps of the same scene after 1 warm-up ({dt:.2f} s/step)"}
+            "sample": f"{n} fine-stage steps of the same scene after 1 warm-up ({dt:.2f} s/step)",
+            "host": host_description(),
+            "note": "threads = the fastest setting measured on this host class, not its core count: the restatement's "
+                    "backward uses float `omp atomic` and torch's small CPU ops stop scaling (8: 2.4, 16: 1.4, 32: 1.6, 64: 2.5, "
+                    "128: 4.5 s per step on 2 x EPYC 9575F)"}
+
+
+def host_description():
+    """lscpu model / sockets / cores of the host the CPU baseline ran on (BASELINE.md protocol: stated with every result)."""
+    import subprocess
+    d = {"logical_cpus": os.cpu_count()}
+    try:
+        txt = subprocess.run(["lscpu"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10).stdout
+        for line in txt.splitlines():
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core"):
+                d[k] = v.strip()
+    except Exception:
+        pass
+    return d
 
 
 def measured_traffic(kernel, cfg):
@@ -89,6 +112,13 @@ def measured_traffic(kernel, cfg):
     return None
 
 
+def step_bytes(P, R, npix, lambda_dssim=0.0, deform_floats=2_904_970):
+    """algorithmic bytes of one fine-stage step, fp32: B = P*2751 + R*172 + N_pix*84 (+240 with SSIM)
+    + B_def, B_def = live deformation floats * 28 (Adam) + 2 * 11.55 MB (plane-gradient RMW) + 11.55 MB (regulariser read)."""
+    planes = 2_887_680 * 4
+    return P * 2751 + R * 172 + npix * (84 + (240 if lambda_dssim else 0)) + deform_floats * 28 + 3 * planes
+
+
 def metric_name():
     """BASELINE.json's metric string, verbatim (it travels with the repo); the literal is the same text."""
     try:
@@ -96,17 +126,6 @@ def metric_name():
             return json.load(fh)["metric"]
     except (OSError, KeyError, ValueError):
         return "4DGS train-steps/sec @200k Gaussians, 960\u00d7540, 60 frames; render FPS"
-
-
-def timed_steps(one, first, steps):
-    """`steps` training steps between two synchronisations -> seconds."""
-    import torch
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = one(first + i)
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0, loss
 
 
 def render_fps(scene, g, pp, background, delta_scale, passes=2):
@@ -135,7 +154,7 @@ def render_fps(scene, g, pp, background, delta_scale, passes=2):
             "mode": "no-grad render(), deformation on, images kept on the device (no PNG writer)"}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -153,21 +172,36 @@ def main():
     ap.add_argument("--lambda-dssim", type=float, default=0.0,
                     help="weight of the SSIM loss term in the headline value (0 = the reference's default)")
     ap.add_argument("--no-extra", action="store_true",
-                    help="skip the two extra single-GPU legs (training with lambda_dssim 0.2, render FPS)")
+                    help="skip the extra single-GPU legs (steady state, training with lambda_dssim 0.2, render FPS)")
+    ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state leg (SURVEY 8d: >= 200)")
+    ap.add_argument("--steady-warmup", type=int, default=50, help="warm-up of the steady-state leg (SURVEY 8d: 50)")
     ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
                     help="fused: explicit launch sequence (fused_step.py); autograd: render() + loss.backward()")
-    a = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def main():
+    a = parse_args()
+    # N ranks wanted and no launcher started us: become the launcher -- before anything touches the GPU (launch.py).
+    # MOM_BENCH_SPAWN=1 forces that route with one rank too (the only way to exercise it on a one-GPU box).
+    launch = importlib.import_module("iclr2025_3d-mom_amd.launch")
+    force_spawn = os.environ.get("MOM_BENCH_SPAWN") == "1" and not launch.launched_by_a_launcher()
+    if force_spawn:
+        os.environ["MOM_FORCE_DIST"] = "1"
+    launch.main_or_spawn(a.gpus, os.path.abspath(__file__), sys.argv[1:], force=force_spawn)
     import torch
     import torch.distributed as dist
     cfg = CONFIGS[a.config]
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmom4d has no CPU path)")
     torch.cuda.set_device(local)
     # MOM_FORCE_DIST=1: run the multi-GPU code path (RCCL process group, DistContext, the step's all-reduces) even with one
-    # rank -- the only way to exercise it on a box with a single GPU.  Launch under torch.distributed.run as usual.
+    # rank -- the only way to exercise it on a box with a single GPU.
     force_dist = world == 1 and os.environ.get("MOM_FORCE_DIST") == "1" and "RANK" in os.environ
     if world > 1 or force_dist:
         dist.init_process_group("nccl")
@@ -178,66 +212,125 @@ def main():
     for c in cams:                       # inputs resident in HBM before the timed region: the cameras' matrices and
         c.device_tensors(dev)            # ground-truth images are uploaded here, not on first use inside it
     par = None
+    ranks_seen = 1
     if world > 1 or force_dist:
         par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
         par.attach(trainer, rank, world, mode=a.shard)
+        one_t = torch.ones(1, device=dev)
+        dist.all_reduce(one_t)
+        ranks_seen = int(one_t[0])
     it0 = 5000  # mid-training iteration numbers: densification statistics on, no densify/reset in the window
+    npix = cfg["W"] * cfg["H"]
+
+    def cam_of(i):
+        # every rank takes a different camera of the cycle (camera-batch shard); N=1 walks all F+5 cameras
+        return cams[(i * world + rank) % len(cams)] if a.shard == "camera" else cams[i % len(cams)]
 
     def one(i):
-        # every rank takes a different camera of the cycle (camera-batch shard); N=1 walks all F+5 cameras
-        cam = cams[(i * world + rank) % len(cams)] if a.shard == "camera" else cams[i % len(cams)]
-        return trainer.step(it0 + 1 + (i if a.with_densify else i % 90), cams=[cam])
+        return trainer.step(it0 + 1 + (i if a.with_densify else i % 90), cams=[cam_of(i)])
+
+    def instances_of(i):
+        """Instance count R of the camera step i draws (read once, outside any timed region)."""
+        return r_of_cam.get(id(cam_of(i)))
 
     DGR.set_sync_mode("exact")
     one(0)                                                   # sizes the binning buffers
     R = DGR.last_num_rendered() if trainer.fused is None else int(trainer.fused.nr_host[0])
     if a.sync_mode == "async" and trainer.fused is None:
         DGR.set_sync_mode("async", capacity_hint=int(R * 1.6) + 65536)
-    for i in range(a.warmup):
-        one(i + 1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    # per-camera instance counts (R is data dependent: SURVEY 8d asks for it with every timing).  One untimed pass over the
+    # cameras this rank will draw; each step's count is read after a synchronisation.
+    r_of_cam = {}
+    if trainer.fused is not None:
+        for i in range(1, 1 + len(cams)):        # every rank makes the same number of calls (the steps hold collectives)
+            one(i)
+            torch.cuda.synchronize()
+            r_of_cam[id(cam_of(i))] = int(trainer.fused.nr_host[0])
     prof = importlib.import_module("iclr2025_3d-mom_amd.profiling")
-    if rank == 0:
-        prof.enable(a.roofline_kernel)       # two hipEventRecord per step around the dominant kernel only
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        loss = one(a.warmup + 1 + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt[0])
+
+    def timed(first, steps, profile_kernel=None):
+        """`steps` training steps bracketed by barrier + synchronize on both sides; max over ranks.  Every step enqueued
+        inside the region is verified applied before the clock stops (Trainer.drain: an overflowed step is replayed, never
+        dropped)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if profile_kernel and rank == 0:
+            prof.enable(profile_kernel)      # two hipEventRecord per step around the dominant kernel only
+        t0 = time.perf_counter()
+        loss = None
+        for i in range(steps):
+            loss = one(first + i)
+        trainer.drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt[0])
+        rs = [instances_of(first + i) for i in range(steps)]
+        rs = [r for r in rs if r is not None]
+        return dt, loss, (sum(rs) / len(rs) if rs else float(R))
+
+    scale = world if a.shard == "camera" else 1
+    nxt = 1 + len(cams)
+    steady = None
+    if not a.no_extra:
+        # SURVEY 8(d)'s reading of the metric: >= 200 steps after 50 warm-up.  It runs BEFORE the headline region, so the
+        # headline's K steps are measured on a warm device whatever --steps / --warmup the caller chose.
+        for i in range(a.steady_warmup):
+            one(nxt + i)
+        nxt += a.steady_warmup
+        dts, loss_s, r_mean = timed(nxt, a.steady_steps)
+        nxt += a.steady_steps
+        assert torch.isfinite(loss_s).all(), "loss is not finite (steady leg)"
+        b = step_bytes(cfg["P"], r_mean, npix, a.lambda_dssim)
+        steady = {"value": a.steady_steps * scale / dts, "unit": "steps/s", "steps": a.steady_steps, "warmup": a.steady_warmup,
+                  "ms_per_step": 1e3 * dts / a.steady_steps, "instances_R_mean": r_mean,
+                  "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": b, "achieved": b * a.steady_steps / dts / 1e9,
+                                    "peak": 8000.0, "unit": "GB/s", "frac": b * a.steady_steps / dts / 1e9 / 8000.0,
+                                    "formula": "P*2751 + R*172 + Npix*84 + 116 MB (SURVEY 8d); per GPU"}}
+    for i in range(a.warmup):
+        one(nxt + i)
+    nxt += a.warmup
+    dt, loss, r_mean = timed(nxt, a.steps, profile_kernel=a.roofline_kernel)
+    nxt += a.steps
     assert torch.isfinite(loss).all(), "loss is not finite"
+    b_step = step_bytes(cfg["P"], r_mean, npix, a.lambda_dssim)
     out = {
-        "metric": metric_name(), "value": a.steps * (world if a.shard == "camera" else 1) / dt,
+        "metric": metric_name(), "value": a.steps * scale / dt,
         "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak" if a.shard == "camera" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "gaussians": cfg["P"], "frames": cfg["F"], "width": cfg["W"],
-                   "height": cfg["H"], "instances_R": int((DGR.last_num_rendered() if trainer.fused is None else trainer.fused.nr_host[0]) or 0),
+                   "height": cfg["H"], "instances_R": r_mean, "instances_R_is": "mean over the cameras of the timed steps",
                    "sh_degree": 3, "step_path": a.path, "batch_size": 1,
                    "lambda_dssim": a.lambda_dssim, "parallelism": (f"camera-batch x{world}" if a.shard == "camera" else f"tile-row x{world}") if world > 1 else "single",
-                   "host_sync": a.sync_mode, "final_loss": float(loss), "densify_in_window": bool(a.with_densify),
-                   "gaussians_at_end": int(g.get_xyz.shape[0])},
+                   "ranks_seen": ranks_seen, "host_sync": a.sync_mode, "final_loss": float(loss), "densify_in_window": bool(a.with_densify),
+                   "gaussians_at_end": int(g.get_xyz.shape[0]), "steps_replayed_after_overflow": int(trainer.replayed),
+                   "inputs": "camera matrices and ground-truth images pre-staged in HBM before the timed region"},
+        "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": b_step, "achieved": b_step * a.steps / dt / 1e9,
+                          "peak": 8000.0, "unit": "GB/s", "frac": b_step * a.steps / dt / 1e9 / 8000.0,
+                          "formula": "P*2751 + R*172 + Npix*84 + 116 MB (SURVEY 8d); per GPU"},
     }
+    if steady is not None:
+        out["steady"] = steady
     if rank == 0:
-        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], out["config"]["instances_R"], cfg["W"] * cfg["H"],
+        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], r_mean, npix,
                                         traffic=measured_traffic(a.roofline_kernel, cfg))
+        prof.enable(a.roofline_kernel, False)
         if world == 1 and not a.no_extra:
             # the metric's two other readings, on the same scene and model state (SURVEY 8d): the SSIM/L1 loss of the
             # north star, and render FPS.  Both after the headline region, so they cannot disturb it.
-            prof.enable(a.roofline_kernel, False)
             k2 = max(1, min(a.steps, 50))
             op.lambda_dssim = 0.2
             for i in range(5):
-                one(a.warmup + a.steps + 1 + i)
-            dt2, loss2 = timed_steps(one, a.warmup + a.steps + 6, k2)
+                one(nxt + i)
+            dt2, loss2, _ = timed(nxt + 5, k2)
+            nxt += 5 + k2
             op.lambda_dssim = a.lambda_dssim
             assert torch.isfinite(loss2).all(), "loss (lambda_dssim 0.2) is not finite"
             out["with_ssim"] = {"lambda_dssim": 0.2, "value": k2 / dt2, "unit": "steps/s", "steps": k2,

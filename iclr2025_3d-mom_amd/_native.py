@@ -97,14 +97,14 @@ def _sig(lib):
     lib.mom_morton_order_scratch_bytes.restype = sz
     lib.mom_morton_order_scratch_bytes.argtypes = [i32]
     lib.mom_morton_order.argtypes = [i32, vp, vp, vp, vp]
-    lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp]
+    lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.mom_l1_loss.argtypes = [sz, vp, vp, vp, vp, vp]
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
     lib.mom_deform_forward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.mom_deform_backward_scratch_bytes.restype = sz
     lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
     lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp]
-    lib.mom_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp]
+    lib.mom_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_select_scratch_bytes.restype = sz
     lib.mom_select_scratch_bytes.argtypes = [i32]
     lib.mom_select_plan.argtypes = [i32, vp, vp, vp, vp, vp, vp]

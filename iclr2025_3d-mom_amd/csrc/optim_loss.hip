@@ -17,11 +17,13 @@ struct AdamArgs {
     unsigned block_start[MOM_ADAM_MAX_TENSORS + 1];
     int count;
     float beta1, beta2, eps, w1, w2;  // w = 1 - beta evaluated in double on the host, as torch does
+    const uint32_t* skip;             // device word, may be null: nonzero -> the whole launch is a no-op
 };
 constexpr int kAdamPerBlock = 256 * 8;
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a)
 {
+    if (a.skip && *a.skip) return;    // the step's binning overflowed: its gradients are truncated, leave the state alone
     // find the tensor this workgroup works on (count <= 64: linear scan on the scalar unit)
     int ti = 0;
     while (ti + 1 < a.count && blockIdx.x >= a.block_start[ti + 1]) ti++;
@@ -192,7 +194,8 @@ act_bwd_kernel(int P, const float* __restrict__ s, const float* __restrict__ rr,
 
 }  // namespace
 
-extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double beta2, double eps, mom_stream_t stream)
+extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double beta2, double eps,
+                             const uint32_t* skip_if_nonzero, mom_stream_t stream)
 {
     if (count < 0 || (count > 0 && !tensors)) return MOM_EINVAL;
     int done = 0;
@@ -200,6 +203,7 @@ extern "C" int mom_adam_step(const MomAdamTensor* tensors, int count, double bet
         AdamArgs a;
         a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
         a.w1 = (float)(1.0 - beta1); a.w2 = (float)(1.0 - beta2);
+        a.skip = skip_if_nonzero;
         int n = count - done;
         if (n > MOM_ADAM_MAX_TENSORS) n = MOM_ADAM_MAX_TENSORS;
         unsigned blocks = 0;
@@ -247,10 +251,10 @@ extern "C" int mom_l1_loss(size_t n, const float* img, const float* gt, float* d
 namespace {
 __global__ void __launch_bounds__(256)
 densify_stats_kernel(int P, const int* __restrict__ radii, const float* __restrict__ vsp_grad, float* __restrict__ max_radii2D,
-                     float* __restrict__ grad_accum, float* __restrict__ denom)
+                     float* __restrict__ grad_accum, float* __restrict__ denom, const uint32_t* __restrict__ skip)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= P) return;
+    if (i >= P || (skip && *skip)) return;
     const int r = radii[i];
     if (r <= 0) return;
     max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
@@ -261,13 +265,13 @@ densify_stats_kernel(int P, const int* __restrict__ radii, const float* __restri
 }  // namespace
 
 extern "C" int mom_densify_stats(int P, const int* radii, const float* viewspace_grad, float* max_radii2D, float* xyz_gradient_accum,
-                                 float* denom, mom_stream_t stream)
+                                 float* denom, const uint32_t* skip_if_nonzero, mom_stream_t stream)
 {
     if (P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!radii || !viewspace_grad || !max_radii2D || !xyz_gradient_accum || !denom) return MOM_EINVAL;
     hipLaunchKernelGGL(densify_stats_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, radii, viewspace_grad,
-                       max_radii2D, xyz_gradient_accum, denom);
+                       max_radii2D, xyz_gradient_accum, denom, skip_if_nonzero);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

@@ -35,6 +35,14 @@ static int check_grads(const MomRasterArgs* a, const MomRasterGrads* gr)
     return MOM_OK;
 }
 
+namespace {
+__global__ void status_or_kernel(const uint32_t* __restrict__ hdr_status, uint32_t* __restrict__ sticky)
+{
+    const uint32_t v = *hdr_status;
+    if (v) atomicOr(sticky, v);
+}
+}  // namespace
+
 extern "C" {
 
 const char* mom_version(void) { return "mom4d 0.1 (gfx950)"; }
@@ -120,8 +128,10 @@ int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning,
     rc = mom_launch_render_fwd(a, g, b, im, capacity, out_color, out_depth, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
-    if (status_dev)
-        if (hipMemcpyAsync(status_dev, im.hdr + 1, 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return MOM_ELAUNCH;
+    if (status_dev) {
+        hipLaunchKernelGGL(status_or_kernel, dim3(1), dim3(1), 0, s, im.hdr + 1, status_dev);
+        if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    }
     return MOM_OK;
 }
 

@@ -16,13 +16,41 @@ import torch
 
 from .. import _native as N
 
-_state = {"mode": "exact", "cap_hint": 0, "last_R": None, "status": None}
+from collections import deque
+
+_state = {"mode": "exact", "cap_hint": 0, "last_R": None, "flag": None, "pending": deque()}
+_FLAG_LAG = 4
+
+
+def overflow_flag(device):
+    """The sticky int32 device word async-mode forwards OR their overflow bit into (created on first use).  Point
+    ops.FusedAdam.skip_flag at it and no optimizer step taken after an overflow reaches the model."""
+    f = _state["flag"]
+    if f is None or f.device != torch.device(device):
+        f = _state["flag"] = torch.zeros(1, dtype=torch.int32, device=device)
+        _state["pending"].clear()
+    return f
+
+
+def _check_overflow(lag):
+    q = _state["pending"]
+    while len(q) > lag:
+        ev, host, count = q.popleft()
+        ev.synchronize()
+        if int(host[0]) & 1:
+            q.clear()
+            _state["flag"].zero_()
+            _state["cap_hint"] = max(_state["cap_hint"], int(count[0]) * 2)
+            raise RuntimeError("libmom4d: an async-mode forward overflowed its binning capacity (instance count "
+                               f"{int(count[0])}); its image and every image since were truncated.  Optimizer steps were skipped "
+                               "on the device from that forward on if FusedAdam.skip_flag is overflow_flag(); the capacity "
+                               "hint has been doubled -- repeat those iterations, or use set_sync_mode('exact')")
 
 
 def set_sync_mode(mode: str, capacity_hint: int = 0) -> None:
     """'exact': read the instance count back (blocking) and size the binning buffer exactly.
-    'async': never block; size the buffer from `capacity_hint` / 1.5x the last observed count and raise at the
-    next call if the previous one overflowed."""
+    'async': never block; size the buffer from `capacity_hint` / 1.5x the last observed count.  An overflow sets a sticky
+    device word (overflow_flag) that is read back behind an event and raised a few calls later (_FLAG_LAG)."""
     assert mode in ("exact", "async")
     _state["mode"] = mode
     if capacity_hint:
@@ -92,7 +120,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     a, keep = _args(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                     projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug)
     stream = N.current_stream()
-    nr_dev = torch.empty((2,), dtype=torch.int32, device=dev)
+    nr_dev = torch.empty((1,), dtype=torch.int32, device=dev)
     nr_host = torch.empty((1,), dtype=torch.int32).pin_memory()
     N.check(lib.mom_raster_forward_geometry(C.byref(a), geom.data_ptr(), img.data_ptr(), radii.data_ptr(),
                                             nr_dev.data_ptr(), nr_host.data_ptr(), stream), "mom_raster_forward_geometry")
@@ -100,24 +128,24 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
         torch.cuda.current_stream().synchronize()
         cap = int(nr_host[0])
     else:
+        flag = overflow_flag(dev)
+        _check_overflow(_FLAG_LAG)
         prev = _state["last_R"]
-        if _state["status"] is not None and prev is not None:
-            # the previous call has long finished (the training loop syncs on loss.item()); check it now
-            if int(_state["status"][0]) & 1:
-                raise RuntimeError("libmom4d: binning capacity overflowed in the previous async forward "
-                                   f"(count {int(prev[0])}); raise capacity_hint or use exact mode")
+        if prev is not None:      # an earlier call's count (a sizing hint; whichever copy has landed)
             _state["cap_hint"] = max(_state["cap_hint"], int(int(prev[0]) * 1.5) + 4096)
         cap = max(_state["cap_hint"], 4096)
     _state["last_R"] = nr_host
     binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, cap),), dtype=torch.uint8, device=dev)
-    status_host = None
     N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
-                                          out_color.data_ptr(), out_depth.data_ptr(), nr_dev[1:].data_ptr(), stream),
+                                          out_color.data_ptr(), out_depth.data_ptr(),
+                                          flag.data_ptr() if _state["mode"] == "async" else None, stream),
             "mom_raster_forward_render")
     if _state["mode"] == "async":
         status_host = torch.empty((1,), dtype=torch.int32).pin_memory()
-        status_host.copy_(nr_dev[1:], non_blocking=True)
-    _state["status"] = status_host
+        status_host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _state["pending"].append((ev, status_host, nr_host))
     del keep
     return cap, out_color, out_depth, radii, geom, binning, img
 

@@ -7,6 +7,7 @@ callers keep them.
 """
 import ctypes as C
 import math
+from collections import deque
 
 import torch
 
@@ -23,6 +24,8 @@ class FusedRender:
         self.cap = 0
         self.binning = None
         self._desc_key = None
+        self.serial = 0
+        self.pending = deque()
 
     def _ensure(self, P, W, H, dev):
         if self.key == (P, W, H, dev):
@@ -34,10 +37,30 @@ class FusedRender:
         self.sc, self.rot, self.op = e(P, 3), e(P, 4), e(P, 1)
         self.geom = torch.empty(self.lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
         self.img = torch.empty(self.lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
-        self.nr_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.nr_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        # per-frame status word of the image scratch (header word 1: bit 0 = this frame's binning overflowed), copied to a
+        # pinned ring behind an event after every async-mode frame
+        self.hdr = self.img[(-self.img.data_ptr()) % 256:][:8].view(torch.int32)
+        self.flag_ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+        self.pending = deque()               # (frame serial, ring slot, event), oldest first
         self.cap, self.binning = 0, None
+
+    RING, FLAG_LAG = 64, 8
+
+    def overflowed(self, lag=0):
+        """Serial numbers (FusedRender.serial after the render() that produced them) of async-mode frames older than `lag`
+        frames whose binning buffer overflowed -- their images are incomplete and must be rendered again.  lag=0 waits for
+        everything rendered so far.  The capacity is raised so that a repeat fits."""
+        bad = []
+        while len(self.pending) > lag:
+            serial, slot, ev = self.pending.popleft()
+            ev.synchronize()
+            if int(self.flag_ring[slot]) & 1:
+                bad.append(serial)
+        if bad:
+            self.cap_floor = max(getattr(self, "cap_floor", 0), 2 * self.cap)
+        return bad
 
     def render(self, cam, bg, delta_scale, scaling_modifier=1.0, debug=False):
         g, lib, s = self.g, self.lib, N.current_stream()
@@ -82,24 +105,33 @@ class FusedRender:
         radii = torch.empty(P, dtype=torch.int32, device=dev)
         # Binning capacity, as diff_gaussian_rasterization._C does it.  "exact" (the reference's own synchronisation point,
         # rasterizer_impl.cu:282): wait for this frame's instance count.  "async": size from the previous frames' counts with
-        # headroom and do not wait; an overflow sets a flag that is read back asynchronously and raised at the next call.
+        # headroom and do not wait; a frame that does not fit is flagged per frame (overflowed()): callers that render a
+        # whole trajectory collect the flagged frames at the end and render them again (render.render_set); a caller that
+        # never asks gets a MomError FLAG_LAG frames later.
         prev_R = int(self.nr_host[0])
-        if int(self.status_host[0]) & 1:
-            self.status_host.zero_()
-            raise N.MomError(f"binning capacity {self.cap} overflowed in the previous async render (count {prev_R}); "
-                             "render that frame again or use set_sync_mode('exact')")
+        late = self.overflowed(self.FLAG_LAG) if len(self.pending) > self.FLAG_LAG else []
+        if late:
+            raise N.MomError(f"async render(): frames {late} overflowed the binning capacity and are incomplete; render them "
+                             "again (the capacity has been raised), collect such frames with FusedRender.overflowed(), or use "
+                             "set_sync_mode('exact')")
         N.check(lib.mom_raster_forward_geometry(C.byref(a), self.geom.data_ptr(), self.img.data_ptr(), radii.data_ptr(),
                                                 self.nr_dev.data_ptr(), self.nr_host.data_ptr(), s), "raster_geometry")
         if RC._state["mode"] == "exact" or self.cap == 0:
             torch.cuda.current_stream().synchronize()
             want = int(self.nr_host[0]) + (0 if RC._state["mode"] == "exact" else int(self.nr_host[0]) // 2 + 65536)
         else:
-            want = max(self.cap, int(prev_R * 1.5) + 65536)
+            want = max(self.cap, int(prev_R * 1.5) + 65536, getattr(self, "cap_floor", 0))
         if self.binning is None or want > self.cap or want < self.cap // 4:
             self.cap = want
             self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, self.cap), dtype=torch.uint8, device=dev)
         N.check(lib.mom_raster_forward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                               self.img.data_ptr(), color.data_ptr(), depth.data_ptr(),
-                                              self.nr_dev[1:].data_ptr(), s), "raster_render")
-        self.status_host.copy_(self.nr_dev[1:], non_blocking=True)
+                                              None, s), "raster_render")
+        self.serial += 1
+        if RC._state["mode"] != "exact":
+            slot = self.serial % self.RING
+            self.flag_ring[slot:slot + 1].copy_(self.hdr[1:2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.pending.append((self.serial, slot, ev))
         return color, depth, radii

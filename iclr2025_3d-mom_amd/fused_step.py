@@ -44,11 +44,19 @@ class FusedStep:
         self.radii = torch.empty(P, dtype=torch.int32, device=dev)
         self.geom = torch.empty(self.lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
         self.img = torch.empty(self.lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
-        self.nr_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.nr_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self.status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        # Sticky overflow word (mom_raster_forward_render only ever sets bits in it).  The binning buffer is sized from
+        # earlier frames without waiting for this frame's count; when a frame does not fit, its image and gradients are
+        # truncated, the word becomes nonzero and stays so, and Adam / the densification statistics of that step and of every
+        # later one are no-ops ON THE DEVICE (mom_adam_step / mom_densify_stats skip_if_nonzero) until the host -- which
+        # runs several steps ahead and reads the word through flag_ring a few steps later -- clears it and replays the
+        # skipped iterations with an exactly sized buffer (train.Trainer._recover).  Nothing truncated ever reaches the model.
+        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.flag_ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
         self.cap = 0
         self.binning = None
+        self._resize_next = False
         self.dimg, self.sums = e(3, H, W), e(2)
         self.ssim_dm = None                  # SSIM term: made on first use (lambda_dssim may be switched on later)
         self.g2d, self.gcol, self.gop_act, self.gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 6)
@@ -64,6 +72,21 @@ class FusedStep:
         self.gsc, self.grot, self.gop = seg(2).view(P, 3), seg(3).view(P, 4), seg(4).view(P, 1)
         self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
         self.regval = e(1)
+
+    RING = 64
+    HEADROOM, MARGIN = 1.5, 65536     # binning capacity = HEADROOM x an earlier frame's instance count + MARGIN
+
+    def exact_next(self):
+        """Size the binning buffer of the next step from that step's own instance count (one host sync): it cannot overflow."""
+        self._resize_next = True
+
+    def post_flag(self, slot):
+        """Copy the overflow word to ring slot `slot` behind everything enqueued so far; the returned event tells when the
+        slot is valid."""
+        self.flag_ring[slot:slot + 1].copy_(self.flags, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
 
     def _gacc_view(self, P, W, H):
         """The per-Gaussian record of the compositing backward inside the geometry scratch, as a flat fp32 tensor."""
@@ -101,6 +124,8 @@ class FusedStep:
         P = g._xyz.shape[0]
         W, H = int(cam.image_width), int(cam.image_height)
         self._ensure(P, W, H, dev)
+        if self._resize_next:                   # after a tile-row re-split, an overflow, or on request (exact_next)
+            self.cap, self._resize_next = 0, False
         view, proj, campos, gt = cam.device_tensors(dev)
         dn = g._deformation.deformation_net
         field = dn.grid
@@ -158,23 +183,22 @@ class FusedStep:
             halo = 1 if (float(self.opt.lambda_dssim) != 0 and rows[1] > rows[0]) else 0
             fwd_rows = (max(rows[0] - halo, 0), min(rows[1] + halo, gy))
             a.tile_row0, a.tile_row1 = fwd_rows
-        # the previous iteration's instance count / overflow flag are long complete: read them without blocking
+        # an earlier iteration's instance count (whichever copy landed last: a sizing hint, read without blocking)
         prev_R = int(self.nr_host[0])
-        if int(self.status_host[0]) & 1:
-            raise N.MomError(f"binning capacity {self.cap} overflowed (count {prev_R}); re-run this iteration")
         N.check(lib.mom_raster_forward_geometry(C.byref(a), self.geom.data_ptr(), self.img.data_ptr(), self.radii.data_ptr(),
                                                 self.nr_dev.data_ptr(), self.nr_host.data_ptr(), s), "raster_geometry")
         if self.cap == 0:                       # first call: size exactly (one sync)
             torch.cuda.current_stream().synchronize()
             prev_R = int(self.nr_host[0])
-        want = int(prev_R * 1.5) + 65536
+        want = max(prev_R, int(prev_R * self.HEADROOM) + self.MARGIN)
         if self.binning is None or want > self.cap or want < self.cap // 4:
             self.cap = want
             self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, self.cap), dtype=torch.uint8, device=dev)
         N.check(lib.mom_raster_forward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                               self.img.data_ptr(), self.color.data_ptr(), self.depth.data_ptr(),
-                                              self.nr_dev[1:].data_ptr(), s), "raster_render")
-        self.status_host.copy_(self.nr_dev[1:], non_blocking=True)
+                                              self.flags.data_ptr(), s), "raster_render")
+        if dc is not None:
+            dc.start(self.flags, "max")         # every rank skips (and later replays) the same steps
         # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
         n = self.color.numel()
         N.check(lib.mom_l1_loss(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
@@ -234,7 +258,9 @@ class FusedStep:
                 own = torch.zeros_like(per_row)
                 own[rows[0]:rows[1]] = per_row[rows[0]:rows[1]]
                 if dc.rebalance_rows(own):
-                    self.cap = 0
+                    # the local instance count can jump with the new rows: size the NEXT step's buffer exactly.  This step's
+                    # backward below still runs on the buffer (and capacity) its forward filled.
+                    self._resize_next = True
             a.tile_row0, a.tile_row1 = rows          # own rows only (the forward may have covered a halo)
             N.check(lib.mom_raster_backward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                                    self.img.data_ptr(), self.dimg.data_ptr(), None, s), "raster_bwd_render")

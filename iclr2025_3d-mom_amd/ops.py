@@ -251,9 +251,10 @@ def select_rows(mask, tensors):
 
 
 # --------------------------------------------------------------------------- densification statistics
-def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom):
+def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom, skip_flag=None):
     """In place, for the Gaussians with radii > 0: running maximum radius, accumulated |dL/d mean2D| and its count
-    (train_4DGS.py:266, scene/gaussian_model.py:713-715)."""
+    (train_4DGS.py:266, scene/gaussian_model.py:713-715).  `skip_flag`: optional int32 device word; nonzero makes the
+    launch a no-op (FusedAdam.skip_flag has the story)."""
     _need_cuda(radii, "densify_stats")
     P = radii.shape[0]
     for t_, n_ in ((max_radii2D, P), (xyz_gradient_accum, P), (denom, P)):
@@ -265,7 +266,8 @@ def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom)
     if g.shape != (P, 3) or g.dtype != torch.float32 or not g.is_contiguous():
         raise N.MomError("densify_stats: viewspace gradient must be a contiguous float32 [P,3] tensor")
     N.check(N.lib().mom_densify_stats(P, radii.data_ptr(), g.data_ptr(), max_radii2D.data_ptr(), xyz_gradient_accum.data_ptr(),
-                                      denom.data_ptr(), N.current_stream()), "mom_densify_stats")
+                                      denom.data_ptr(), None if skip_flag is None else skip_flag.data_ptr(),
+                                      N.current_stream()), "mom_densify_stats")
 
 
 # --------------------------------------------------------------------------- SSIM
@@ -393,6 +395,16 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self._plan = None
+        # int32 device word or None.  While it is nonzero on the device a step() changes neither parameters nor moments:
+        # the asynchronous training step points it at the rasterizer's sticky overflow word, so that a step whose image was
+        # truncated never reaches the model; the host notices later and replays (train.Trainer._recover, rewind()).
+        self.skip_flag = None
+
+    def rewind(self, n):
+        """Take back the host-side step counters of the last n step() calls (they were no-ops on the device)."""
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] -= float(n)
 
     def _build_plan(self, live, key):
         """Validate every (param, grad, state) once and lay the MomAdamTensor arrays out; reused until a pointer moves
@@ -446,7 +458,9 @@ class FusedAdam(torch.optim.Optimizer):
             t.bias_correction1 = 1.0 - b1 ** step
             t.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
         for (b1, b2, eps), arr in arrs.items():
-            N.check(N.lib().mom_adam_step(arr, len(arr), b1, b2, eps, N.current_stream()), "mom_adam_step")
+            N.check(N.lib().mom_adam_step(arr, len(arr), b1, b2, eps,
+                                          None if self.skip_flag is None else self.skip_flag.data_ptr(), N.current_stream()),
+                    "mom_adam_step")
         return loss
 
 

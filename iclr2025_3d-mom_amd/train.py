@@ -2,6 +2,7 @@
 LR update -> SH-degree bump -> camera draw -> render -> loss -> backward -> densification statistics ->
 densify / prune / opacity reset -> Adam step.  Host syncs the reference pays every iteration (loss.item(),
 isnan, the num_rendered read-back, H2D of matrices and ground truth) are optional here."""
+from collections import deque
 from random import randint
 
 import torch
@@ -29,6 +30,55 @@ class Trainer:
         if fused and stage == "fine" and opt.batch_size == 1:
             from .fused_step import FusedStep
             self.fused = FusedStep(gaussians, opt, hyper, self.background)
+        # fused steps whose overflow word has not been read yet: (iteration, camera, ring slot, event), oldest first
+        self._pending = deque()
+        self._serial = 0
+        self.replayed = 0    # iterations replayed after a binning overflow (diagnostics)
+
+    # The host enqueues a fused step without knowing whether the step's binning buffer will be large enough (it is sized
+    # from earlier frames; waiting for the count would be the reference's per-iteration sync, rasterizer_impl.cu:282).
+    # A step that does not fit sets a sticky device word that turns its own and every later Adam / statistics launch into
+    # no-ops (FusedStep.flags).  The host reads the word FLAG_LAG steps later -- a fixed lag, so that all ranks of a
+    # multi-GPU run reach the same decision at the same step -- and, if it is set, clears it and replays the logged
+    # iterations from the first skipped one with exactly sized buffers.  The model therefore always equals what a fully
+    # synchronous run would have produced.
+    FLAG_LAG = 8
+
+    def _boundary(self, iteration):
+        """Iterations whose host logic reads or restructures model state (densify / prune / opacity reset / SH bump): every
+        earlier step must be verified first, and the step itself runs with an exactly sized buffer."""
+        o = self.opt
+        return (iteration % o.densification_interval == 0 or iteration % o.pruning_interval == 0
+                or iteration % o.opacity_reset_interval == 0 or iteration % 1000 == 0)
+
+    def _poll(self, lag):
+        while len(self._pending) > lag:
+            it, cam, slot, ev = self._pending[0]
+            ev.synchronize()
+            if int(self.fused.flag_ring[slot]) != 0:
+                self._recover()
+                return
+            self._pending.popleft()
+
+    def drain(self):
+        """Every step enqueued so far has been applied to the model (replaying the ones an overflow skipped)."""
+        if self.fused is not None:
+            self._poll(0)
+
+    def _recover(self):
+        torch.cuda.synchronize()
+        entries = list(self._pending)
+        self._pending.clear()
+        ring = self.fused.flag_ring
+        bad = next(i for i, e in enumerate(entries) if int(ring[e[2]]) != 0)   # the word is sticky: all later ones are set too
+        redo = entries[bad:]
+        self.g.optimizer.rewind(len(redo))      # the host counted steps the device skipped
+        self.fused.flags.zero_()
+        for it, cam, _, _ in redo:
+            self.g.update_learning_rate(it)
+            self.fused.exact_next()
+            self._step_fused(it, cam, replay=True)
+            self.replayed += 1
 
     def _draw(self):
         cams = []
@@ -40,6 +90,14 @@ class Trainer:
 
     def step(self, iteration, cams=None):
         g, opt, hyper = self.g, self.opt, self.hyper
+        if self.fused is not None:
+            # before anything of this iteration touches host state: earlier fused steps are verified (and replayed if an
+            # overflow skipped them) -- all of them at an iteration that restructures the model, else up to a fixed lag
+            if self._boundary(iteration):
+                self.drain()
+                self.fused.exact_next()
+            else:
+                self._poll(self.FLAG_LAG)
         g.update_learning_rate(iteration)
         if iteration % 1000 == 0:
             g.oneupSHdegree()
@@ -86,9 +144,10 @@ class Trainer:
             self.last = {"loss": loss.detach(), "l1": Ll1.detach(), "points": g._xyz.shape[0]}
         return self._after_backward(iteration, loss.detach(), radii, visibility, vsp_grad)
 
-    def _step_fused(self, iteration, cam):
+    def _step_fused(self, iteration, cam, replay=False):
         with torch.no_grad():
             loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale)
+            self.g.optimizer.skip_flag = self._skip = self.fused.flags
             if self.dist is not None:
                 # the step began its all-reduces as each bucket became final (fused_step.py); radii and vsp_grad come
                 # back reduced in place (largest radius over the ranks, mean screen-space gradient)
@@ -100,7 +159,13 @@ class Trainer:
                     raise FloatingPointError("loss is nan")
                 self.ema_loss = 0.4 * loss.item() + 0.6 * self.ema_loss
             self.last = {"loss": loss, "l1": self.fused.last["l1"], "points": self.g._xyz.shape[0]}
-        return self._after_backward(iteration, loss, radii, visibility, vsp_grad)
+        loss = self._after_backward(iteration, loss, radii, visibility, vsp_grad)
+        self._skip = None
+        if not replay:
+            slot = self._serial % self.fused.RING
+            self._serial += 1
+            self._pending.append((iteration, cam, slot, self.fused.post_flag(slot)))
+        return loss
 
     def _after_backward(self, iteration, loss, radii, visibility, vsp_grad):
         g, opt = self.g, self.opt
@@ -109,7 +174,7 @@ class Trainer:
             if iteration < opt.densify_until_iter:
                 # same values as the reference's boolean-mask indexing (train_4DGS.py:266), without the host sync a
                 # nonzero() costs: invisible entries keep their old value
-                g.update_densification_stats(radii, vsp_grad)
+                g.update_densification_stats(radii, vsp_grad, skip_flag=getattr(self, "_skip", None))
                 if self.stage == "coarse":
                     op_thr, de_thr = opt.opacity_threshold_coarse, opt.densify_grad_threshold_coarse
                 else:

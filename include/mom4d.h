@@ -97,7 +97,9 @@ int mom_raster_forward_geometry(const MomRasterArgs* a, void* geom, void* image,
  * rasterizer_impl.cu:70-111,301-318) and alpha compositing (renderCUDA,
  * forward.cu:261-379).  `capacity` is the instance capacity the binning buffer
  * was sized for; if the true count exceeds it nothing beyond capacity is written,
- * bit 0 of *status_dev is set and the image is incomplete.
+ * bit 0 is OR-ed into *status_dev and the image is incomplete.  The word is STICKY: the call
+ * only ever sets bits, the caller zeroes it (before the first call, and after it has dealt
+ * with an overflow), so a host that reads it late cannot miss one.
  * out_color [3,H,W], out_depth [1,H,W]. */
 int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning, size_t capacity, void* image,
                               float* out_color, float* out_depth, uint32_t* status_dev, mom_stream_t stream);
@@ -219,7 +221,12 @@ typedef struct MomAdamTensor {
     float bias_correction1;
     float bias_correction2_sqrt;
 } MomAdamTensor;
-int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double beta2, double eps, mom_stream_t stream);
+/* skip_if_nonzero (device word, may be null): when it is nonzero at execution time the launch changes nothing.  The fused
+ * training step points it at the rasterizer's sticky overflow word (mom_raster_forward_render), so that a step whose binning
+ * buffer overflowed -- its image and gradients are truncated -- never reaches the parameters or the moments; the host, which
+ * runs ahead of the GPU, finds the flag later and replays that iteration with a larger buffer. */
+int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double beta2, double eps,
+                  const uint32_t* skip_if_nonzero, mom_stream_t stream);
 
 /* ---- L1 loss + PSNR sums + gradient (utils/loss_utils.py:23-24, utils/image_utils.py:17-38) --
  * sums2[0] = sum |img-gt|, sums2[1] = sum (img-gt)^2 over n elements (zeroed by the call);
@@ -249,7 +256,7 @@ int mom_select_apply(int n, const int* dst_index, const MomRowSelect* tensors, i
  *   max_radii2D[i] = max(max_radii2D[i], radii[i]);  xyz_gradient_accum[i] += |viewspace_grad[i, :2]|;  denom[i] += 1.
  * viewspace_grad is [P,3] (dL/d mean2D; the third column is unused), the three accumulators are [P] floats. */
 int mom_densify_stats(int P, const int* radii, const float* viewspace_grad, float* max_radii2D, float* xyz_gradient_accum,
-                      float* denom, mom_stream_t stream);
+                      float* denom, const uint32_t* skip_if_nonzero /* as in mom_adam_step */, mom_stream_t stream);
 
 /* ---- SSIM term of the loss (utils/loss_utils.py:29-92: ssim / _ssim / create_window / gaussian) ----
  * 11x11 Gaussian window = outer product of the 11 taps in window11 (host pointer; the reference's

@@ -31,7 +31,7 @@ def _run(s, rows=None, dcol=None, ddep=None):
     radii = torch.empty(P, dtype=torch.int32, device=dev)
     geom = torch.empty(lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
     img = torch.empty(lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
-    nr_dev = torch.empty(2, dtype=torch.int32, device=dev)
+    nr_dev = torch.zeros(2, dtype=torch.int32, device=dev)
     nr_host = torch.empty(1, dtype=torch.int32).pin_memory()
     st = N.current_stream()
     N.check(lib.mom_raster_forward_geometry(C.byref(a), geom.data_ptr(), img.data_ptr(), radii.data_ptr(), nr_dev.data_ptr(),
