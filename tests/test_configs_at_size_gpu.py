@@ -1,0 +1,176 @@
+"""BASELINE configs[3] and configs[4] at their real sizes, on one GPU with virtual ranks (the 8-GPU node is the driver's).
+
+Config 4: 200k Gaussians, 960x540 (34 tile rows), tile-row shard x8 -- eight virtual ranks render the same camera, each its
+own rows (split_rows: 6 x 4 + 2 x 5), exchange the per-Gaussian record of the compositing backward, and must all end with the
+unsharded step's gradients and loss, with the reference's default loss (lambda_dssim 0) and with the SSIM term (0.2).
+
+Config 5: 4M Gaussians, 1920x1080, camera-batch shard x8 with the densify / prune cadence.  The reference's gates
+(train_4DGS.py:275-282) only densify while P < 360 000 and only prune while P > 200 000, so at 4M "densify / prune every 100
+iterations" is a PRUNE round; both cases are covered: (a) 4M: the buckets of 8 virtual camera ranks sum to the batch mean and a
+prune round at iteration 5100 leaves two replicas bit-identical; (b) 300k (inside both gates): the same with a densify +
+prune round.  Rasterizer properties at 4M / 1080p: tests/test_raster_gpu.py::test_full_size_properties[config5...].
+"""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+@pytest.mark.parametrize("lambda_dssim", [0.0, 0.2])
+def test_config4_tile_row_x8_at_200k_960x540(lambda_dssim):
+    import bench
+    from test_fused_step_gpu import _RowRank
+    par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    cfg = bench.CONFIGS["c2"]
+    scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=True, lambda_dssim=lambda_dssim)
+    fs, cam = trainer.fused, trainer.cams[7]
+    world, gy = 8, (cfg["H"] + 15) // 16
+    split = par.split_rows(gy, world)
+    assert gy == 34 and sorted(b - a for a, b in split) == [4] * 6 + [5] * 2 and split[0][0] == 0 and split[-1][1] == 34
+
+    def run(dist):
+        fs.dist = dist
+        loss, radii, g2d = fs.forward_backward(cam, 1)
+        torch.cuda.synchronize()
+        assert int(fs.flags[0]) == 0
+        return {"loss": float(loss), "radii": radii.clone(), "g2d": g2d.clone(), "early": fs.early.clone(),
+                "late": fs._dg_flat.clone(), "mse": float(fs.last["mse_sum"]), "R": int(fs.nr_host[0])}
+
+    want = run(None)
+    first = [_RowRank(r, world) for r in range(world)]
+    local_R = []
+    for d in first:
+        fs.exact_next()
+        local_R.append(run(d)["R"])
+        assert len(d.captured) == 2
+    # property: the ranks' instance counts partition the unsharded count (a splat's tile rectangle is cut by rows); with the
+    # SSIM term every forward also bins its halo rows, so the counts overlap there
+    if lambda_dssim == 0:
+        assert sum(local_R) == want["R"], (local_R, want["R"])
+    else:
+        assert want["R"] < sum(local_R) < 2 * want["R"], (local_R, want["R"])
+    # property: the per-Gaussian records of the ranks sum to the unsharded record (linearity of the exchange)
+    fs.dist = None
+    fs.exact_next()
+    run(None)
+    full_rec = fs._gacc_view(cfg["P"], cfg["W"], cfg["H"]).clone()
+    rec_sum = sum(d.captured[0] for d in first)
+    sc = float(full_rec.abs().max())
+    assert float((rec_sum - full_rec).abs().max()) <= 3e-5 * sc
+    feed = [rec_sum, sum(d.captured[1] for d in first)]
+    for r in range(world):
+        fs.exact_next()
+        got = run(_RowRank(r, world, feed))
+        assert abs(got["loss"] - want["loss"]) <= 2e-6 * max(1.0, abs(want["loss"])), (r, got["loss"], want["loss"])
+        assert abs(got["mse"] - want["mse"]) <= 2e-5 * abs(want["mse"])
+        torch.testing.assert_close(got["radii"], want["radii"], rtol=0, atol=0)
+        for k in ("g2d", "early", "late"):
+            scale = float(want[k].abs().max())
+            err = float((got[k] - want[k]).abs().max())
+            assert torch.isfinite(got[k]).all() and err <= 5e-5 * scale + 1e-9, (r, k, err, scale)
+    fs.dist = None
+
+
+class _CamRank:
+    """DistContext stand-in for one rank of a camera-batch shard on one GPU.  Pass 1 (feed=None) captures what the rank hands
+    to start(); pass 2 writes the reduction over the ranks back into the buffer, as the in-place all-reduce does."""
+    mode = "camera"
+
+    def __init__(self, rank, world, feed=None, seed=6666):
+        self.rank, self.world, self.feed, self.captured, self.seed = rank, world, feed, [], seed
+
+    def start(self, tensor, op="sum"):
+        assert tensor.is_contiguous()
+        if tensor.dtype == torch.int32 and tensor.numel() == 1:      # the sticky overflow word
+            return
+        self.captured.append(tensor.clone())
+        if self.feed is not None:
+            tensor.copy_(self.feed[len(self.captured) - 1])
+
+    def finish(self):
+        pass
+
+    def seed_for(self, iteration):
+        importlib.import_module("iclr2025_3d-mom_amd.parallel").DistContext.seed_for(self, iteration)
+
+
+def _camera_batch_round(cfg, world, check_ranks, iteration, expect, pruning_interval=100):
+    """`world` virtual camera ranks take one step at `iteration` (a densify / prune boundary): pass 1 collects every rank's
+    buckets on one model, then each rank in `check_ranks` is replayed on a fresh, identically seeded model with the reduced
+    buckets fed back, through Trainer.step -- Adam, statistics, densify / prune included.  Returns the replicas' states."""
+    import bench
+    states = []
+    feed = None
+    for which in [None] + list(check_ranks):
+        scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=True, lambda_dssim=0.0)
+        fs = trainer.fused
+        cams = trainer.cams
+        if which is None:
+            caps = []
+            for r in range(world):
+                fs.dist = d = _CamRank(r, world)
+                fs.exact_next()
+                fs.forward_backward(cams[(iteration * world + r) % len(cams)], 1)
+                torch.cuda.synchronize()
+                assert int(fs.flags[0]) == 0 and len(d.captured) == 4            # radii, g2d, early bucket, late bucket
+                caps.append(d.captured)
+            feed = [torch.stack([c[0] for c in caps]).max(0).values] + [sum(c[i] for c in caps) for i in (1, 2, 3)]
+            # the buckets carry 1/world each: their sum is the batch-mean gradient; finite, and not all zero
+            assert all(torch.isfinite(f).all() for f in feed[1:]) and float(feed[2].abs().max()) > 0
+            del scene, g, trainer, fs
+            torch.cuda.empty_cache()
+            continue
+        trainer.dist = fs.dist = _CamRank(which, world, feed)
+        # BASELINE configs[4]: "densify/prune every 100 iters" = the argparse default (arguments/__init__.py:146); the
+        # dnerf_default overlay the scripts load would prune every 8000 (arguments/dnerf/dnerf_default.py:13)
+        op.pruning_interval = pruning_interval
+        # Adam state as after earlier iterations (deterministic: a step on zero gradients creates it and moves nothing)
+        for grp in g.optimizer.param_groups:
+            for p in grp["params"]:
+                p.grad = torch.zeros_like(p, memory_format=torch.preserve_format)
+        g.optimizer.step()
+        g.optimizer.zero_grad(set_to_none=True)
+        # statistics of earlier iterations so that the round has something to act on (same on every replica)
+        gen = torch.Generator("cpu").manual_seed(99)
+        n = g.get_xyz.shape[0]
+        g.xyz_gradient_accum += (torch.rand(n, 1, generator=gen) * 4e-4).to("cuda")
+        g.denom += 1.0
+        g.max_radii2D += (torch.rand(n, generator=gen) * 30).to("cuda")
+        trainer.step(iteration, cams=[cams[(iteration * world + which) % len(cams)]])
+        trainer.drain()
+        torch.cuda.synchronize()
+        states.append({k: v.detach().clone() for k, v in (("xyz", g._xyz), ("opacity", g._opacity), ("scaling", g._scaling),
+                                                          ("f_rest", g._features_rest), ("flow", g._scene_flow),
+                                                          ("m_xyz", g.optimizer.state[g._xyz]["exp_avg"]))})
+        expect(n, g.get_xyz.shape[0])
+        del scene, g, trainer, fs
+        torch.cuda.empty_cache()
+    a, b = states
+    for k in a:
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k          # replicas bit-identical
+    return a
+
+
+def test_config5_camera_batch_x8_at_4M_1080p_with_a_prune_round():
+    import bench
+    cfg = dict(bench.CONFIGS["c5"])
+
+    def expect(before, after):
+        assert before == 4_000_000 and after < before and after > 200_000      # pruned (P > 200 000), not densified (P >= 360 000)
+
+    _camera_batch_round(cfg, 8, check_ranks=(0, 5), iteration=5100, expect=expect)
+
+
+def test_camera_batch_x8_with_a_densify_and_prune_round_inside_the_gates():
+    cfg = dict(P=300_000, F=8, W=960, H=540, time_res=50, name="300k, inside the reference's densify and prune gates")
+
+    def expect(before, after):
+        assert before == 300_000 and after != before
+
+    _camera_batch_round(cfg, 8, check_ranks=(2, 7), iteration=5100, expect=expect)

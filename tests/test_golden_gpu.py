@@ -196,7 +196,14 @@ def test_g8_adam_densify_prune_reset_on_hip():
     got_xyz = gm._xyz.detach().cpu().numpy()
     same = np.isclose(got_xyz, ref_xyz, rtol=1e-6, atol=1e-7).all(axis=1)
     n_split = int((~same).sum())
-    assert 0 < n_split <= got_xyz.shape[0] // 2 and (~same)[-n_split:].all(), n_split   # the split's rows are the last ones
+    # the split's 2k children are the last rows (k parents were removed in front of them); everything before is bit-equal
+    assert n_split > 0 and n_split % 2 == 0 and (~same)[-n_split:].all() and same[:-n_split].all(), n_split
+    k = n_split // 2
+    par_scale = np.exp(d["dens_scaling"][-n_split:]) * 1.6        # children carry log(s / 1.6): undo it -> the parents' scales
+    assert np.allclose(par_scale[:k], par_scale[k:])              # repeat(N=2): child i and child k+i share a parent
+    # both children of a parent are drawn around the parent's position: their offsets are bounded by a few sigma of it
+    off = np.abs(got_xyz[-n_split:][:k] - got_xyz[-n_split:][k:])
+    assert float((off / (par_scale[:k].max(axis=1, keepdims=True) + 1e-12)).max()) < 12.0
     st = gm.optimizer.state[gm._xyz]
     np.testing.assert_array_equal(st["exp_avg"].cpu().numpy() != 0, d["dens_exp_avg_xyz"] != 0)       # zero-extended moments
     close(st["exp_avg"], d["dens_exp_avg_xyz"], 1e-6, "exp_avg")

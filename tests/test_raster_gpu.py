@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 IMG_L1_TOL = 1e-4      # mean per-pixel L1 (north_star)
 IMG_MAX_TOL = 2e-2     # a 1-ulp exp difference may flip one of the hard thresholds (1/255, T<1e-4) on a few pixels
-GRAD_REL_TOL = 2e-3    # float-atomic / reduction-order differences
+GRAD_REL_TOL = 2e-3
+ROW_TOL, ROW_FRAC, ROW_MAX = 1e-4, 0.999, 5e-3
 
 
 def _oracle(s, **kw):
@@ -144,6 +145,14 @@ def test_backward_parity(seed, P, W, H, kw):
         assert _relerr(a, b) <= GRAD_REL_TOL, (name, _relerr(a, b))
         inv = st.radii == 0
         assert np.abs(a[inv]).max(initial=0.0) == 0.0, name
+        # per GAUSSIAN, not only as a whole-tensor norm (a norm hides a few badly wrong rows): the worst element of a row,
+        # relative to the tensor's largest element, is within ROW_TOL on at least ROW_FRAC of the rows and within ROW_MAX on
+        # all of them.  Rows outside ROW_TOL are Gaussians with a (pixel, splat) pair whose alpha sits within an ulp of the
+        # 1/255 or 0.99 thresholds (v_exp_f32 vs expf), where the two implementations legitimately take different branches.
+        scale = max(float(np.abs(b).max()), 1e-30)
+        row_err = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1) / scale
+        frac_ok = float((row_err <= ROW_TOL).mean())
+        assert frac_ok >= ROW_FRAC and float(row_err.max()) <= ROW_MAX, (name, frac_ok, float(row_err.max()))
 
 
 def test_dropin_autograd_matches_oracle():
@@ -180,10 +189,10 @@ def test_dropin_autograd_matches_oracle():
     np.testing.assert_array_equal(vis.cpu().numpy(), s["means3D"][:, 2] > 0.2)
 
 
-@pytest.mark.parametrize("P,W,H,seed", [(200_000, 960, 540, 33), (1_000_000, 1920, 1080, 34)],
-                         ids=["config2_200k_960x540", "config3_1M_1920x1080"])
+@pytest.mark.parametrize("P,W,H,seed", [(200_000, 960, 540, 33), (1_000_000, 1920, 1080, 34), (4_000_000, 1920, 1080, 35)],
+                         ids=["config2_200k_960x540", "config3_1M_1920x1080", "config5_4M_1920x1080"])
 def test_full_size_properties(P, W, H, seed):
-    """BASELINE configs[1] and configs[2] sizes: size-independent properties instead of the oracle (which would need
+    """BASELINE configs[1], configs[2] and configs[4] (per-GPU model of the camera-batch shard) sizes: size-independent properties instead of the oracle (which would need
     minutes per frame there).  Binning: the instance counts agree three ways, the tile ranges partition the list and
     every tile's list is strictly sorted by (depth bits, index).  Compositing: weights + final transmittance = 1.
     Determinism: same inputs, same bits.  Backward: every gradient is linear in dL/dpixels."""

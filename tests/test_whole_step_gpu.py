@@ -1,0 +1,102 @@
+"""Whole training iterations on the HIP path against the same iterations on the CPU oracle path.
+
+The oracle path is the package's own Trainer with every libmom4d call swapped for the oracle (oracle.cpu_backend: the C
+restatement of the reference rasterizer + the reference's torch-op sequence for HexPlane / MLP / loss / Adam).  The HIP side
+runs twice: the autograd path (render() + loss.backward()) and the fused launch sequence (fused_step.py).
+
+What can differ: fp32 summation order (float atomics on the GPU, OpenMP-free serial sums in the oracle), v_exp_f32 vs
+expf in the compositing exponent (~1.5 ulp), and therefore -- for a handful of (pixel, splat) pairs whose alpha sits
+within an ulp of 1/255 or of the 0.99 cap -- a different branch.  Those pairs move single Gaussians' gradients visibly,
+which is why the comparison is per ELEMENT with a stated quantile instead of a whole-tensor norm."""
+import contextlib
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CFG = dict(P=6000, F=4, W=160, H=96, time_res=10, name="tiny")
+LIVE = ("xyz", "f_dc", "f_rest", "scaling", "rotation", "opacity", "plane_0_0", "plane_0_2", "plane_1_3", "plane_1_5", "w0", "b0",
+        "w_pos1", "w_pos3", "w_sc1", "w_rot3", "b_rot3")
+
+
+def _tensors(g):
+    dn = g._deformation.deformation_net
+    return {"xyz": g._xyz, "f_dc": g._features_dc, "f_rest": g._features_rest, "scaling": g._scaling, "rotation": g._rotation,
+            "opacity": g._opacity, "plane_0_0": dn.grid.grids[0][0], "plane_0_2": dn.grid.grids[0][2],
+            "plane_1_3": dn.grid.grids[1][3], "plane_1_5": dn.grid.grids[1][5], "w0": dn.feature_out[0].weight,
+            "b0": dn.feature_out[0].bias, "w_pos1": dn.pos_deform[1].weight, "w_pos3": dn.pos_deform[3].weight,
+            "w_sc1": dn.scales_deform[1].weight, "w_rot3": dn.rotations_deform[3].weight, "b_rot3": dn.rotations_deform[3].bias}
+
+
+def _one_step(device, fused, lambda_dssim, cam_index=1):
+    """One fine-stage iteration from the seeded benchmark state; returns loss, every live gradient (Adam's first moment
+    after ONE step is 0.1 * gradient exactly), the statistics and the radii."""
+    import bench
+    from oracle import cpu_backend
+    ctx = cpu_backend.installed() if device == "cpu" else contextlib.nullcontext()
+    with ctx:
+        scene, g, trainer, op = bench.build_state(CFG, torch.device(device), fused=fused, lambda_dssim=lambda_dssim)
+        assert (trainer.fused is not None) == fused
+        loss = float(trainer.step(5001, cams=[trainer.cams[cam_index]]))
+        if device != "cpu":
+            trainer.drain()
+            torch.cuda.synchronize()
+        t = _tensors(g)
+        grads = {k: (g.optimizer.state[t[k]]["exp_avg"].detach().float().cpu().numpy() * 10.0) for k in LIVE}
+        stats = {"accum": g.xyz_gradient_accum.detach().cpu().numpy().copy(), "denom": g.denom.detach().cpu().numpy().copy(),
+                 "maxr": g.max_radii2D.detach().cpu().numpy().copy()}
+        dead = [n for n, p in g._deformation.named_parameters()
+                if ("opacity_deform" in n or "shs_deform" in n or "timenet" in n) and p in g.optimizer.state
+                and "exp_avg" in g.optimizer.state[p] and float(g.optimizer.state[p]["exp_avg"].abs().sum()) != 0]
+    return loss, grads, stats, dead
+
+
+@pytest.mark.parametrize("lambda_dssim", [0.0, 0.2])
+def test_one_iteration_hip_vs_cpu_oracle(lambda_dssim):
+    ref_loss, ref_g, ref_s, _ = _one_step("cpu", False, lambda_dssim)
+    for fused in (False, True):
+        loss, grads, stats, dead = _one_step("cuda", fused, lambda_dssim)
+        assert not dead, ("dead heads received a gradient", dead)
+        assert abs(loss - ref_loss) <= 2e-6 * max(1.0, abs(ref_loss)), (fused, loss, ref_loss)
+        # statistics: visibility (radius > 0) is integer work and must agree exactly; the accumulated gradient norm is float
+        np.testing.assert_array_equal(stats["denom"], ref_s["denom"])
+        np.testing.assert_array_equal(stats["maxr"], ref_s["maxr"])
+        for k in LIVE:
+            a, b = grads[k], ref_g[k]
+            assert a.shape == b.shape
+            scale = max(float(np.abs(b).max()), 1e-30)
+            err = np.abs(a - b) / scale
+            # every element within 2e-3 of the tensor's scale, 99.9 % of them within 1e-4
+            frac_loose = float((err > 1e-4).mean())
+            assert frac_loose <= 1e-3 and float(err.max()) <= 2e-3, (fused, k, frac_loose, float(err.max()))
+        acc_scale = max(float(np.abs(ref_s["accum"]).max()), 1e-30)
+        e = np.abs(stats["accum"] - ref_s["accum"]) / acc_scale
+        assert float((e > 1e-4).mean()) <= 1e-3 and float(e.max()) <= 2e-3, (fused, float(e.max()))
+
+
+def test_loss_curve_of_config_1_replayed_on_hip():
+    """tests/golden/g10_loss_curve.npz (oracle/make_curve_fixture.py): 50 coarse + 50 fine iterations of BASELINE config 1 on
+    the CPU oracle path.  The same 100 iterations on the HIP path (coarse: autograd path; fine: fused step) must follow the
+    same curve.  Adam with eps = 1e-15 turns a sign flip of a vanishing gradient into a full learning-rate step, so two
+    correct fp32 implementations drift apart slowly: the loss is held to 2e-3 relative over all 100 iterations (1e-4 over the
+    first 5 of each stage), the Gaussian count exactly, the parameter sums to 1e-3 of their absolute sums."""
+    from oracle.make_curve_fixture import run, N_COARSE
+    d = np.load(os.path.join(ROOT, "tests", "golden", "g10_loss_curve.npz"))
+    losses, points, cs, xyz = run("cuda", fused_fine=True)
+    np.testing.assert_array_equal(points, d["points"])
+    ref = d["losses"]
+    rel = np.abs(losses - ref) / np.abs(ref)
+    assert float(rel[:5].max()) <= 1e-4 and float(rel[N_COARSE:N_COARSE + 5].max()) <= 1e-4, (rel[:5], rel[N_COARSE:N_COARSE + 5])
+    assert float(rel.max()) <= 2e-3, (int(rel.argmax()), float(rel.max()))
+    for k in cs:
+        if k.startswith("sum_"):
+            tot = float(d["abs_" + k[4:]])
+            assert abs(cs[k] - float(d[k])) <= 1e-3 * max(tot, 1e-12), (k, cs[k], float(d[k]), tot)
+    np.testing.assert_allclose(xyz, d["xyz_sample"], rtol=0, atol=2e-3)
