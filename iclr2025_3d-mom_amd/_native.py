@@ -93,7 +93,12 @@ def _sig(lib):
     lib.mom_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
     lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
-    lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp, vp]
+    lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_hexplane_backward_scratch_bytes.restype = sz
+    lib.mom_hexplane_backward_scratch_bytes.argtypes = [C.POINTER(MomHexPlane), i32]
+    lib.mom_hexplane_orders_scratch_bytes.restype = sz
+    lib.mom_hexplane_orders_scratch_bytes.argtypes = [i32]
+    lib.mom_hexplane_orders.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, vp, vp, vp]
     lib.mom_morton_order_scratch_bytes.restype = sz
     lib.mom_morton_order_scratch_bytes.argtypes = [i32]
     lib.mom_morton_order.argtypes = [i32, vp, vp, vp, vp]
@@ -146,6 +151,7 @@ EXPORTS = [
     "mom_ssim_forward", "mom_ssim_backward", "mom_raster_backward_render", "mom_raster_backward_geometry",
     "mom_densify_stats", "mom_select_scratch_bytes", "mom_select_plan", "mom_select_apply",
     "mom_ssim_forward_slab", "mom_ssim_backward_slab",
+    "mom_hexplane_backward_scratch_bytes", "mom_hexplane_orders_scratch_bytes", "mom_hexplane_orders",
 ]
 
 

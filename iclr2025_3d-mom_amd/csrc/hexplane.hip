@@ -192,15 +192,7 @@ hexplane_bwd_kernel(HexArgs a, const float* __restrict__ xyz, const float* __res
 }
 
 
-// ---- aggregated backward -------------------------------------------------------------------------------------
-// One timestamp for every point (the render() case).  Two structural facts cut the float-atomic traffic of the
-// generic kernel above (1.2 GB per call at 200k Gaussians, and worse, all of it for the space-time planes lands
-// on just two texel rows):
-//  * space-time planes (x,t) (y,t) (z,t): the t interpolation is the same for every point, so a workgroup sums
-//    S[ix][ch] = sum gv * wx in an LDS line per plane and adds wt0*S / wt1*S to the two global rows once at the end;
-//  * space planes: a half-wave walks a CONTIGUOUS chunk of the (spatially sorted) processing order and keeps, per
-//    plane and corner, a pending texel row in registers; consecutive points that fall on the same texel are summed
-//    there and reach memory as ONE 128-byte atomic row.
+// ---- helpers shared by the chunked kernels -------------------------------------------------------------------
 __device__ __forceinline__ int time_sample(float c, int size, int& i0, int& i1, float& w0, float& w1)
 {
     float gm;
@@ -213,167 +205,18 @@ __device__ __forceinline__ int time_sample(float c, int size, int& i0, int& i1, 
     return 0;
 }
 
-__global__ void __launch_bounds__(256)
-hexplane_bwd_agg_kernel(HexArgs a, int chunk, const float* __restrict__ xyz, const float* __restrict__ dfeat, float* __restrict__ dxyz)
-{
-    extern __shared__ float s_line[];   // [3 space-time planes][Wmax][32]
-    const int ch = threadIdx.x & 31;
-    const int hw = (blockIdx.x * 256 + threadIdx.x) >> 5;          // half-wave id
-    const int begin = hw * chunk, end = min(a.P, begin + chunk);
-    for (int lvl = 0; lvl < a.levels; lvl++) {
-        const int Wx = a.res[lvl][0], Wy = a.res[lvl][1], Wz = a.res[lvl][2], Wt = a.res[lvl][3];
-        const int line_off[3] = {0, Wx * 32, (Wx + Wy) * 32};      // planes 2 (x,t), 4 (y,t), 5 (z,t)
-        const int line_total = (Wx + Wy + Wz) * 32;
-        __syncthreads();
-        for (int i = threadIdx.x; i < line_total; i += 256) s_line[i] = 0.f;
-        __syncthreads();
-        // the shared t interpolation
-        int t0, t1;
-        float wt0, wt1;
-        time_sample(a.time, Wt, t0, t1, wt0, wt1);
-        // pending rows: 3 space planes x 4 corners
-        int pid[3][4];
-        float pacc[3][4];
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int c = 0; c < 4; c++) { pid[p][c] = -1; pacc[p][c] = 0.f; }
-        float* gsp[3] = {a.grads[lvl][0], a.grads[lvl][1], a.grads[lvl][3]};
-        for (int gi = begin; gi < end; gi++) {
-            const int g = a.order ? (int)a.order[gi] : gi;
-            float c[4];
-            norm_coords(a, xyz, g, c);
-            PlaneSample s[6];
-            float v[6], t00[6], t01[6], t10[6], t11[6];
-#pragma unroll
-            for (int p = 0; p < 6; p++) {
-                const int ca = kCombA[p], cb = kCombB[p];
-                s[p] = make_sample(c[ca], c[cb], a.res[lvl][ca], a.res[lvl][cb]);
-                const float* __restrict__ pl = a.planes[lvl][p];
-                t00[p] = s[p].i00 >= 0 ? pl[(size_t)s[p].i00 * 32 + ch] : 0.f;
-                t01[p] = s[p].i01 >= 0 ? pl[(size_t)s[p].i01 * 32 + ch] : 0.f;
-                t10[p] = s[p].i10 >= 0 ? pl[(size_t)s[p].i10 * 32 + ch] : 0.f;
-                t11[p] = s[p].i11 >= 0 ? pl[(size_t)s[p].i11 * 32 + ch] : 0.f;
-                float acc = 0.f;
-                acc += t00[p] * s[p].w00;
-                acc += t01[p] * s[p].w01;
-                acc += t10[p] * s[p].w10;
-                acc += t11[p] * s[p].w11;
-                v[p] = acc;
-            }
-            const float go = dfeat[(size_t)g * (a.levels * 32) + lvl * 32 + ch];
-            float pre[7], suf[7];
-            pre[0] = 1.f;
-#pragma unroll
-            for (int p = 0; p < 6; p++) pre[p + 1] = pre[p] * v[p];
-            suf[6] = 1.f;
-#pragma unroll
-            for (int p = 5; p >= 0; p--) suf[p] = suf[p + 1] * v[p];
-            float gc[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int p = 0; p < 6; p++) {
-                const float gv = go * pre[p] * suf[p + 1];
-                const int ca = kCombA[p], cb = kCombB[p];
-                if (cb == 3) {
-                    // space-time plane: W axis = space coordinate ca, H axis = t (shared)
-                    const int li = p == 2 ? 0 : (p == 4 ? 1 : 2);
-                    const float wx0 = (float)(s[p].ixn + 1) - s[p].ix, wx1 = s[p].ix - (float)s[p].ixn;
-                    const int Wd = a.res[lvl][ca];
-                    if (s[p].ixn >= 0 && s[p].ixn < Wd) atomicAdd(&s_line[line_off[li] + s[p].ixn * 32 + ch], gv * wx0);
-                    if (s[p].ixn + 1 >= 0 && s[p].ixn + 1 < Wd) atomicAdd(&s_line[line_off[li] + (s[p].ixn + 1) * 32 + ch], gv * wx1);
-                } else {
-                    const int si = p == 0 ? 0 : (p == 1 ? 1 : 2);   // planes 0 (x,y), 1 (x,z), 3 (y,z)
-                    const int ids[4] = {s[p].i00, s[p].i01, s[p].i10, s[p].i11};
-                    const float ws[4] = {s[p].w00, s[p].w01, s[p].w10, s[p].w11};
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (ids[k] == pid[si][k]) {
-                            pacc[si][k] += gv * ws[k];
-                        } else {
-                            if (pid[si][k] >= 0) atomicAdd(&gsp[si][(size_t)pid[si][k] * 32 + ch], pacc[si][k]);
-                            pid[si][k] = ids[k];
-                            pacc[si][k] = gv * ws[k];
-                        }
-                    }
-                }
-                // grid gradient (same expressions as the generic kernel)
-                const float x0 = (float)s[p].ixn, y0 = (float)s[p].iyn, x1 = x0 + 1.f, y1 = y0 + 1.f;
-                float gix = 0.f, giy = 0.f;
-                gix -= t00[p] * (y1 - s[p].iy) * gv;
-                giy -= t00[p] * (x1 - s[p].ix) * gv;
-                gix += t01[p] * (y1 - s[p].iy) * gv;
-                giy -= t01[p] * (s[p].ix - x0) * gv;
-                gix -= t10[p] * (s[p].iy - y0) * gv;
-                giy += t10[p] * (x1 - s[p].ix) * gv;
-                gix += t11[p] * (s[p].iy - y0) * gv;
-                giy += t11[p] * (s[p].ix - x0) * gv;
-                if (ca < 3) gc[ca] += gix * s[p].gx_mul;
-                if (cb < 3) gc[cb] += giy * s[p].gy_mul;
-            }
-            if (dxyz) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float tot = half_wave_sum(gc[k]) * (2.0f / (a.a1[k] - a.a0[k]));
-                    if (ch == 0) atomicAdd(&dxyz[3 * g + k], tot);
-                }
-            }
-        }
-        // drain the pending rows
-#pragma unroll
-        for (int p = 0; p < 3; p++)
-#pragma unroll
-            for (int c = 0; c < 4; c++)
-                if (pid[p][c] >= 0) atomicAdd(&gsp[p][(size_t)pid[p][c] * 32 + ch], pacc[p][c]);
-        __syncthreads();
-        // S lines -> the two global rows t0 / t1 of each space-time plane
-        float* gtp[3] = {a.grads[lvl][2], a.grads[lvl][4], a.grads[lvl][5]};
-        const int Wl[3] = {Wx, Wy, Wz};
-#pragma unroll
-        for (int li = 0; li < 3; li++) {
-            for (int i = threadIdx.x; i < Wl[li] * 32; i += 256) {
-                const float sv = s_line[line_off[li] + i];
-                if (sv != 0.f) {
-                    if (t0 >= 0) atomicAdd(&gtp[li][(size_t)t0 * Wl[li] * 32 + i], sv * wt0);
-                    if (t1 >= 0) atomicAdd(&gtp[li][(size_t)t1 * Wl[li] * 32 + i], sv * wt1);
-                }
-            }
-        }
-    }
-}
-
-
 // =================================================================================================================
-// v4 kernels: sample parameters are computed ONCE per (point, level) -- by one lane, in "phase A" of a 64-point
-// chunk -- and parked in LDS as a 16-byte record per plane; "phase B" then walks the chunk with lane = channel and
-// reads each point's records as LDS broadcasts.  This removes the 32-fold replication of the coordinate arithmetic
-// of the kernels above (every channel lane redoes it there).  Workgroups specialise by level (blockIdx.y).
+// Chunked kernels: sample parameters are computed ONCE per (point, level) -- by one lane, in "phase A" of a chunk of
+// points -- and parked in LDS as small records; "phase B" then walks the chunk with lane = channel and reads each
+// point's records as LDS broadcasts.  This removes the 32-fold replication of the coordinate arithmetic of the
+// generic kernels above (every channel lane redoes it there).  Workgroups specialise by level (blockIdx.y).
 //
-// Record of one (point, plane): {off00 | flags, bx, by, x0} with off00 = texel (y0, x0) in floats (a multiple of 32,
+// Record of one (point, plane): {off00 | flags, bx, by, aux} with off00 = texel (y0, x0) in floats (a multiple of 32,
 // so the low bits are free): bit0 = x0+1 is inside, bit1 = y0+1 is inside, bit2 / bit3 = the x / y coordinate was
 // NOT clipped at the border (its gradient multiplier is (size-1)/2, else 0), bit4 = y0 is odd.  bx = ix - x0 and by = iy - y0 are
 // exact; ax = 1 - bx, ay = 1 - by are bit-identical to ATen's (x0+1) - ix (Sterbenz), so the four weights are
 // ATen's.  A corner that is outside gets weight exactly 0 and is redirected to the texel next to it.
 // =================================================================================================================
-#ifdef MOM_DBG_NOGATOM
-#define GATOM(p, v) ((void)(v))
-#else
-#define GATOM(p, v) atomicAdd(p, v)
-#endif
-#ifdef MOM_DBG_NOLATOM
-#define LATOM(p, v) ((void)(v))
-#else
-#define LATOM(p, v) atomicAdd(p, v)
-#endif
-#ifdef MOM_DBG_NOTEX
-#define TEX(pl, o) (__int_as_float(o) * 1e-30f + 0.5f)
-#else
-#define TEX(pl, o) (pl)[o]
-#endif
-#ifdef MOM_DBG_NODFEAT
-#define DFEAT(x) (1e-3f * ch)
-#else
-#define DFEAT(x) (x)
-#endif
 constexpr int kChunk4 = 64;
 
 __device__ __forceinline__ float4 make_rec4(float cx, float cy, int Wd, int Hd)
@@ -447,93 +290,134 @@ hexplane_fwd4_kernel(HexArgs a, int nchunks, const float* __restrict__ xyz, floa
     }
 }
 
-__global__ void __launch_bounds__(256)
-hexplane_bwd4_kernel(HexArgs a, int chunks_per_wave, int nchunks, const float* __restrict__ xyz, const float* __restrict__ dfeat,
-                     float* __restrict__ dxyz)
+// =================================================================================================================
+// Backward, one timestamp for all points (the render() case), in TWO passes.
+//
+// The gradient of a plane texel is a sum over the points around it; the reference (autograd of grid_sample) issues one
+// scatter-add per (point, corner, channel).  Here:
+//
+//  pass 1 (GATHER, points in 3-D Morton order, one half-wave per point, lane = channel): per (point, level) the six plane
+//    samples, their product, and for each plane gv = dfeat * (product of the other five).  Every gv row (128 B) is STORED
+//    -- no atomics, no LDS accumulation in this pass -- at the point's position in the order of the space plane it will be
+//    scattered with.  The position gradient (ATen's grid_sampler_2d backward, regrouped) is reduced over the 32 channels
+//    and added to dxyz.
+//  pass 2 (SCATTER, one launch over the three space planes; points in that plane's own order = sorted by the finest
+//    level's texel cell, 2-D Morton over cells): streams the gv rows sequentially and keeps four pending texel rows per
+//    (plane, level) in registers -- slot = (parity of y, parity of x): a 4-way set that keeps a row while the walk moves to
+//    a neighbouring cell -- issuing one 128-byte row of float atomics only when a row leaves its slot.  All points of a
+//    cell are consecutive, so a row is flushed once per cell visit.  Each space plane carries ONE space-time plane that
+//    shares an axis with it -- (x,y) carries (x,t), (x,z) carries (z,t), (y,z) carries (y,t): in the space plane's order the
+//    shared coordinate's cell changes as rarely as the cell itself, so the space-time plane's line S[x][ch] = sum gv * wx
+//    (the two time rows are the same for every point) accumulates in two pending rows, spills into a per-workgroup LDS line
+//    when a row changes, and is drained with the two time weights at the end of the workgroup.
+//
+// Both passes compute the per-point sample parameters once, by one lane, into LDS records (phase A) and walk the chunk with
+// lane = channel (phase B); everything uniform over the channels (byte offsets, fractions, gradient multipliers, slot
+// permutation) is done in phase A, so phase B is loads, a dozen FMAs per plane and the stores.
+// =================================================================================================================
+constexpr int kChunk5 = 32;            // points per wave and chunk in pass 1: each half-wave walks 16
+
+// order slot (0: (x,y), 1: (x,z), 2: (y,z)) whose sorted position a plane's gv row is stored at
+__device__ __forceinline__ constexpr int order_slot_of_plane(int p) { return p == 0 ? 0 : (p == 1 ? 1 : (p == 2 ? 0 : (p == 3 ? 2 : (p == 4 ? 2 : 1)))); }
+
+// pass-1 record of one (point, plane): R1 = {byte offset of texel (y0, x0), byte step to x0+1 (0 if outside), byte step to
+// y0+1 (0 if outside), byte offset of the point's gv row}; R2 = {bx, by, gx, gy}: the fractions and d(ix)/d(world coordinate)
+// (0 when the coordinate was clipped at the border, and for the time axis)
+__device__ __forceinline__ void make_rec5(float cx, float cy, int Wd, int Hd, unsigned row_off, float gsx, float gsy, uint4& R1, float4& R2)
 {
-    extern __shared__ float s_dyn[];                   // [4][64][6] float4 records | [3 planes][W][32] lines of this level
-    float4* s_recs = reinterpret_cast<float4*>(s_dyn);
-    float* s_line = s_dyn + 4 * kChunk4 * 6 * 4;
+    float gxm, gym;
+    const float ix = unnorm_clip(cx, Wd, gxm), iy = unnorm_clip(cy, Hd, gym);
+    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+    R1 = make_uint4((unsigned)(y0 * Wd + x0) * 128u, (x0 + 1 < Wd) ? 128u : 0u, (y0 + 1 < Hd) ? (unsigned)Wd * 128u : 0u, row_off);
+    R2 = make_float4(ix - (float)x0, iy - (float)y0, gxm != 0.f ? gsx : 0.f, gym != 0.f ? gsy : 0.f);
+}
+
+__device__ __forceinline__ float ld_f32(const float* __restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);     // uniform base + 32-bit lane offset
+}
+
+#ifndef HX_GATHER_WAVES
+#define HX_GATHER_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, HX_GATHER_WAVES)
+hexplane_bwd5_gather_kernel(HexArgs a, int nchunks, const float* __restrict__ xyz, const float* __restrict__ dfeat,
+                            float* __restrict__ dxyz, const uint32_t* __restrict__ inv /* [3][P] */,
+                            float* __restrict__ gvbuf /* [6][P][levels][32] */)
+{
+    __shared__ uint4 s_r1[4][kChunk5][6];
+    __shared__ float4 s_r2[4][kChunk5][6];
     const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     const int lvl = blockIdx.y;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int Wx = a.res[lvl][0], Wy = a.res[lvl][1], Wz = a.res[lvl][2], Wt = a.res[lvl][3];
-    const int line_off[3] = {0, Wx * 32, (Wx + Wy) * 32};
-    const int line_total = (Wx + Wy + Wz) * 32;
-    for (int i = threadIdx.x; i < line_total; i += 256) s_line[i] = 0.f;
-    __syncthreads();
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    const unsigned chb = (unsigned)ch * 4u;
+    const size_t plane_floats = (size_t)a.P * 32;                    // one (plane, level) buffer of gv rows
+    // d(ix)/d(world coordinate) per axis when the coordinate is not clipped: (size-1)/2 * 2/(aabb1 - aabb0)
+    float gscale[4];
+#pragma unroll
+    for (int k = 0; k < 3; k++) gscale[k] = ((float)(a.res[lvl][k] - 1) / 2.f) * (2.0f / (a.a1[k] - a.a0[k]));
+    gscale[3] = 0.f;
 
-    int pid[3][4];
-    float pacc[3][4];
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) { pid[p][c] = -1; pacc[p][c] = 0.f; }
-    int lpid[3][2];
-    float lacc[3][2];
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int c = 0; c < 2; c++) { lpid[p][c] = -1; lacc[p][c] = 0.f; }
-    float* gsp[3] = {a.grads[lvl][0], a.grads[lvl][1], a.grads[lvl][3]};
-    float gmul[4];                                      // d(ix)/d(normalised coord) when not clipped
-#pragma unroll
-    for (int k = 0; k < 4; k++) gmul[k] = (float)(a.res[lvl][k] - 1) / 2.f;
-
-    const int c_begin = wave * chunks_per_wave, c_end = min(nchunks, c_begin + chunks_per_wave);
-    for (int chunk = c_begin; chunk < c_end; chunk++) {
-        const int gi = chunk * kChunk4 + lane;
+    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
+        // phase A: lane j < 32 prepares planes 0..2 of point j, lane 32 + j planes 3..5 of the same point
+        const int gi = chunk * kChunk5 + ch;
         const int g_mine = gi < a.P ? (a.order ? (int)a.order[gi] : gi) : -1;
-        float4* wrec = s_recs + wv * kChunk4 * 6;
         __builtin_amdgcn_wave_barrier();
         if (g_mine >= 0) {
             float c[4];
             norm_coords(a, xyz, g_mine, c);
+            unsigned pos[3];
 #pragma unroll
-            for (int p = 0; p < 6; p++) wrec[lane * 6 + p] = make_rec4(c[kCombA[p]], c[kCombB[p]], a.res[lvl][kCombA[p]], a.res[lvl][kCombB[p]]);
+            for (int k = 0; k < 3; k++) pos[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * 128u;
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const int p0 = q, p1 = 3 + q;            // h == 0: (x,y) (x,z) (x,t); h == 1: (y,z) (y,t) (z,t)
+                const int ca = h ? kCombA[p1] : kCombA[p0], cb = h ? kCombB[p1] : kCombB[p0];
+                const int slot = h ? order_slot_of_plane(p1) : order_slot_of_plane(p0);
+                uint4 R1; float4 R2;
+                make_rec5(c[ca], c[cb], a.res[lvl][ca], a.res[lvl][cb], pos[slot], gscale[ca], gscale[cb], R1, R2);
+                s_r1[wv][ch][3 * h + q] = R1;
+                s_r2[wv][ch][3 * h + q] = R2;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        const int npts = min(kChunk4, a.P - chunk * kChunk4);
-        const int n_half = max(0, min(32, npts - 32 * h));
-        // software pipeline: records + the 24 texel loads + dfeat of point i+1 are in flight while point i is processed
-        float4 nr[6], r[6];
-        float n00[6], n01[6], n10[6], n11[6], t00[6], t01[6], t10[6], t11[6];
-        float go = 0.f, ngo = 0.f;
+        const int npts = min(kChunk5, a.P - chunk * kChunk5);
+        const int n_half = max(0, min(16, npts - 16 * h));     // this half walks points [16h, 16h + n_half)
+        float t00[6], t01[6], t10[6], t11[6];
+        float go = 0.f;
         float dx_mine[3] = {0.f, 0.f, 0.f};
-        int ng = 0;
         auto fetch = [&](int i) {
-            ng = __shfl(g_mine, 32 * h + i);
+            const int ng = __shfl(g_mine, 16 * h + i);
 #pragma unroll
             for (int p = 0; p < 6; p++) {
-                nr[p] = wrec[(32 * h + i) * 6 + p];
-                const int raw = __float_as_int(nr[p].x);
-                const int o00 = raw & ~31, sx = (raw & 1) ? 32 : 0, sy = (raw & 2) ? a.res[lvl][kCombA[p]] * 32 : 0;
-                const float* __restrict__ pl = a.planes[lvl][p] + ch;
-                n00[p] = TEX(pl, o00);
-                n01[p] = TEX(pl, o00 + sx);
-                n10[p] = TEX(pl, o00 + sy);
-                n11[p] = TEX(pl, o00 + sy + sx);
+                const uint4 R1 = s_r1[wv][16 * h + i][p];
+                const float* __restrict__ pl = a.planes[lvl][p];
+                const unsigned o = R1.x + chb;
+                t00[p] = ld_f32(pl, o);
+                t01[p] = ld_f32(pl, o + R1.y);
+                t10[p] = ld_f32(pl, o + R1.z);
+                t11[p] = ld_f32(pl, o + R1.y + R1.z);
             }
-            ngo = DFEAT(dfeat[(size_t)ng * (a.levels * 32) + lvl * 32 + ch]);
+            go = dfeat[(size_t)ng * (a.levels * 32) + lvl * 32 + ch];
         };
         if (n_half > 0) fetch(0);
         for (int i = 0; i < n_half; i++) {
-            go = ngo;
-#pragma unroll
-            for (int p = 0; p < 6; p++) { r[p] = nr[p]; t00[p] = n00[p]; t01[p] = n01[p]; t10[p] = n10[p]; t11[p] = n11[p]; }
-            if (i + 1 < n_half) fetch(i + 1);
-            Corner4 c[6];
-            float v[6];
+            // first half of the iteration: consume the texels (bilinear sample and the two raw position derivatives per plane);
+            // after it the 24 texel registers are dead and the next point's loads can land in them while the second half runs
+            float v[6], dgx[6], dgy[6];
 #pragma unroll
             for (int p = 0; p < 6; p++) {
-                c[p] = decode4(r[p], a.res[lvl][kCombA[p]]);
-                float acc = 0.f;
-                acc += t00[p] * c[p].w00;
-                acc += t01[p] * c[p].w01;
-                acc += t10[p] * c[p].w10;
-                acc += t11[p] * c[p].w11;
-                v[p] = acc;
+                const float4 R2 = s_r2[wv][16 * h + i][p];
+                const float d0 = t01[p] - t00[p], d1 = t11[p] - t10[p];
+                const float tx0 = __builtin_fmaf(R2.x, d0, t00[p]), tx1 = __builtin_fmaf(R2.x, d1, t10[p]);
+                const float dy = tx1 - tx0;                          // = ax (t10 - t00) + bx (t11 - t01): d sample / d iy
+                v[p] = __builtin_fmaf(R2.y, dy, tx0);
+                dgx[p] = __builtin_fmaf(R2.y, d1 - d0, d0) * R2.z;   // (ay (t01 - t00) + by (t11 - t10)) * d ix / d coord
+                dgy[p] = dy * R2.w;
             }
+            const float gcur = go;
+            const int icur = i;
+            if (i + 1 < n_half) fetch(i + 1);
             float pre[7], suf[7];
             pre[0] = 1.f;
 #pragma unroll
@@ -544,118 +428,248 @@ hexplane_bwd4_kernel(HexArgs a, int chunks_per_wave, int nchunks, const float* _
             float gc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < 6; p++) {
-                const float gv = go * pre[p] * suf[p + 1];
+                const float gv = gcur * (pre[p] * suf[p + 1]);
                 const int ca = kCombA[p], cb = kCombB[p];
-                const int raw = __float_as_int(r[p].x);
-                const bool has_x1 = raw & 1, has_y1 = raw & 2;
-                if (cb == 3) {
-                    // space-time plane: sum gv * (x weights) into the level's LDS line; the t weights are applied at the end
-                    // consecutive points (Morton order) mostly share x0: keep the two line rows in registers and
-                    // touch LDS only when the row changes
-                    const int li = p == 2 ? 0 : (p == 4 ? 1 : 2);
-                    const int x0 = __float_as_int(r[p].w);
-                    // a pending row sits in the slot of its PARITY, so it keeps its slot when the walk moves to the next column
-                    // (rows x0 and x0 + 1 always have different parities): slot k takes corner k ^ (x0 & 1)
-                    const bool odd_x = x0 & 1;
-                    const int id_a = x0, id_b = has_x1 ? x0 + 1 : -2;
-                    const float w_a = gv * c[p].ax, w_b = gv * c[p].bx;
-                    const int lid[2] = {odd_x ? id_b : id_a, odd_x ? id_a : id_b};
-                    const float lw[2] = {odd_x ? w_b : w_a, odd_x ? w_a : w_b};
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        if (lid[k] == lpid[li][k]) {
-                            lacc[li][k] += lw[k];
-                        } else if (lid[k] >= 0) {
-                            if (lpid[li][k] >= 0) LATOM(&s_line[line_off[li] + lpid[li][k] * 32 + ch], lacc[li][k]);
-                            lpid[li][k] = lid[k];
-                            lacc[li][k] = lw[k];
-                        }
-                    }
-                } else {
-                    const int si = p == 0 ? 0 : (p == 1 ? 1 : 2);
-                    // corners outside the plane carry weight 0: give them id -2 so that they never start a row
-                    // A pending row sits in the slot (parity of its y, parity of its x).  The four corners of a texel always take
-                    // four different slots, and a row keeps its slot when the walk moves to a neighbouring texel, so e.g. after
-                    // x0 -> x0 + 1 the two rows of column x0 + 1 stay pending instead of being flushed and restarted: exactly the
-                    // flush count of a 4-way associative set (tools/sim_hexplane_runs.py: 40 % fewer rows than one slot per
-                    // corner).  Slot k takes corner k ^ s, s = 2 (y0 & 1) + (x0 & 1): two conditional swap stages.
-                    int ids[4] = {c[p].o00, has_x1 ? c[p].o01 : -2, has_y1 ? c[p].o10 : -2, (has_x1 && has_y1) ? c[p].o11 : -2};
-                    float ws[4] = {c[p].w00, c[p].w01, c[p].w10, c[p].w11};
-                    {
-                        const bool sx1 = __float_as_int(r[p].w) & 1, sy1 = raw & 16;
-                        const int i0 = sx1 ? ids[1] : ids[0], i1 = sx1 ? ids[0] : ids[1], i2 = sx1 ? ids[3] : ids[2], i3 = sx1 ? ids[2] : ids[3];
-                        const float f0 = sx1 ? ws[1] : ws[0], f1 = sx1 ? ws[0] : ws[1], f2 = sx1 ? ws[3] : ws[2], f3 = sx1 ? ws[2] : ws[3];
-                        ids[0] = sy1 ? i2 : i0; ids[1] = sy1 ? i3 : i1; ids[2] = sy1 ? i0 : i2; ids[3] = sy1 ? i1 : i3;
-                        ws[0] = sy1 ? f2 : f0; ws[1] = sy1 ? f3 : f1; ws[2] = sy1 ? f0 : f2; ws[3] = sy1 ? f1 : f3;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (ids[k] == pid[si][k]) {
-                            pacc[si][k] += gv * ws[k];
-                        } else if (ids[k] >= 0) {
-                            if (pid[si][k] >= 0) GATOM(&gsp[si][(size_t)pid[si][k] + ch], pacc[si][k]);
-                            pid[si][k] = ids[k];
-                            pacc[si][k] = gv * ws[k];
-                        }
-                    }
-                }
-                // grid gradient (ATen grid_sampler_2d backward); out-of-plane corners have value 0 there
-                const float v01 = has_x1 ? t01[p] : 0.f, v10 = has_y1 ? t10[p] : 0.f, v11 = (has_x1 && has_y1) ? t11[p] : 0.f;
-                float gix = 0.f, giy = 0.f;
-                gix -= t00[p] * c[p].ay * gv;
-                giy -= t00[p] * c[p].ax * gv;
-                gix += v01 * c[p].ay * gv;
-                giy -= v01 * c[p].bx * gv;
-                gix -= v10 * c[p].by * gv;
-                giy += v10 * c[p].ax * gv;
-                gix += v11 * c[p].by * gv;
-                giy += v11 * c[p].bx * gv;
-                if (ca < 3) gc[ca] += gix * ((raw & 4) ? gmul[ca] : 0.f);
-                if (cb < 3) gc[cb] += giy * ((raw & 8) ? gmul[cb] : 0.f);
+                float* __restrict__ dst = gvbuf + ((size_t)p * a.levels + lvl) * plane_floats;          // uniform
+                *reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (s_r1[wv][16 * h + icur][p].w + chb)) = gv;
+                gc[ca] = __builtin_fmaf(gv, dgx[p], gc[ca]);
+                if (cb < 3) gc[cb] = __builtin_fmaf(gv, dgy[p], gc[cb]);
             }
             if (dxyz) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const float tot = half_wave_sum(gc[k]) * (2.0f / (a.a1[k] - a.a0[k]));
-                    if (ch == i) dx_mine[k] = tot;                       // lane i of the half keeps point i's total
+                    const float tot = half_wave_sum(gc[k]);
+                    if (ch == icur) dx_mine[k] = tot;                    // lane i of the half keeps point 16h + i's total
                 }
             }
         }
-        // lane (32h + i) holds point (32h + i) == its own phase-A point: one wave-wide add per component
-        if (dxyz && g_mine >= 0) {
+        if (dxyz) {
+            const int gp = __shfl(g_mine, 16 * h + (ch & 15));           // lanes 0..15 of each half: point 16h + ch
+            if (ch < n_half && gp >= 0) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) GATOM(&dxyz[3 * g_mine + k], dx_mine[k]);   // the other level adds its share too
+                for (int k = 0; k < 3; k++) atomicAdd(&dxyz[3 * gp + k], dx_mine[k]);   // the other levels add their share too
+            }
+        }
+    }
+}
+
+// pass 2: blockIdx.y = order slot (0: (x,y) + (x,t), 1: (x,z) + (z,t), 2: (y,z) + (y,t)); blockIdx.z = level.  Every level has
+// its own orders (its cells do not nest in the finer level's: align_corners scales by size - 1).  Each HALF-wave walks its own
+// contiguous range of sorted positions.
+constexpr int kChunk5s = 32;           // sorted positions per half-wave and chunk
+constexpr int kBatch5s = 16;           // gv rows in flight per lane and plane
+constexpr int kRec5s = 4 + 4 + 4 + 2;  // dwords of one pass-2 record: int4 ids | float4 ws | float4 {lw0, lw1, flag, -} | int2 ride ids
+
+__global__ void __launch_bounds__(256)
+hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ xyz,
+                             const uint32_t* __restrict__ order /* [3][levels][P] */, const float* __restrict__ gvbuf)
+{
+    extern __shared__ float s_dyn5[];                  // [4 waves] x (int4 ids[64] | float4 ws[64] | float4 rd[64] | int2 rid[64]) | line [W][32]
+    constexpr int kPer = 64 * kRec5s;                  // dwords per wave
+    float* s_line = s_dyn5 + 4 * kPer;
+    const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int si = blockIdx.y, lvl = blockIdx.z;
+    const int p = si == 0 ? 0 : (si == 1 ? 1 : 3), ca = si == 2 ? 1 : 0, cb = si == 0 ? 1 : 2;
+    const int pt = si == 0 ? 2 : (si == 1 ? 5 : 4);    // the space-time plane carried along: shares axis `cs` with this plane
+    const bool ride_on_b = si == 1;                     // (x,z) carries (z,t): the shared axis is this plane's second one
+    const int cs = ride_on_b ? cb : ca;
+    const int Wd = a.res[lvl][ca], Hd = a.res[lvl][cb], Ws = a.res[lvl][cs];
+    float* __restrict__ gp = a.grads[lvl][p] + ch;
+    const size_t plane_floats = (size_t)a.P * 32;
+    const float* __restrict__ src_s = gvbuf + ((size_t)p * a.levels + lvl) * plane_floats + ch;
+    const float* __restrict__ src_t = gvbuf + ((size_t)pt * a.levels + lvl) * plane_floats + ch;
+    const uint32_t* __restrict__ ord = order + ((size_t)si * a.levels + lvl) * a.P;
+    const float lo_a = a.a0[ca], sc_a = 2.0f / (a.a1[ca] - a.a0[ca]), lo_b = a.a0[cb], sc_b = 2.0f / (a.a1[cb] - a.a0[cb]);
+    float* __restrict__ my_line = s_line + ch;
+    for (int i = threadIdx.x; i < Ws * 32; i += 256) s_line[i] = 0.f;
+    __syncthreads();
+
+    int pid[4] = {-1, -1, -1, -1};
+    float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+    int lpid[2] = {-1, -1};
+    float lacc[2] = {0.f, 0.f};
+    int prev_cell = -1, prev_row = -1;                  // of the position before this chunk (uniform per half-wave)
+    // this half-wave's contiguous range of sorted positions
+    const long long hw = ((long long)blockIdx.x * 4 + wv) * 2 + h;
+    const long long r_begin = hw * per_half;
+    const int r_end = (int)(r_begin + per_half < (long long)a.P ? r_begin + per_half : (long long)a.P);
+    float* rec = s_dyn5 + wv * kPer;
+    int4* w_ids = reinterpret_cast<int4*>(rec);
+    float4* w_ws = reinterpret_cast<float4*>(rec + 4 * 64);
+    float4* w_rd = reinterpret_cast<float4*>(rec + 8 * 64);
+    int2* w_rid = reinterpret_cast<int2*>(rec + 12 * 64);
+    for (long long base_ll = r_begin; base_ll < r_end; base_ll += kChunk5s) {
+        const int base = (int)base_ll;
+        const int npts = min(kChunk5s, r_end - base);
+        // phase A: lane (32 h + j) prepares position base + j of its half: corner ids and weights, already permuted into their
+        // slots.  Slot k takes corner k ^ s, s = 2 (y0 & 1) + (x0 & 1): the four corners of a texel always take four different
+        // slots and a row keeps its slot when the walk moves to a neighbouring texel.  The carried plane's two line rows take the
+        // slot of their parity the same way.  A position whose cell (ride row) equals its predecessor's, both with every corner
+        // inside, gets flag bit 0 (1) clear: phase B then only accumulates, without looking at the ids.
+        __builtin_amdgcn_wave_barrier();
+        {
+            const bool on = ch < npts;
+            const int g = (int)ord[base + (on ? ch : 0)];
+            const float cx = (xyz[3 * g + ca] - lo_a) * sc_a - 1.0f, cy = (xyz[3 * g + cb] - lo_b) * sc_b - 1.0f;
+            float gxm, gym;
+            const float ix = unnorm_clip(cx, Wd, gxm), iy = unnorm_clip(cy, Hd, gym);
+            const int x0 = (int)floorf(ix), y0 = (int)floorf(iy);
+            const bool hx = x0 + 1 < Wd, hy = y0 + 1 < Hd;
+            const int o00 = (y0 * Wd + x0) * 32;
+            const float bx = ix - (float)x0, by = iy - (float)y0, ax = 1.f - bx, ay = 1.f - by;
+            const int ids[4] = {o00, hx ? o00 + 32 : -2, hy ? o00 + Wd * 32 : -2, (hx && hy) ? o00 + Wd * 32 + 32 : -2};
+            const float ws[4] = {ax * ay, bx * ay, ax * by, bx * by};
+            const bool sx1 = x0 & 1, sy1 = y0 & 1;
+            const int i0 = sx1 ? ids[1] : ids[0], i1 = sx1 ? ids[0] : ids[1], i2 = sx1 ? ids[3] : ids[2], i3 = sx1 ? ids[2] : ids[3];
+            const float f0 = sx1 ? ws[1] : ws[0], f1 = sx1 ? ws[0] : ws[1], f2 = sx1 ? ws[3] : ws[2], f3 = sx1 ? ws[2] : ws[3];
+            // carried plane: rows r0 (weight 1 - b) and r0 + 1 (weight b) along the shared axis
+            const int r0 = ride_on_b ? y0 : x0;
+            const bool hr = ride_on_b ? hy : hx;
+            const float bw = ride_on_b ? by : bx, aw = 1.f - bw;
+            const bool odd = r0 & 1;
+            const int ra = r0 * 32, rb = hr ? (r0 + 1) * 32 : -2;
+            // run detection: a position with a corner outside gets a unique negative value, so neither it nor its successor
+            // compares equal
+            const int cell = (hx && hy) ? o00 : -2 - ch, row = hr ? r0 : -2 - ch;
+            int pc = __shfl_up(cell, 1), pr = __shfl_up(row, 1);
+            if (ch == 0) { pc = prev_cell; pr = prev_row; }
+            const int flag = (cell != pc ? 1 : 0) | (row != pr ? 2 : 0);
+            prev_cell = __shfl(cell, 32 * h + max(npts, 1) - 1);
+            prev_row = __shfl(row, 32 * h + max(npts, 1) - 1);
+            if (on) {
+                w_ids[lane] = make_int4(sy1 ? i2 : i0, sy1 ? i3 : i1, sy1 ? i0 : i2, sy1 ? i1 : i3);
+                w_ws[lane] = make_float4(sy1 ? f2 : f0, sy1 ? f3 : f1, sy1 ? f0 : f2, sy1 ? f1 : f3);
+                w_rd[lane] = make_float4(odd ? bw : aw, odd ? aw : bw, __int_as_float(flag), 0.f);
+                w_rid[lane] = make_int2(odd ? rb : ra, odd ? ra : rb);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // phase B: the gv rows of this order are consecutive in memory: a batch is loaded, then consumed with no vector-memory
+        // wait inside (the rare atomics never sit between a load and its use)
+        for (int b0 = 0; b0 < npts; b0 += kBatch5s) {
+            float val[kBatch5s], vat[kBatch5s];
+#pragma unroll
+            for (int j = 0; j < kBatch5s; j++) {
+                const int q = min(b0 + j, npts - 1);
+                val[j] = src_s[(size_t)(base + q) * 32];
+                vat[j] = src_t[(size_t)(base + q) * 32];
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch5s; j++) {
+                if (b0 + j >= npts) continue;
+                const float4 w4 = w_ws[32 * h + b0 + j];
+                const float4 rd = w_rd[32 * h + b0 + j];
+                const int flag = __float_as_int(rd.z);
+                const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+                const float lw[2] = {rd.x, rd.y};
+                if (flag & 1) {
+                    // the cell changed (or touches the border): a slot whose row differs flushes its pending row and restarts
+                    const int4 id4 = w_ids[32 * h + b0 + j];
+                    const int ids[4] = {id4.x, id4.y, id4.z, id4.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (ids[k] == pid[k]) {
+                            pacc[k] = __builtin_fmaf(val[j], ws[k], pacc[k]);
+                        } else if (ids[k] >= 0) {
+                            if (pid[k] >= 0) atomicAdd(&gp[pid[k]], pacc[k]);
+                            pid[k] = ids[k];
+                            pacc[k] = val[j] * ws[k];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pacc[k] = __builtin_fmaf(val[j], ws[k], pacc[k]);
+                }
+                if (flag & 2) {
+                    const int2 r2 = w_rid[32 * h + b0 + j];
+                    const int lid[2] = {r2.x, r2.y};
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        if (lid[k] == lpid[k]) {
+                            lacc[k] = __builtin_fmaf(vat[j], lw[k], lacc[k]);
+                        } else if (lid[k] >= 0) {
+                            if (lpid[k] >= 0) atomicAdd(&my_line[lpid[k]], lacc[k]);
+                            lpid[k] = lid[k];
+                            lacc[k] = vat[j] * lw[k];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 2; k++) lacc[k] = __builtin_fmaf(vat[j], lw[k], lacc[k]);
+                }
+            }
         }
     }
 #pragma unroll
-    for (int p = 0; p < 3; p++)
+    for (int k = 0; k < 4; k++)
+        if (pid[k] >= 0) atomicAdd(&gp[pid[k]], pacc[k]);
 #pragma unroll
-        for (int c = 0; c < 4; c++)
-            if (pid[p][c] >= 0) GATOM(&gsp[p][(size_t)pid[p][c] + ch], pacc[p][c]);
-#pragma unroll
-    for (int p = 0; p < 3; p++)
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-            if (lpid[p][c] >= 0) LATOM(&s_line[line_off[p] + lpid[p][c] * 32 + ch], lacc[p][c]);
+    for (int k = 0; k < 2; k++)
+        if (lpid[k] >= 0) atomicAdd(&my_line[lpid[k]], lacc[k]);
     __syncthreads();
-    // S lines -> the two global rows t0 / t1 of each space-time plane
+    // the carried plane's line -> its two global time rows t0 / t1 (the same for every point)
     int t0, t1;
     float wt0, wt1;
-    time_sample(a.time, Wt, t0, t1, wt0, wt1);
-    float* gtp[3] = {a.grads[lvl][2], a.grads[lvl][4], a.grads[lvl][5]};
-    const int Wl[3] = {Wx, Wy, Wz};
-#pragma unroll
-    for (int li = 0; li < 3; li++)
-        for (int i = threadIdx.x; i < Wl[li] * 32; i += 256) {
-            const float sv = s_line[line_off[li] + i];
-            if (sv != 0.f) {
-                if (t0 >= 0) GATOM(&gtp[li][(size_t)t0 * Wl[li] * 32 + i], sv * wt0);
-                if (t1 >= 0) GATOM(&gtp[li][(size_t)t1 * Wl[li] * 32 + i], sv * wt1);
-            }
+    time_sample(a.time, a.res[lvl][3], t0, t1, wt0, wt1);
+    float* __restrict__ gt = a.grads[lvl][pt];
+    for (int i = threadIdx.x; i < Ws * 32; i += 256) {
+        const float sv = s_line[i];
+        if (sv != 0.f) {
+            if (t0 >= 0) atomicAdd(&gt[(size_t)t0 * Ws * 32 + i], sv * wt0);
+            if (t1 >= 0) atomicAdd(&gt[(size_t)t1 * Ws * 32 + i], sv * wt1);
         }
+    }
+}
+
+// sort key of a point for one space plane: 2-D Morton code of the texel cell it falls into at resolution (Wd, Hd)
+__device__ __forceinline__ unsigned spread16(unsigned x)
+{
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+__global__ void __launch_bounds__(256)
+plane_key_kernel(HexArgs a, int ca, int cb, int Wd, int Hd, const float* __restrict__ xyz, unsigned* __restrict__ keys,
+                 unsigned* __restrict__ idx)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.P) return;
+    const float cx = (xyz[3 * i + ca] - a.a0[ca]) * (2.0f / (a.a1[ca] - a.a0[ca])) - 1.0f;
+    const float cy = (xyz[3 * i + cb] - a.a0[cb]) * (2.0f / (a.a1[cb] - a.a0[cb])) - 1.0f;
+    float gm;
+    const int x0 = (int)floorf(unnorm_clip(cx, Wd, gm)), y0 = (int)floorf(unnorm_clip(cy, Hd, gm));
+    keys[i] = spread16((unsigned)x0) | (spread16((unsigned)y0) << 1);
+    idx[i] = (unsigned)i;
+}
+__global__ void __launch_bounds__(256)
+invert_perm_kernel(int n, const unsigned* __restrict__ order, unsigned* __restrict__ order_out, unsigned* __restrict__ inv)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned g = order[i];
+    order_out[i] = g;
+    inv[g] = (unsigned)i;
 }
 
 }  // namespace
+
+// stable LSD radix sort of (u32 key, u32 value) pairs on the low `bits` bits (knn.hip); returns the index (0 / 1) of the
+// buffer pair that holds the result, or a negative MOM_E* code
+int mom_sort_pairs_u32(int n, int bits, unsigned* keys[2], unsigned* vals[2], unsigned* counts, hipStream_t s);
+size_t mom_sort_pairs_counts_bytes(int n);
+
+static void fill_args(const MomHexPlane* hp, int P, const float* times, float time, const uint32_t* order, bool grads, HexArgs* a)
+{
+    a->P = P; a->levels = hp->levels; a->time = time; a->times = times; a->order = order;
+    for (int l = 0; l < 4; l++)
+        for (int k = 0; k < 4; k++) a->res[l][k] = hp->res[l][k];
+    for (int l = 0; l < 4; l++)
+        for (int p = 0; p < 6; p++) { a->planes[l][p] = hp->planes[l][p]; a->grads[l][p] = grads ? hp->grads[l][p] : nullptr; }
+    for (int k = 0; k < 3; k++) { a->a0[k] = hp->aabb[k]; a->a1[k] = hp->aabb[3 + k]; }
+}
 
 extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
                                     const uint32_t* order, float* feat, mom_stream_t stream)
@@ -664,15 +678,10 @@ extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* x
     if (P == 0) return MOM_OK;
     if (!xyz || !feat) return MOM_EINVAL;
     HexArgs a;
-    a.P = P; a.levels = hp->levels; a.time = time; a.times = times; a.order = order;
-    for (int l = 0; l < 4; l++)
-        for (int k = 0; k < 4; k++) a.res[l][k] = hp->res[l][k];
-    for (int l = 0; l < 4; l++)
-        for (int p = 0; p < 6; p++) { a.planes[l][p] = hp->planes[l][p]; a.grads[l][p] = nullptr; }
-    for (int k = 0; k < 3; k++) { a.a0[k] = hp->aabb[k]; a.a1[k] = hp->aabb[3 + k]; }
+    fill_args(hp, P, times, time, order, false, &a);
     const long long units = (long long)P * hp->levels;
     MomProfScope ps(MOM_P_HEX_FWD, (hipStream_t)stream);
-    if (!getenv("MOM_HEX_V1")) {
+    if (!times) {
         const int nchunks = (P + kChunk4 - 1) / kChunk4;
         int blocks = (nchunks + 3) / 4;
         if (blocks > 1024) blocks = 1024;
@@ -683,63 +692,110 @@ extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* x
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
+extern "C" size_t mom_hexplane_orders_scratch_bytes(int P)
+{
+    const size_t n = (size_t)(P > 0 ? P : 1);
+    return 4 * mom_align_up(n * 4) + mom_align_up(mom_sort_pairs_counts_bytes(P)) + MOM_ALIGN;
+}
+
+extern "C" int mom_hexplane_orders(const MomHexPlane* hp, int P, const float* xyz, uint32_t* order, uint32_t* inverse, void* scratch,
+                                   mom_stream_t stream)
+{
+    if (!hp || hp->levels < 1 || hp->levels > 4 || P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!xyz || !order || !inverse || !scratch) return MOM_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    HexArgs a;
+    fill_args(hp, P, nullptr, 0.f, nullptr, false, &a);
+    const size_t n = (size_t)P;
+    char* base = mom_align_ptr(scratch);
+    unsigned* keys[2]; unsigned* vals[2];
+    keys[0] = (unsigned*)base; base += mom_align_up(n * 4);
+    keys[1] = (unsigned*)base; base += mom_align_up(n * 4);
+    vals[0] = (unsigned*)base; base += mom_align_up(n * 4);
+    vals[1] = (unsigned*)base; base += mom_align_up(n * 4);
+    unsigned* counts = (unsigned*)base;
+    // one order per (space plane, level): a level's cells do not nest in a finer level's (align_corners scales by size - 1)
+    const int axes[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int si = 0; si < 3; si++)
+        for (int l = 0; l < hp->levels; l++) {
+            const int ca = axes[si][0], cb = axes[si][1], Wd = hp->res[l][ca], Hd = hp->res[l][cb];
+            if (Wd < 1 || Hd < 1 || Wd > 65536 || Hd > 65536) return MOM_EINVAL;
+            int bits = 0;
+            while ((1 << bits) < (Wd > Hd ? Wd : Hd)) bits++;
+            hipLaunchKernelGGL(plane_key_kernel, dim3((P + 255) / 256), dim3(256), 0, s, a, ca, cb, Wd, Hd, xyz, keys[0], vals[0]);
+            const int cur = mom_sort_pairs_u32(P, 2 * bits, keys, vals, counts, s);
+            if (cur < 0) return cur;
+            const size_t off = ((size_t)si * hp->levels + l) * n;
+            hipLaunchKernelGGL(invert_perm_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, vals[cur], order + off, inverse + off);
+        }
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
+extern "C" size_t mom_hexplane_backward_scratch_bytes(const MomHexPlane* hp, int P)
+{
+    if (!hp || P <= 0) return MOM_ALIGN;
+    return (size_t)6 * (size_t)P * (size_t)hp->levels * 32 * sizeof(float) + MOM_ALIGN;
+}
+
 extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
-                                     const uint32_t* order, const float* dfeat, float* dxyz, mom_stream_t stream)
+                                     const uint32_t* order, const float* dfeat, float* dxyz, const uint32_t* plane_order,
+                                     const uint32_t* plane_inverse, void* scratch, mom_stream_t stream)
 {
     if (!hp || hp->channels != 32 || hp->levels < 1 || hp->levels > 4 || P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!xyz || !dfeat) return MOM_EINVAL;
     HexArgs a;
-    a.P = P; a.levels = hp->levels; a.time = time; a.times = times; a.order = order;
-    for (int l = 0; l < 4; l++)
-        for (int k = 0; k < 4; k++) a.res[l][k] = hp->res[l][k];
-    for (int l = 0; l < 4; l++)
-        for (int p = 0; p < 6; p++) {
-            a.planes[l][p] = hp->planes[l][p];
-            a.grads[l][p] = hp->grads[l][p];
-            if (l < hp->levels && (!a.planes[l][p] || !a.grads[l][p])) return MOM_EINVAL;
-        }
-    for (int k = 0; k < 3; k++) { a.a0[k] = hp->aabb[k]; a.a1[k] = hp->aabb[3 + k]; }
+    fill_args(hp, P, times, time, order, true, &a);
+    for (int l = 0; l < hp->levels; l++)
+        for (int p = 0; p < 6; p++)
+            if (!a.planes[l][p] || !a.grads[l][p]) return MOM_EINVAL;
     const long long units = (long long)P * hp->levels;
     MomProfScope ps(MOM_P_HEX_BWD, (hipStream_t)stream);
-    // aggregated path: one shared timestamp and space-time lines that fit in LDS
     int wmax = 0;
-    for (int l = 0; l < hp->levels; l++) {
-        const int w = hp->res[l][0] + hp->res[l][1] + hp->res[l][2];
-        if (w > wmax) wmax = w;
-    }
-    const size_t lds_bytes = (size_t)wmax * 32 * sizeof(float);
-    const size_t lds4 = sizeof(float) * ((size_t)4 * kChunk4 * 6 * 4 + (size_t)wmax * 32);
-    if (!times && lds4 <= 160 * 1024 && !getenv("MOM_HEX_V2")) {
+    for (int l = 0; l < hp->levels; l++)
+        for (int k = 0; k < 3; k++)
+            if (hp->res[l][k] > wmax) wmax = hp->res[l][k];
+    const size_t lds_s = sizeof(float) * ((size_t)4 * 64 * kRec5s + (size_t)wmax * 32);
+    // gv rows are addressed with 32-bit byte offsets inside one (plane, level) buffer
+    const bool fits32 = (unsigned long long)P * 128ull < (1ull << 32);
+    if (!times && plane_order && plane_inverse && scratch && lds_s <= 160 * 1024 && fits32) {
+        // two-pass path: one shared timestamp, per-plane orders and the gv scratch given
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(hexplane_bwd4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(hexplane_bwd5_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess)
                 return MOM_ELAUNCH;
             attr_set = true;
         }
-        const int nchunks = (P + kChunk4 - 1) / kChunk4;
-        static int blocks4 = 0;
-        if (!blocks4) {
+        float* gvbuf = (float*)mom_align_ptr(scratch);
+        static int blocks_g = 0, blocks_s = 0;
+        if (!blocks_g) {
             const char* e = getenv("MOM_HEX_BLOCKS");
-            blocks4 = e ? atoi(e) : 768;
+            blocks_g = e ? atoi(e) : 1536;
+            const char* e2 = getenv("MOM_HEX_SBLOCKS");
+            blocks_s = e2 ? atoi(e2) : 512;
         }
-        const int waves = blocks4 * 4;
-        const int cpw = (nchunks + waves - 1) / waves;     // contiguous chunks per wave (run-length aggregation)
-        hipLaunchKernelGGL(hexplane_bwd4_kernel, dim3(blocks4, hp->levels), dim3(256), lds4, (hipStream_t)stream, a, cpw, nchunks, xyz,
-                           dfeat, dxyz);
+        {
+            const int nchunks = (P + kChunk5 - 1) / kChunk5;
+            int blocks = (nchunks + 3) / 4;
+            if (blocks > blocks_g) blocks = blocks_g;
+            hipLaunchKernelGGL(hexplane_bwd5_gather_kernel, dim3(blocks, hp->levels), dim3(256), 0, (hipStream_t)stream, a, nchunks, xyz,
+                               dfeat, dxyz, plane_inverse, gvbuf);
+            if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+        }
+        {
+            // every half-wave walks one contiguous range of sorted positions (a multiple of the chunk size)
+            const int halves = blocks_s * 8;
+            int per_half = (P + halves - 1) / halves;
+            per_half = ((per_half + kChunk5s - 1) / kChunk5s) * kChunk5s;
+            const int blocks = (int)(((long long)P + (long long)per_half * 8 - 1) / ((long long)per_half * 8));
+            hipLaunchKernelGGL(hexplane_bwd5_scatter_kernel, dim3(blocks, 3, hp->levels), dim3(256), lds_s, (hipStream_t)stream, a,
+                               per_half, xyz, plane_order, gvbuf);
+        }
         return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
     }
-    if (!times && lds_bytes <= 64 * 1024) {
-        static int blocks = 0;                        // persistent half-waves walking contiguous chunks of the order
-        if (!blocks) {
-            const char* e = getenv("MOM_HEX_BLOCKS");
-            blocks = e ? atoi(e) : 512;
-        }
-        const int chunk = (P + blocks * 8 - 1) / (blocks * 8);
-        hipLaunchKernelGGL(hexplane_bwd_agg_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, a, chunk, xyz, dfeat, dxyz);
-        return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
-    }
+    // generic path (per-point timestamps, or no orders / scratch given): one half-wave per (point, level), 24 atomic rows each
     hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)((units + 7) / 8)), dim3(256), 0, (hipStream_t)stream, a, xyz, dfeat, dxyz);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

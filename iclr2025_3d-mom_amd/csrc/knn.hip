@@ -230,6 +230,27 @@ __global__ void __launch_bounds__(256) box_mean_dist_kernel(int P, const float* 
 
 }  // namespace
 
+// stable LSD radix sort of (u32 key, u32 value) pairs on the low `bits` bits, 8 per pass; keys[0] / vals[0] hold the input,
+// the pair of buffers holding the result is returned (0 / 1).  counts: mom_sort_pairs_counts_bytes(n) bytes.
+size_t mom_sort_pairs_counts_bytes(int n)
+{
+    const size_t nb = ((size_t)(n > 0 ? n : 1) + kSortItems - 1) / kSortItems;
+    return 256 * nb * 4;
+}
+int mom_sort_pairs_u32(int n, int bits, unsigned* keys[2], unsigned* vals[2], unsigned* counts, hipStream_t s)
+{
+    const int nb = (int)(((size_t)n + kSortItems - 1) / kSortItems);
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nb), dim3(256), 0, s, n, nb, shift, keys[cur], counts);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, 256 * nb, counts);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nb), dim3(256), 0, s, n, nb, shift, keys[cur], vals[cur], counts, keys[cur ^ 1],
+                           vals[cur ^ 1]);
+        cur ^= 1;
+    }
+    return hipGetLastError() == hipSuccess ? cur : MOM_ELAUNCH;
+}
+
 extern "C" size_t mom_knn_scratch_bytes(int P)
 {
     const size_t n = (size_t)(P > 0 ? P : 1);

@@ -138,6 +138,7 @@ class FusedStep:
         time = float(cam.time)
         order = field._processing_order(xyz)
         optr = None if order is None else order.data_ptr()
+        porders = field._plane_orders(xyz)           # per-space-plane orders of the two-pass HexPlane backward
 
         # ---- deformation field
         # the descriptors only hold pointers and shapes: rebuilt when a parameter or the aabb moves, not every iteration
@@ -289,8 +290,13 @@ class FusedStep:
         N.check(lib.mom_deform_backward(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
                                         d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
                                         self.dh_scratch.data_ptr(), s), "deform_bwd")
+        if porders is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (P, hp.levels)):
+            self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
+            self._hex_scratch_key = (P, hp.levels)
         N.check(lib.mom_hexplane_backward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.dfeat.data_ptr(),
-                                          self.gxyz.data_ptr(), s), "hexplane_bwd")
+                                          self.gxyz.data_ptr(), None if porders is None else porders[0].data_ptr(),
+                                          None if porders is None else porders[1].data_ptr(),
+                                          None if porders is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
         # ---- plane regularisers (value + gradient added into the plane gradients)
         hy = self.hyper
         reg = None

@@ -66,8 +66,9 @@ class HexPlaneFunction(torch.autograd.Function):
     """features[P, L*32] = HexPlaneField(xyz, t) (reference scene/hexplane.py:160-183)."""
 
     @staticmethod
-    def forward(ctx, xyz, time, aabb, n_levels, order, aabb_host, *planes):
+    def forward(ctx, xyz, time, aabb, n_levels, order, aabb_host, plane_orders, *planes):
         _need_cuda(xyz, "hexplane")
+        ctx.plane_orders = plane_orders
         lv = [list(planes[6 * l:6 * l + 6]) for l in range(n_levels)]
         d, keep = _hexplane_desc(lv, aabb, aabb_host=aabb_host)
         ctx.aabb_host = aabb_host
@@ -94,18 +95,41 @@ class HexPlaneFunction(torch.autograd.Function):
         P = xyz_c.shape[0]
         dxyz = torch.zeros_like(xyz_c) if ctx.needs_input_grad[0] else None
         dfeat = dfeat.contiguous()
-        N.check(N.lib().mom_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(),
-                                              None if ctx.times is None else ctx.times.data_ptr(), ctx.time,
-                                              None if ctx.order is None else ctx.order.data_ptr(), dfeat.data_ptr(),
-                                              None if dxyz is None else dxyz.data_ptr(), N.current_stream()),
+        lib = N.lib()
+        po, scratch = ctx.plane_orders, None
+        if po is not None and ctx.times is None:        # two-pass backward: per-plane orders + the gradient-row scratch
+            scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(d), P), dtype=torch.uint8, device=xyz_c.device)
+        N.check(lib.mom_hexplane_backward(C.byref(d), P, xyz_c.data_ptr(),
+                                          None if ctx.times is None else ctx.times.data_ptr(), ctx.time,
+                                          None if ctx.order is None else ctx.order.data_ptr(), dfeat.data_ptr(),
+                                          None if dxyz is None else dxyz.data_ptr(),
+                                          None if scratch is None else po[0].data_ptr(), None if scratch is None else po[1].data_ptr(),
+                                          None if scratch is None else scratch.data_ptr(), N.current_stream()),
                 "mom_hexplane_backward")
         flat = [g for level in grads for g in level]
-        return (dxyz, None, None, None, None, None, *flat)
+        return (dxyz, None, None, None, None, None, None, *flat)
 
 
-def hexplane_features(xyz, time, aabb, planes_by_level, order=None, aabb_host=None):
+def hexplane_features(xyz, time, aabb, planes_by_level, order=None, aabb_host=None, plane_orders=None):
     flat = [p for level in planes_by_level for p in level]
-    return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), order, aabb_host, *flat)
+    return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), order, aabb_host, plane_orders, *flat)
+
+
+def hexplane_orders(xyz, planes_by_level, aabb, aabb_host=None):
+    """(order, inverse), int32 [3, levels, P] each: per space plane and level the permutation that sorts the points by that
+    level's texel cell, and its inverse (mom_hexplane_orders) -- what the two-pass HexPlane backward walks.  Speed only."""
+    _need_cuda(xyz, "hexplane_orders")
+    lib = N.lib()
+    pts = xyz.detach().contiguous().float()
+    P = pts.shape[0]
+    d, keep = _hexplane_desc([[p.detach() for p in lv] for lv in planes_by_level], aabb, aabb_host=aabb_host)
+    order = torch.empty((3, d.levels, max(P, 1)), dtype=torch.int32, device=pts.device)
+    inverse = torch.empty((3, d.levels, max(P, 1)), dtype=torch.int32, device=pts.device)
+    if P:
+        scratch = torch.empty(lib.mom_hexplane_orders_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
+        N.check(lib.mom_hexplane_orders(C.byref(d), P, pts.data_ptr(), order.data_ptr(), inverse.data_ptr(), scratch.data_ptr(),
+                                        N.current_stream()), "mom_hexplane_orders")
+    return order, inverse
 
 
 def morton_order(xyz):
@@ -470,6 +494,7 @@ class _HipBackend:
     restatement here EXPLICITLY (oracle.torch_ref.TorchBackend); nothing falls back to it by itself."""
     name = "hip"
     hexplane_features = staticmethod(hexplane_features)
+    hexplane_orders = staticmethod(hexplane_orders)
     morton_order = staticmethod(morton_order)
     deform_mlp = staticmethod(deform_mlp)
     l1_loss_with_sums = staticmethod(l1_loss_with_sums)

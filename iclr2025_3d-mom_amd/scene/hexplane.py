@@ -84,8 +84,12 @@ class HexPlaneField(nn.Module):
         """[N,3] points (+ [N,1] timestamps, or one python float for all points) -> [N, feat_dim]."""
         pts = pts.reshape(-1, pts.shape[-1])
         levels = [list(g) for g in self.grids]
-        return ops.BACKEND.hexplane_features(pts, timestamps, self.aabb, levels, order=self._processing_order(pts),
-                                             aabb_host=self.aabb_host() if self.aabb.is_cuda else None)
+        order = self._processing_order(pts)
+        kw = {}
+        if hasattr(ops.BACKEND, "hexplane_orders"):
+            kw["plane_orders"] = self._plane_orders(pts)
+        return ops.BACKEND.hexplane_features(pts, timestamps, self.aabb, levels, order=order,
+                                             aabb_host=self.aabb_host() if self.aabb.is_cuda else None, **kw)
 
     REORDER_EVERY = 64
 
@@ -100,6 +104,18 @@ class HexPlaneField(nn.Module):
             self._order_age = 0
         self._order_age += 1
         return self._order
+
+    def _plane_orders(self, pts):
+        """Per-space-plane orders of the two-pass backward (ops.hexplane_orders), rebuilt together with the Morton order:
+        call right after _processing_order()."""
+        if not hasattr(ops.BACKEND, "hexplane_orders") or pts.shape[0] == 0 or not pts.is_cuda:
+            return None
+        po = getattr(self, "_porders", None)
+        if po is None or po[0].shape[-1] != pts.shape[0] or po[0].device != pts.device or self._order_age == 1 \
+                or getattr(self, "_porders_key", None) != tuple(self.aabb_host()):
+            self._porders = ops.BACKEND.hexplane_orders(pts, [list(g) for g in self.grids], self.aabb, aabb_host=self.aabb_host())
+            self._porders_key = tuple(self.aabb_host())
+        return self._porders
 
     def forward(self, pts: torch.Tensor, timestamps=None):
         return self.get_density(pts, timestamps)

@@ -186,9 +186,22 @@ typedef struct MomHexPlane {
  * (render() uses one timestamp per camera). */
 int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
                          const uint32_t* order, float* feat, mom_stream_t stream);
-/* dfeat [P, levels*32]; plane gradients accumulate into hp->grads; dxyz [P,3] (may be null) is ACCUMULATED into */
+/* dfeat [P, levels*32]; plane gradients accumulate into hp->grads; dxyz [P,3] (may be null) is ACCUMULATED into.
+ * plane_order / plane_inverse ([3][levels][P] each, from mom_hexplane_orders) and scratch (mom_hexplane_backward_scratch_bytes)
+ * select the two-pass path (times == null only): pass 1 gathers in `order` and stores each space plane's per-point gradient
+ * row at the point's position in that plane's order, pass 2 walks each space plane in its order and turns runs of points of
+ * one texel cell into one row of float atomics.  Any of the three null: the generic path (24 atomic rows per point and level). */
+size_t mom_hexplane_backward_scratch_bytes(const MomHexPlane* hp, int P);
 int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
-                          const uint32_t* order, const float* dfeat, float* dxyz, mom_stream_t stream);
+                          const uint32_t* order, const float* dfeat, float* dxyz, const uint32_t* plane_order,
+                          const uint32_t* plane_inverse, void* scratch, mom_stream_t stream);
+/* Per-plane processing orders for the two-pass backward: for each space plane (x,y), (x,z), (y,z) and each level the
+ * permutation of 0..P-1 that sorts the points by the texel cell of that level they fall into (2-D Morton order over the
+ * cells), and its inverse.  Like `order`, they never change a result; they may be reused while the points drift (refresh
+ * every few dozen iterations) and must be rebuilt when P changes. */
+size_t mom_hexplane_orders_scratch_bytes(int P);
+int mom_hexplane_orders(const MomHexPlane* hp, int P, const float* xyz, uint32_t* order /* [3][levels][P] */,
+                        uint32_t* inverse /* [3][levels][P] */, void* scratch, mom_stream_t stream);
 /* `order` (both calls, may be null = identity): a permutation of 0..P-1 giving the order in which points are
  * processed, e.g. mom_morton_order(xyz).  It never changes a result (float atomics aside); walking the points in a
  * spatially sorted order lets the backward sum consecutive points that hit the same texel in registers and issue one
