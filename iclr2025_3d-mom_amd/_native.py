@@ -120,6 +120,7 @@ def _sig(lib):
     lib.mom_ssim_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp]
     lib.mom_activations_forward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_activations_backward.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_image_to_rgb8.argtypes = [i32, i32, i32, vp, vp, vp]
     lib.mom_profile_enable.argtypes = [i32, i32]
     lib.mom_profile_read.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), i32]
     lib.mom_profile_name.restype = C.c_char_p
@@ -151,7 +152,7 @@ EXPORTS = [
     "mom_ssim_forward", "mom_ssim_backward", "mom_raster_backward_render", "mom_raster_backward_geometry",
     "mom_densify_stats", "mom_select_scratch_bytes", "mom_select_plan", "mom_select_apply",
     "mom_ssim_forward_slab", "mom_ssim_backward_slab",
-    "mom_hexplane_backward_scratch_bytes", "mom_hexplane_orders_scratch_bytes", "mom_hexplane_orders",
+    "mom_hexplane_backward_scratch_bytes", "mom_hexplane_orders_scratch_bytes", "mom_hexplane_orders", "mom_image_to_rgb8",
 ]
 
 

@@ -315,3 +315,28 @@ extern "C" int mom_activations_backward(int P, const float* scales, const float*
                        dopac, dscales_raw, drots_raw, dopac_raw);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
+
+// ---------------------------------------------------------------- image -> 8-bit RGB (render_4DGS.py:64 save_image, :65 to8b)
+// out[y][x][c] = (uint8) clamp(img[c][y][x] * 255 + 0.5, 0, 255): torchvision.utils.save_image's quantisation of one image, in one
+// pass that also does its CHW -> HWC permute, so that the frame leaves the device as the bytes the PNG encoder wants.
+namespace {
+__global__ void __launch_bounds__(256) image_to_rgb8_kernel(int C, int HW, const float* __restrict__ img, uint8_t* __restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= HW) return;
+    for (int c = 0; c < C; c++) {
+        const float v = fminf(fmaxf(img[(size_t)c * HW + i] * 255.0f + 0.5f, 0.f), 255.f);
+        out[(size_t)i * C + c] = (uint8_t)v;
+    }
+}
+}  // namespace
+
+extern "C" int mom_image_to_rgb8(int C, int H, int W, const float* img, uint8_t* out, mom_stream_t stream)
+{
+    if (C < 1 || C > 4 || H < 0 || W < 0) return MOM_EINVAL;
+    if (H == 0 || W == 0) return MOM_OK;
+    if (!img || !out) return MOM_EINVAL;
+    const int HW = H * W;
+    hipLaunchKernelGGL(image_to_rgb8_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, HW, img, out);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

@@ -26,6 +26,8 @@ class FusedRender:
         self._desc_key = None
         self.serial = 0
         self.pending = deque()
+        self.collect = False         # True: frames found overflowed FLAG_LAG frames later go to self.bad instead of raising
+        self.bad = []
 
     def _ensure(self, P, W, H, dev):
         if self.key == (P, W, H, dev):
@@ -47,6 +49,7 @@ class FusedRender:
         self.cap, self.binning = 0, None
 
     RING, FLAG_LAG = 64, 8
+    HEADROOM, MARGIN = 1.5, 65536       # async binning capacity = HEADROOM x an earlier frame's instance count + MARGIN
 
     def overflowed(self, lag=0):
         """Serial numbers (FusedRender.serial after the render() that produced them) of async-mode frames older than `lag`
@@ -110,7 +113,9 @@ class FusedRender:
         # never asks gets a MomError FLAG_LAG frames later.
         prev_R = int(self.nr_host[0])
         late = self.overflowed(self.FLAG_LAG) if len(self.pending) > self.FLAG_LAG else []
-        if late:
+        if late and self.collect:
+            self.bad += late
+        elif late:
             raise N.MomError(f"async render(): frames {late} overflowed the binning capacity and are incomplete; render them "
                              "again (the capacity has been raised), collect such frames with FusedRender.overflowed(), or use "
                              "set_sync_mode('exact')")
@@ -120,7 +125,7 @@ class FusedRender:
             torch.cuda.current_stream().synchronize()
             want = int(self.nr_host[0]) + (0 if RC._state["mode"] == "exact" else int(self.nr_host[0]) // 2 + 65536)
         else:
-            want = max(self.cap, int(prev_R * 1.5) + 65536, getattr(self, "cap_floor", 0))
+            want = max(self.cap, int(prev_R * self.HEADROOM) + self.MARGIN, getattr(self, "cap_floor", 0))
         if self.binning is None or want > self.cap or want < self.cap // 4:
             self.cap = want
             self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, self.cap), dtype=torch.uint8, device=dev)

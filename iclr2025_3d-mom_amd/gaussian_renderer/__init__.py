@@ -8,7 +8,9 @@ import torch
 
 from .. import ops
 from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from ..scene.gaussian_model import GaussianModel  # noqa: F401  (render_4DGS.py:22 imports it from here)
 from ..utils.sh_utils import eval_sh
+from . import network_gui  # noqa: F401  (train_4DGS.py:17)
 
 
 def _nograd_fast_path_applies(cam, pc, pipe, stage, override_color, cam_type):

@@ -417,7 +417,10 @@ class FusedAdam(torch.optim.Optimizer):
     state_dict()/load_state_dict() work unchanged."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        # the other keys are torch.optim.Adam's (all at their defaults: this optimizer implements exactly that configuration), so
+        # that a state_dict() written here loads into the reference's torch.optim.Adam and the other way round
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
+                                      capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False))
         self._plan = None
         # int32 device word or None.  While it is nonzero on the device a step() changes neither parameters nor moments:
         # the asynchronous training step points it at the rasterizer's sticky overflow word, so that a step whose image was

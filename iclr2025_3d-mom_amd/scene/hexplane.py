@@ -76,7 +76,8 @@ class HexPlaneField(nn.Module):
         return self._aabb_host_val
 
     def set_aabb(self, xyz_max, xyz_min):
-        aabb = torch.tensor([xyz_max, xyz_min], dtype=torch.float32)
+        import numpy as np
+        aabb = torch.tensor(np.asarray([np.asarray(xyz_max, np.float32), np.asarray(xyz_min, np.float32)]), dtype=torch.float32)
         self.aabb = nn.Parameter(aabb.to(self.aabb.device), requires_grad=False)
         print("Voxel Plane: set aabb=", self.aabb)
 

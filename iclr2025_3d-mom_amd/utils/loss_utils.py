@@ -27,6 +27,12 @@ def l2_loss(network_output, gt):
     return ((network_output - gt) ** 2).mean()
 
 
+def lpips_loss(img1, img2, lpips_model):
+    """utils/loss_utils.py:20-22.  train_4DGS.py imports the name but its call is commented out (:89); the lpips package is not
+    part of this path."""
+    return torch.mean(lpips_model(img1, img2))
+
+
 def gaussian(window_size, sigma):
     g = torch.Tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)])
     return g / g.sum()

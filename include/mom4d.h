@@ -332,6 +332,11 @@ size_t mom_deform_backward_scratch_bytes(int P);   /* 4 x [P,64] floats: the per
 int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                         const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream);
 
+/* ---- rendered image -> 8-bit interleaved RGB (render_4DGS.py:64 torchvision.utils.save_image: x * 255 + 0.5, clamp, truncate;
+ * CHW -> HWC) in one pass, so that a frame can leave the device as the bytes a PNG encoder takes.  img [C,H,W] floats, out [H,W,C]
+ * bytes; C <= 4. */
+int mom_image_to_rgb8(int C, int H, int W, const float* img, uint8_t* out, mom_stream_t stream);
+
 const char* mom_version(void);
 
 /* Per-kernel HIP-event timing (bench.py's live roofline figure).  Slots: see mom_profile_name(0..15).

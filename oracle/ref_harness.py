@@ -290,6 +290,90 @@ def g9_side_trajectory():
                         t=np.stack([np.asarray(x) for x in t]))
 
 
+def g9_trajectories():
+    """All four render trajectories of the reference (test_trajectory/{up-down,side,zoom-in,circle}_{R,t}_list, loaded at
+    scene/dataset_readers.py:1168-1175): pose data.  Pins scene/dataset_readers.trajectory()'s closed forms."""
+    out = {}
+    for name in ("up-down", "side", "zoom-in", "circle"):
+        R = torch.load(os.path.join(REF, "test_trajectory", name + "_R_list"), map_location="cpu", weights_only=False)
+        t = torch.load(os.path.join(REF, "test_trajectory", name + "_t_list"), map_location="cpu", weights_only=False)
+        out["R_" + name], out["t_" + name] = np.stack([np.asarray(r) for r in R]), np.stack([np.asarray(x) for x in t])
+    np.savez_compressed(os.path.join(OUT, "g9_trajectories.npz"), **out)
+
+
+def g11_checkpoint_formats():
+    """What the reference's GaussianModel writes: (a) the PLY vertex element of save_ply (gaussian_model.py:342-360) -- attribute
+    names in order and the float32 table -- captured by standing in for plyfile's PlyElement.describe; (b) the layout of the
+    capture() tuple (:72-90) and of the optimizer state_dict inside it, for a 40-Gaussian model after one Adam step."""
+    import argparse
+    import scene.gaussian_model as gmod
+    from scene.gaussian_model import GaussianModel
+    torch.manual_seed(5)
+    gm = GaussianModel(3, HP)
+    n = 40
+    g = torch.Generator().manual_seed(6)
+    P = torch.nn.Parameter
+    gm._xyz = P(torch.randn(n, 3, generator=g))
+    gm._features_dc = P(torch.randn(n, 1, 3, generator=g))
+    gm._features_rest = P(torch.randn(n, 15, 3, generator=g) * 0.1)
+    gm._scaling = P(torch.randn(n, 3, generator=g) * 0.7 - 3.0)
+    gm._rotation = P(torch.randn(n, 4, generator=g))
+    gm._opacity = P(torch.randn(n, 1, generator=g) * 2)
+    gm._scene_flow = torch.randn(n, 3, generator=g) * 1e-2
+    gm._deformation_table = torch.ones(n, dtype=torch.bool)
+    gm.max_radii2D = torch.zeros(n)
+    gm.spatial_lr_scale = 0.29
+    gm.active_sh_degree = 2
+    out = {k: getattr(gm, k).detach().numpy().copy() for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation",
+                                                                  "_opacity", "_scene_flow")}
+    captured = {}
+
+    class Element:
+        @staticmethod
+        def describe(elements, name):
+            captured["elements"], captured["name"] = elements, name
+            return (elements, name)
+
+    class Data:
+        def __init__(self, els):
+            pass
+
+        def write(self, path):
+            captured["path"] = path
+    gmod.PlyElement, gmod.PlyData = Element, Data
+    gm.save_ply(os.path.join("/tmp", "mom_ref_harness", "point_cloud.ply"))
+    el = captured["elements"]
+    out["ply_names"] = np.array(list(el.dtype.names))
+    out["ply_formats"] = np.array([str(el.dtype[n]) for n in el.dtype.names])
+    out["ply_table"] = np.stack([el[n] for n in el.dtype.names], axis=1).astype(np.float32)
+    out["ply_element"] = np.array(captured["name"])
+    opt = argparse.Namespace(percent_dense=0.01, position_lr_init=1.6e-4, position_lr_final=1.6e-6, position_lr_delay_mult=0.01,
+                             position_lr_max_steps=20000, deformation_lr_init=1.6e-4, deformation_lr_final=1.6e-6,
+                             deformation_lr_delay_mult=0.01, grid_lr_init=1.6e-3, grid_lr_final=1.6e-5, feature_lr=0.0025,
+                             opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+    gm.training_setup(opt)
+    for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+        p = getattr(gm, name)
+        p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    gm.optimizer.step()
+    cap = gm.capture()
+
+    def kind(x):
+        if torch.is_tensor(x):
+            return f"tensor{tuple(x.shape)}:{str(x.dtype).replace('torch.', '')}:{'param' if isinstance(x, torch.nn.Parameter) else 'plain'}"
+        if isinstance(x, dict):
+            return "dict:" + ",".join(str(k) for k in x.keys())
+        return type(x).__name__ + ":" + repr(x)
+    out["capture_kinds"] = np.array([kind(x) for x in cap])
+    od = cap[13]
+    out["opt_group_names"] = np.array([g_["name"] for g_ in od["param_groups"]])
+    out["opt_group_keys"] = np.array(sorted(od["param_groups"][0].keys()))
+    out["opt_group_nparams"] = np.array([len(g_["params"]) for g_ in od["param_groups"]])
+    out["opt_state_keys"] = np.array(sorted(next(iter(od["state"].values())).keys()))
+    out["opt_state_ids"] = np.array(sorted(od["state"].keys()))
+    np.savez_compressed(os.path.join(OUT, "g11_checkpoint_formats.npz"), **out)
+
+
 if __name__ == "__main__":
     # python oracle/ref_harness.py            -> every fixture
     # python oracle/ref_harness.py g9 g3      -> only the named ones (g7 needs g1's field, so it pulls g1 in)
@@ -306,4 +390,6 @@ if __name__ == "__main__":
     if want("g7"): g7_regulation(field)
     if want("g8"): g8_densify()
     if want("g9"): g9_side_trajectory()
+    if want("g9t"): g9_trajectories()
+    if want("g11"): g11_checkpoint_formats()
     print("golden fixtures written to", OUT, sorted(os.listdir(OUT)))
