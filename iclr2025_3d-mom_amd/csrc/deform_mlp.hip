@@ -36,7 +36,8 @@ constexpr int kHid = 64;
 constexpr int kWStride = 65;                         // LDS row stride of a weight matrix ([in][out])
 constexpr int kWFloats = kHid * kWStride;            // one layer
 constexpr int kStageStride = 33;                     // staging rows: [feature][32 gaussians + 1 pad]
-constexpr int kStageFloats = 2 * kHid * kStageStride + 4 * 32;   // sA | sB | dout[32][4]
+constexpr int kStageFloats = kHid * kStageStride + 4 * 32;       // sA | dout[32][4]
+constexpr int kDxWaves = 8;                          // waves per workgroup of the dx kernel (they share one copy of the weights)
 
 // LDS map (floats)
 constexpr int kLW = 0;                               // [4][64][65]
@@ -44,8 +45,8 @@ constexpr int kLB = kLW + 4 * kWFloats;              // [4][64]
 constexpr int kLW2 = kLB + 4 * kHid;                 // [3][4][64] (rows >= nout are zero)
 constexpr int kLB2 = kLW2 + 3 * 4 * kHid;            // [3][4]
 constexpr int kLFwdTotal = kLB2 + 16;
-constexpr int kLStage = kLFwdTotal;                  // [4 waves][kStageFloats]   (backward only)
-constexpr int kLBwdTotal = kLStage + 4 * kStageFloats;
+constexpr int kLStage = kLFwdTotal;                  // [kDxWaves][kStageFloats]   (backward only)
+constexpr int kLBwdTotal = kLStage + kDxWaves * kStageFloats;
 
 __device__ __forceinline__ int fmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -226,7 +227,9 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ s, const f32x16 (
 }
 
 // (A) activations backward: dH for the four layers, d(features), output-layer weight gradients
-__global__ void __launch_bounds__(256)
+// 512 threads: two waves per SIMD share one copy of the weights (142 KB of LDS with the staging tiles), so that one wave's vector
+// and memory phases -- the thin output layers, the dH stores -- run under the other's MFMAs (4 waves: 288 us for dx + dW, 8: 276)
+__global__ void __launch_bounds__(64 * kDxWaves)
 deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, const float* __restrict__ dpts,
                      const float* __restrict__ dscales, const float* __restrict__ drots, float* __restrict__ dfeat,
                      float* __restrict__ dH /* [4][P][64] */)
@@ -236,8 +239,8 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
     __syncthreads();
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     float* sA = lds + kLStage + wv * kStageFloats;
-    float* sD = sA + 2 * kHid * kStageStride;          // dout[32 gaussians][4]
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    float* sD = sA + kHid * kStageStride;              // dout[32 gaussians][4]
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     const size_t PH = (size_t)P * kHid;
     float dW2[3][4], db2[3];                           // lane = feature; db2: lane n < 4 holds output n
 #pragma unroll
@@ -315,7 +318,7 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
     // output-layer gradients: combine the four waves in LDS, one atomic per element per workgroup
     __syncthreads();
     float* R = lds;
-    for (int i = threadIdx.x; i < 12 * kHid + 16; i += 256) R[i] = 0.f;
+    for (int i = threadIdx.x; i < 12 * kHid + 16; i += blockDim.x) R[i] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -324,7 +327,7 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
         if (lane < 4) atomicAdd(&R[12 * kHid + k * 4 + lane], db2[k]);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 12 * kHid; i += 256) {
+    for (int i = threadIdx.x; i < 12 * kHid; i += blockDim.x) {
         const int k = i >> 8, n = (i >> 6) & 3, f = i & 63;
         const int nout = k == 2 ? 4 : 3;
         const float v = R[i];
@@ -542,7 +545,7 @@ extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* fe
         if (!d.dW1[i] || !d.db1[i] || !d.dW2[i] || !d.db2[i]) return MOM_EINVAL;
     float* dH = (float*)scratch;
     const int tiles = (P + 31) / 32;
-    int blocks = (tiles + 3) / 4;
+    int blocks = (tiles + kDxWaves - 1) / kDxWaves;
     if (blocks > 256) blocks = 256;                    // persistent: one workgroup per CU
     static bool attr_set = false;
     const size_t lds_a = sizeof(float) * kLBwdTotal;
@@ -554,7 +557,7 @@ extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* fe
         attr_set = true;
     }
     MomProfScope ps(MOM_P_MLP_BWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(deform_bwd_dx_kernel, dim3(blocks), dim3(256), lds_a, (hipStream_t)stream, d, P, tiles, a0, dpts, dscales, drots,
+    hipLaunchKernelGGL(deform_bwd_dx_kernel, dim3(blocks), dim3(64 * kDxWaves), lds_a, (hipStream_t)stream, d, P, tiles, a0, dpts, dscales, drots,
                        dfeat, dH);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     // weight gradients: 1024 waves, each a contiguous (even-sized) range of gaussians

@@ -32,7 +32,6 @@ __device__ __forceinline__ float dpp_add(float v)
 // Sum over the 64 lanes; the total is returned in every lane (via v_readlane of lane 63).
 __device__ __forceinline__ float wave_sum(float v)
 {
-#if MOM_USE_DPP
     v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
     v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
     v = dpp_add<0x124, 0xF>(v);  // row_ror:4
@@ -40,11 +39,6 @@ __device__ __forceinline__ float wave_sum(float v)
     v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
     v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> row 3 holds the wave sum
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-#else
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-#endif
 }
 
 // Pair step of a reduce-scatter: lanes whose `upper` bit is clear end up with the pair-sum of x, the others with the
@@ -258,8 +252,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     }
     if (inside) {
         const int pix = py * W + px;
-        final_T[pix] = T;
-        n_contrib[pix] = last_contributor;
+        if (final_T) final_T[pix] = T;                      // null in forward-only rendering: nothing will read them
+        if (n_contrib) n_contrib[pix] = last_contributor;
         const size_t HW = (size_t)H * W;
         out_color[pix] = C0 + T * bg[0];
         out_color[HW + pix] = C1 + T * bg[1];
@@ -361,7 +355,9 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                   g_d = 0.f;
             if (valid) {
                 const float4 r2 = s_rec[j * 3 + 2];
-                const float inv_1ma = 1.f / (1.f - alpha);      // shared by T and the background term below
+                // the reference divides (T = T / (1 - alpha), backward.cu:502); the hardware reciprocal is within 1 ulp of that
+                // quotient and costs one instruction instead of ten
+                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);      // shared by T and the background term below
                 T = T * inv_1ma;
                 const float w = alpha * T;
                 float dL_dalpha = 0.f;

@@ -1,0 +1,50 @@
+"""How many (footprint, splat) pairs the compositing kernels have to walk for different wave footprints, on one camera of
+config c2: a pair counts when any pixel of the footprint reaches alpha >= 1/255 (saturation ignored).  Decides whether finer
+footprints (lists per half-wave / per 16-lane row) would pay."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, ctypes as C
+import bench
+N = importlib.import_module("iclr2025_3d-mom_amd._native")
+scene, g, trainer, op = bench.build_state(bench.CONFIGS["c2"], torch.device("cuda"), fused=True)
+fs = trainer.fused
+cam = trainer.cams[7]
+fs.exact_next(); fs.forward_backward(cam, 1); torch.cuda.synchronize()
+P, W, H = 200000, 960, 540
+lay = N.MomRasterLayout(); N.lib().mom_raster_layout(P, W, H, fs.cap, C.byref(lay))
+geom = fs.geom[(-fs.geom.data_ptr()) % 256:].cpu().numpy()
+rec = geom[lay.geom_rec:lay.geom_rec + P * 48].view(np.float32).reshape(P, 12)
+img = fs.img[(-fs.img.data_ptr()) % 256:].cpu().numpy()
+tiles = 60 * 34
+ranges = img[lay.img_ranges:lay.img_ranges + tiles * 8].view(np.uint32).reshape(tiles, 2)
+b = fs.binning[(-fs.binning.data_ptr()) % 256:].cpu().numpy()
+R = int(fs.nr_host[0])
+pl = b[lay.bin_point_list:lay.bin_point_list + R * 4].view(np.uint32)
+print("R", R)
+tot = {k: 0 for k in ("inst", "px_valid", "s16x4", "s8x4", "s8x8", "s4x4")}
+rng = np.random.default_rng(0)
+for t in rng.choice(tiles, 200, replace=False):
+    a, e = ranges[t]
+    if e <= a: continue
+    ids = pl[a:e]
+    r = rec[ids]
+    tx, ty = t % 60, t // 60
+    px = (tx * 16 + np.arange(16))[None, None, :].astype(np.float32); py = (ty * 16 + np.arange(16))[None, :, None].astype(np.float32)
+    dx = r[:, 0][:, None, None] - px; dy = r[:, 1][:, None, None] - py
+    power = -0.5 * (r[:, 4][:, None, None] * dx * dx + r[:, 6][:, None, None] * dy * dy) - r[:, 5][:, None, None] * dx * dy
+    alpha = np.minimum(0.99, r[:, 7][:, None, None] * np.exp(power))
+    v = (power <= 0) & (alpha >= 1 / 255.0)                      # [n,16(y),16(x)]
+    n = v.shape[0]
+    tot["inst"] += n; tot["px_valid"] += int(v.sum())
+    tot["s16x4"] += int(v.reshape(n, 4, 4, 16).any(axis=(2, 3)).sum())
+    tot["s8x4"] += int(v.reshape(n, 4, 4, 2, 8).any(axis=(2, 4)).sum())
+    tot["s8x8"] += int(v.reshape(n, 2, 8, 2, 8).any(axis=(2, 4)).sum())
+    tot["s4x4"] += int(v.reshape(n, 4, 4, 4, 4).any(axis=(2, 4)).sum())
+print(tot)
+i = tot["inst"]
+print("valid pixels per instance", tot["px_valid"] / i)
+for k, lanes in (("s16x4", 64), ("s8x4", 32), ("s8x8", 64), ("s4x4", 16)):
+    print(k, "footprint-pairs per instance %.2f" % (tot[k] / i), "lane-slots per instance %.1f" % (tot[k] / i * lanes),
+          "useful %.3f" % (tot["px_valid"] / (tot[k] * lanes)))

@@ -10,7 +10,7 @@ extra=""
 case $base in raster_preprocess|knn) extra="-ffp-contract=off";; esac
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DMOM_USE_DPP=1 $extra $flags -c $base.hip -o ../lib/var/$name.o || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $extra $flags -c $base.hip -o ../lib/var/$name.o || exit 1
   objs=$(ls ../lib/obj/*.o | grep -v "/$base.o")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/var/$name.so $objs ../lib/var/$name.o || exit 1
   rm ../lib/var/$name.o
