@@ -143,6 +143,7 @@ def render_fps(scene, g, pp, background, delta_scale, passes=2):
     dev = g._xyz.device
     for c in cams:
         c.device_tensors(dev)
+    cfg_hw = (int(cams[0].image_height), int(cams[0].image_width))
     DGR.set_sync_mode("async")          # size the binning buffer from earlier frames; overflowed frames are rendered again below
     try:
         with torch.no_grad():
@@ -169,8 +170,13 @@ def render_fps(scene, g, pp, background, delta_scale, passes=2):
                "mode": "no-grad render(), deformation on, images kept on the device (no PNG writer)"}
         tmp = tempfile.mkdtemp(prefix="mom_bench_render_")
         try:
-            own.render_set(tmp, "warm", 0, cams[:8], g, pp, background, scene.dataset_type, delta_scale=delta_scale, video=False)
-            a = own.render_set(tmp, "side", 0, cams, g, pp, background, scene.dataset_type, delta_scale=delta_scale, video=False)
+            # one writer for the whole script, as render_sets() would keep it over its four trajectories: pinned ring and encoder
+            # threads exist before the first frame
+            writer = own.AsyncPNGWriter(cfg_hw[0], cfg_hw[1])
+            own.render_set(tmp, "warm", 0, cams, g, pp, background, scene.dataset_type, delta_scale=delta_scale, video=False, writer=writer)
+            a = own.render_set(tmp, "side", 0, cams, g, pp, background, scene.dataset_type, delta_scale=delta_scale, video=False,
+                               writer=writer)
+            writer.close()
             DGR.set_sync_mode("exact")
             b = own.render_set(tmp, "side_blocking", 0, cams, g, pp, background, scene.dataset_type, delta_scale=delta_scale,
                                video=False, scripted=True)

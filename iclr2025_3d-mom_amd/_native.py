@@ -28,7 +28,8 @@ class MomRasterArgs(C.Structure):
                 ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("scale_modifier", C.c_float),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int),
-                ("tile_row0", C.c_int), ("tile_row1", C.c_int)]     # tile-row shard: 0,0 = every row
+                ("tile_row0", C.c_int), ("tile_row1", C.c_int),     # tile-row shard: 0,0 = every row
+                ("forward_only", C.c_int)]                          # no backward will follow: skip the state only it reads
 
 
 class MomRasterGrads(C.Structure):

@@ -95,8 +95,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             M3 Sg = mul(transpose(Mm), Mm);
             c3[0] = Sg.m[0][0]; c3[1] = Sg.m[0][1]; c3[2] = Sg.m[0][2];
             c3[3] = Sg.m[1][1]; c3[4] = Sg.m[1][2]; c3[5] = Sg.m[2][2];
+            if (cov3Ds) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) cov3Ds[6 * idx + i] = c3[i];
+                for (int i = 0; i < 6; i++) cov3Ds[6 * idx + i] = c3[i];
+            }
         }
 
         // EWA 2D covariance
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
     rec[3 * (size_t)idx + 0] = r0;
     rec[3 * (size_t)idx + 1] = r1;
     rec[3 * (size_t)idx + 2] = r2;
-    clamped[idx] = cl;
+    if (clamped) clamped[idx] = cl;
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means, const float* __restrict__ view,
@@ -208,7 +210,8 @@ int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* ra
     p.view = a->viewmatrix; p.proj = a->projmatrix; p.cam = a->campos;
     const int blocks = (a->P + 255) / 256;
     MomProfScope ps(MOM_P_PRE_FWD, s);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, s, p, radii, g.rec, g.cov3D, g.clamped);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, s, p, radii, g.rec, a->forward_only ? nullptr : g.cov3D,
+                       a->forward_only ? nullptr : g.clamped);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

@@ -413,7 +413,8 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     const int nt = gx * (ry1 - ry0);
     if (nt == 0) return MOM_OK;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0,
-                       g.rec, a->background, im.final_T, im.n_contrib, out_color, out_depth, cap);
+                       g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
+                       out_depth, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

@@ -31,8 +31,9 @@ class AsyncPNGWriter:
         self.free = queue.Queue()
         for i in range(slots):
             self.free.put(i)
-        self.pool = ThreadPoolExecutor(max_workers=workers or min(64, max(4, (os.cpu_count() or 8) // 2)))
+        self.pool = ThreadPoolExecutor(max_workers=workers or min(slots, max(4, (os.cpu_count() or 8) // 2)))
         self.futures = []
+        list(self.pool.map(lambda _: time.sleep(0.002), range(self.pool._max_workers)))     # start the threads now, not per frame
 
     def submit(self, image, path):
         slot = self.free.get()
@@ -150,6 +151,7 @@ def _render_set_body(model_path, name, views, gaussians, pipeline, background, c
 
 
 def render_sets(dataset, hyperparam, iteration, pipeline, skip_train, skip_test, skip_video, TrainData_path, Gaussian_path, **kw):
+    """render_4DGS.py:77-91.  One AsyncPNGWriter serves the four trajectories."""
     from .scene import GaussianModel, Scene
     with torch.no_grad():
         gaussians = GaussianModel(dataset.sh_degree, hyperparam)
@@ -157,7 +159,16 @@ def render_sets(dataset, hyperparam, iteration, pipeline, skip_train, skip_test,
         dev = gaussians._xyz.device
         background = torch.tensor([1, 1, 1] if dataset.white_background else [0, 0, 0], dtype=torch.float32, device=dev)
         out = {}
-        for name, cams in (("up_down", scene.getVideoCameras_up()), ("side", scene.getVideoCameras_side()),
-                           ("zoom", scene.getVideoCameras_zoom()), ("circle", scene.getVideoCameras_circle())):
-            out[name] = render_set(Gaussian_path, name, scene.loaded_iter, cams, gaussians, pipeline, background, scene.dataset_type, **kw)
+        writer = None
+        if dev.type == "cuda" and not kw.get("scripted") and "writer" not in kw:
+            c0 = scene.getVideoCameras_up()[0]
+            writer = kw["writer"] = AsyncPNGWriter(int(c0.image_height), int(c0.image_width))
+        try:
+            for name, cams in (("up_down", scene.getVideoCameras_up()), ("side", scene.getVideoCameras_side()),
+                               ("zoom", scene.getVideoCameras_zoom()), ("circle", scene.getVideoCameras_circle())):
+                out[name] = render_set(Gaussian_path, name, scene.loaded_iter, cams, gaussians, pipeline, background,
+                                       scene.dataset_type, **kw)
+        finally:
+            if writer is not None:
+                writer.close()
     return out

@@ -1,4 +1,7 @@
 """Camera / MiniCam with the reference's attributes (reference scene/cameras.py:17-83)."""
+import collections
+import weakref
+
 import numpy as np
 import torch
 from torch import nn
@@ -29,15 +32,55 @@ class Camera(nn.Module):
         self.full_proj_transform = (self.world_view_transform.unsqueeze(0).bmm(self.projection_matrix.unsqueeze(0))).squeeze(0)
         self.camera_center = self.world_view_transform.inverse()[3, :3]
         self._dev_cache = None
+        self._gt_dev = None
+
+    # Ground-truth images resident on the device, over all cameras: bounded (least recently used first out), because a real
+    # multi-view video is tens of GB while the three matrices of a camera are 140 bytes.  The reference uploads the image of
+    # the drawn camera every iteration (train_4DGS.py:194); within the budget an image is uploaded once.
+    GT_CACHE_BYTES = 24 << 30
+    _gt_lru = collections.OrderedDict()        # id(camera) -> (weak reference to the camera, bytes)
+    _gt_bytes = 0
 
     def device_tensors(self, device):
-        """(view, full_proj, camera_center[, gt image]) staged on `device` once -- the reference re-uploads the three
-        matrices and the ground-truth image every iteration (gaussian_renderer/__init__.py:49-52, train_4DGS.py:194)."""
-        if self._dev_cache is None or self._dev_cache[0].device != torch.device(device):
+        """(view, full_proj, camera_center, gt image) on `device`: the matrices staged once per camera -- the reference
+        re-uploads them every iteration (gaussian_renderer/__init__.py:49-52) -- the image through the bounded cache above."""
+        device = torch.device(device)
+        if self._dev_cache is None or self._dev_cache[0].device != device:
             # contiguous: world_view_transform is a transposed view, and the C ABI takes raw pointers
             self._dev_cache = (self.world_view_transform.to(device).contiguous(), self.full_proj_transform.to(device).contiguous(),
-                               self.camera_center.to(device).contiguous(), self.original_image.to(device).contiguous())
-        return self._dev_cache
+                               self.camera_center.to(device).contiguous())
+            self._drop_gt()
+        cls = Camera
+        if self._gt_dev is None:
+            img = self.original_image.to(device).contiguous()
+            self._gt_dev = img
+            if img.device.type != "cpu":
+                nbytes = img.numel() * img.element_size()
+                cls._gt_lru[id(self)] = (weakref.ref(self), nbytes)
+                cls._gt_bytes += nbytes
+                while cls._gt_bytes > cls.GT_CACHE_BYTES and len(cls._gt_lru) > 1:
+                    key, (ref, nb) = next(iter(cls._gt_lru.items()))
+                    victim = ref()
+                    if victim is not None:
+                        victim._drop_gt()
+                    else:
+                        del cls._gt_lru[key]
+                        cls._gt_bytes -= nb
+        elif id(self) in cls._gt_lru:
+            cls._gt_lru.move_to_end(id(self))
+        return self._dev_cache + (self._gt_dev,)
+
+    def __del__(self):
+        try:
+            self._drop_gt()
+        except Exception:
+            pass
+
+    def _drop_gt(self):
+        ent = Camera._gt_lru.pop(id(self), None)
+        if ent is not None:
+            Camera._gt_bytes -= ent[1]
+        self._gt_dev = None
 
 
 class MiniCam:

@@ -8,6 +8,7 @@ from random import randint
 import torch
 
 from .gaussian_renderer import render
+from .utils.image_utils import psnr
 from .utils.loss_utils import l1_loss, psnr_from_last_l1, ssim
 
 
@@ -140,7 +141,10 @@ class Trainer:
                 if torch.isnan(loss).any():
                     raise FloatingPointError("loss is nan")
                 self.ema_loss = 0.4 * loss.item() + 0.6 * self.ema_loss
-                self.ema_psnr = 0.4 * float(psnr_from_last_l1()) + 0.6 * self.ema_psnr
+                # the reference logs psnr(image, gt).mean(): the mean of the per-image PSNRs (train_4DGS.py:214), which the pooled
+                # squared error of the fused L1 pass only equals for a batch of one
+                ps = psnr_from_last_l1() if image.shape[0] == 1 else psnr(image.detach(), gt).mean()
+                self.ema_psnr = 0.4 * float(ps) + 0.6 * self.ema_psnr
             self.last = {"loss": loss.detach(), "l1": Ll1.detach(), "points": g._xyz.shape[0]}
         return self._after_backward(iteration, loss.detach(), radii, visibility, vsp_grad)
 

@@ -73,6 +73,10 @@ typedef struct MomRasterArgs {
      * unaffected (radii, depths, conics are those of the whole image); num_rendered counts the local instances;
      * pixels of other rows are neither read nor written. */
     int tile_row0, tile_row1;
+    /* !=0: this forward will never be followed by a backward (no-grad render(), render_4DGS.py): the auxiliary state only the
+     * backward reads -- cov3D[P][6], clamped[P], final_T[H*W], n_contrib[H*W] -- is not written (about 28 B per Gaussian and
+     * 8 B per pixel).  mom_raster_backward on such a forward is an error the caller must not make. */
+    int forward_only;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
