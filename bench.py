@@ -302,6 +302,8 @@ def main():
         for i in range(steps):
             loss = one(first + i)
         trainer.drain()
+        if hasattr(loss, "tensor"):
+            loss = loss.tensor()             # the fused step forms its loss value on demand: take it before later steps overwrite it
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

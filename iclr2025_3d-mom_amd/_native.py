@@ -29,7 +29,8 @@ class MomRasterArgs(C.Structure):
                 ("projmatrix", C.c_void_p), ("campos", C.c_void_p), ("scale_modifier", C.c_float),
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int),
                 ("tile_row0", C.c_int), ("tile_row1", C.c_int),     # tile-row shard: 0,0 = every row
-                ("forward_only", C.c_int)]                          # no backward will follow: skip the state only it reads
+                ("forward_only", C.c_int),                          # no backward will follow: skip the state only it reads
+                ("overflow_tag", C.c_uint)]                         # what an overflow of this call leaves in *status_dev
 
 
 class MomRasterGrads(C.Structure):
@@ -105,7 +106,9 @@ def _sig(lib):
     lib.mom_morton_order.argtypes = [i32, vp, vp, vp, vp]
     lib.mom_adam_step.argtypes = [C.POINTER(MomAdamTensor), i32, C.c_double, C.c_double, C.c_double, vp, vp]
     lib.mom_l1_loss.argtypes = [sz, vp, vp, vp, vp, vp]
+    lib.mom_l1_loss_acc.argtypes = [sz, vp, vp, vp, vp, vp]
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
+    lib.mom_plane_regulation_acc.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
     lib.mom_deform_forward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.mom_deform_backward_scratch_bytes.restype = sz
     lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
@@ -154,6 +157,7 @@ EXPORTS = [
     "mom_densify_stats", "mom_select_scratch_bytes", "mom_select_plan", "mom_select_apply",
     "mom_ssim_forward_slab", "mom_ssim_backward_slab",
     "mom_hexplane_backward_scratch_bytes", "mom_hexplane_orders_scratch_bytes", "mom_hexplane_orders", "mom_image_to_rgb8",
+    "mom_l1_loss_acc", "mom_plane_regulation_acc",
 ]
 
 

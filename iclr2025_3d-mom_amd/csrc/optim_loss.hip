@@ -229,6 +229,12 @@ extern "C" int mom_l1_loss(size_t n, const float* img, const float* gt, float* d
 {
     if (!img || !gt || !sums2) return MOM_EINVAL;
     if (hipMemsetAsync(sums2, 0, 8, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
+    return mom_l1_loss_acc(n, img, gt, dimg, sums2, stream);
+}
+
+extern "C" int mom_l1_loss_acc(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream)
+{
+    if (!img || !gt || !sums2) return MOM_EINVAL;
     if (n == 0) return MOM_OK;
     // every block ends with two atomics on the same two floats, and same-address atomics serialise in the L2: with 760
     // blocks that tail cost more than streaming the images.  A few hundred fat blocks keep every CU busy and the tail short.
@@ -277,8 +283,14 @@ extern "C" int mom_densify_stats(int P, const int* radii, const float* viewspace
 
 extern "C" int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom_stream_t stream)
 {
-    if (count < 0 || count > MOM_REG_MAX_PLANES || !value || (count && !planes)) return MOM_EINVAL;
+    if (!value) return MOM_EINVAL;
     if (hipMemsetAsync(value, 0, 4, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
+    return mom_plane_regulation_acc(planes, count, value, stream);
+}
+
+extern "C" int mom_plane_regulation_acc(const MomRegPlane* planes, int count, float* value, mom_stream_t stream)
+{
+    if (count < 0 || count > MOM_REG_MAX_PLANES || !value || (count && !planes)) return MOM_EINVAL;
     RegArgs a;
     unsigned blocks = 0;
     for (int i = 0; i < count; i++) {

@@ -4,9 +4,9 @@
 int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, hipStream_t s);
 int mom_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const ImageView& im, uint32_t* num_rendered_dev,
-                             hipStream_t s);
+                             uint32_t* num_rendered_host, hipStream_t s);
 int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
-                            hipStream_t s);
+                            uint32_t* status_dev, hipStream_t s);
 int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
                           float* out_color, float* out_depth, hipStream_t s);
 int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
@@ -34,14 +34,6 @@ static int check_grads(const MomRasterArgs* a, const MomRasterGrads* gr)
     if (a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return MOM_EINVAL;
     return MOM_OK;
 }
-
-namespace {
-__global__ void status_or_kernel(const uint32_t* __restrict__ hdr_status, uint32_t* __restrict__ sticky)
-{
-    const uint32_t v = *hdr_status;
-    if (v) atomicOr(sticky, v);
-}
-}  // namespace
 
 extern "C" {
 
@@ -96,11 +88,9 @@ int mom_raster_forward_geometry(const MomRasterArgs* a, void* geom, void* image,
     rc = mom_launch_preprocess_fwd(a, g, radii, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
-    rc = mom_launch_binning_count(a, g, im, num_rendered_dev, s);
+    rc = mom_launch_binning_count(a, g, im, num_rendered_dev, num_rendered_host, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
-    if (num_rendered_host)
-        if (hipMemcpyAsync(num_rendered_host, num_rendered_dev, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return MOM_ELAUNCH;
     return MOM_OK;
 }
 
@@ -122,16 +112,12 @@ int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning,
     geom_view(mom_align_ptr(geom), a->P, &g);
     image_view(mom_align_ptr(image), a->W, a->H, &im);
     bin_view(mom_align_ptr(binning), capacity, &b);
-    rc = mom_launch_binning_sort(a, g, b, im, capacity, s);
+    rc = mom_launch_binning_sort(a, g, b, im, capacity, status_dev, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
     rc = mom_launch_render_fwd(a, g, b, im, capacity, out_color, out_depth, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
-    if (status_dev) {
-        hipLaunchKernelGGL(status_or_kernel, dim3(1), dim3(1), 0, s, im.hdr + 1, status_dev);
-        if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
-    }
     return MOM_OK;
 }
 

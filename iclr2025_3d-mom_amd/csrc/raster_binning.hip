@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int g
 // One workgroup (1024 threads): exclusive scan of the tile counters.
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32_t* __restrict__ tile_counts,
                                                         uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
-                                                        uint32_t* __restrict__ hdr, uint32_t* __restrict__ num_rendered_dev)
+                                                        uint32_t* __restrict__ hdr, uint32_t* __restrict__ num_rendered_dev,
+                                                        uint32_t* __restrict__ num_rendered_host)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
@@ -144,13 +145,16 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
     if (threadIdx.x == 0) {
         hdr[0] = s_carry;
         *num_rendered_dev = s_carry;
+        // device-accessible pinned host memory: the count reaches the host without a copy command behind this kernel
+        if (num_rendered_host) __hip_atomic_store(num_rendered_host, s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
 template <bool LDS_HIST>
 __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, int gx, int gy, int ry0, int ry1, const float4* __restrict__ rec,
                                                           uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
-                                                          uint32_t capacity, uint32_t* __restrict__ hdr)
+                                                          uint32_t capacity, uint32_t* __restrict__ hdr, uint32_t* __restrict__ sticky,
+                                                          uint32_t tag)
 {
     extern __shared__ uint32_t s_cnt[];
     const int tiles = gx * gy;
@@ -187,7 +191,10 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
                 overflow = true;
         });
     }
-    if (overflow) atomicOr(&hdr[1], 1u);
+    if (overflow) {
+        atomicOr(&hdr[1], 1u);
+        if (sticky) atomicCAS(sticky, 0u, tag);         // the FIRST overflow since the caller last cleared the word leaves its tag
+    }
 }
 
 // ---- per-tile sort ------------------------------------------------------------
@@ -271,7 +278,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
 }  // namespace
 
 int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const ImageView& im, uint32_t* num_rendered_dev,
-                             hipStream_t s)
+                             uint32_t* num_rendered_host, hipStream_t s)
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const int tiles = gx * gy;
@@ -292,12 +299,12 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SCAN, s);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tiles, im.tile_counts, im.tile_cursor, im.ranges, im.hdr,
-                       num_rendered_dev);
+                       num_rendered_dev, num_rendered_host);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
 int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
-                            hipStream_t s)
+                            uint32_t* status_dev, hipStream_t s)
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const int tiles = gx * gy;
@@ -307,13 +314,14 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     if (chunks < 1) chunks = 1;
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
+    const uint32_t tag = a->overflow_tag ? a->overflow_tag : 1u;
     mom_prof_begin(MOM_P_SCATTER, s);
     if (tiles <= kMaxLdsTiles)
         hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy,
-                           ry0, ry1, g.rec, im.tile_cursor, b.keys, cap, im.hdr);
+                           ry0, ry1, g.rec, im.tile_cursor, b.keys, cap, im.hdr, status_dev, tag);
     else
         hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, ry0, ry1, g.rec,
-                           im.tile_cursor, b.keys, cap, im.hdr);
+                           im.tile_cursor, b.keys, cap, im.hdr, status_dev, tag);
     mom_prof_end(MOM_P_SCATTER, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SORT, s);

@@ -57,7 +57,12 @@ class FusedStep:
         self.cap = 0
         self.binning = None
         self._resize_next = False
-        self.dimg, self.sums = e(3, H, W), e(2)
+        self.next_tag = 1
+        self.dimg = e(3, H, W)
+        # loss accumulators live in spare words of the image scratch's header, which the rasterizer forward clears at the start
+        # of every step together with its tile counters: no memset of their own (mom_l1_loss_acc / mom_plane_regulation_acc)
+        hdr_f = self.img[(-self.img.data_ptr()) % 256:][:256].view(torch.float32)
+        self.sums, self.regval = hdr_f[8:10], hdr_f[10:11]
         self.ssim_dm = None                  # SSIM term: made on first use (lambda_dssim may be switched on later)
         self.g2d, self.gcol, self.gop_act, self.gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 6)
         self.gsc_act, self.grot_act = e(P, 3), e(P, 4)
@@ -71,7 +76,6 @@ class FusedStep:
         self.gdc, self.grest = seg(0).view(P, 1, 3), seg(1).view(P, 15, 3)
         self.gsc, self.grot, self.gop = seg(2).view(P, 3), seg(3).view(P, 4), seg(4).view(P, 1)
         self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
-        self.regval = e(1)
 
     RING = 64
     HEADROOM, MARGIN = 1.5, 65536     # binning capacity = HEADROOM x an earlier frame's instance count + MARGIN
@@ -82,7 +86,7 @@ class FusedStep:
 
     def post_flag(self, slot):
         """Copy the overflow word to ring slot `slot` behind everything enqueued so far; the returned event tells when the
-        slot is valid."""
+        slot is valid.  The word holds 0 or the tag of the FIRST step that overflowed since it was cleared."""
         self.flag_ring[slot:slot + 1].copy_(self.flags, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -172,6 +176,7 @@ class FusedStep:
         a.scale_modifier = 1.0
         a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         a.prefiltered, a.debug = 0, 0
+        a.overflow_tag = self.next_tag          # what this step leaves in the sticky word if its binning overflows (Trainer numbers the steps)
         dc = self.dist
         rows = fwd_rows = None
         if dc is not None and dc.mode == "tile-row":
@@ -202,7 +207,7 @@ class FusedStep:
             dc.start(self.flags, "max")         # every rank skips (and later replays) the same steps
         # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
         n = self.color.numel()
-        N.check(lib.mom_l1_loss(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
+        N.check(lib.mom_l1_loss_acc(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
         # camera-batch shard: the batch loss is the mean over the ranks' cameras (train_4DGS.py:189-229), so every
         # gradient carries 1/world and the all-reduces below are plain sums (1/2, 1/4, 1/8 are exact in fp32)
         inv_world = 1.0 / dc.world if (dc is not None and dc.mode == "camera") else 1.0
@@ -314,7 +319,7 @@ class FusedStep:
                     arr[i].grad_scale = inv_world      # identical on every rank: the sum over ranks restores it
                 self._reg_arr = (rkey, arr)
             arr = self._reg_arr[1]
-            N.check(lib.mom_plane_regulation(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
+            N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
             reg = self.regval
         if dc is not None and dc.mode == "camera":
             dc.start(self._dg_flat, "sum")     # xyz + deformation field; the caller waits (DistContext.finish) before Adam
@@ -327,7 +332,7 @@ class FusedStep:
         for p, gbuf in zip(mlp, self._dg_mlp):
             p.grad = gbuf
         if rows is None:
-            l1 = self.sums[0] / n
+            l1 = None                        # formed lazily from self.sums (LazyLoss): no kernels for a value nobody may read
         else:
             # the image holds this rank's rows only: the logged L1 is the sum of the ranks' row slabs (value only; the
             # gradient image above is already normalised by the whole image's element count)
@@ -346,8 +351,38 @@ class FusedStep:
             if lam != 0:
                 self.ssim_sum[0] = tot[2].double()
             l1 = tot[0] / n
-        loss = l1 if reg is None else l1 + reg[0]
-        if lam != 0:
-            loss = loss + lam * (1.0 - (self.ssim_sum[0] / n).float())
-        self.last = {"l1": l1, "loss": loss, "mse_sum": self.sums[1], "n": n}
+        loss = LazyLoss(self.sums if l1 is None else None, l1, reg, self.ssim_sum if lam != 0 else None, lam, n)
+        self.last = {"loss": loss, "mse_sum": self.sums[1], "n": n}
         return loss, self.radii, self.g2d
+
+
+class LazyLoss:
+    """The step's loss value, formed on demand from the accumulators the kernels left on the device (the training loop only
+    needs it for logging): float(loss), loss.item(), loss.tensor().  The accumulators are overwritten by the next step, so a
+    value wanted later must be taken (tensor()) before that step is enqueued; tensor() is stream-ordered like any torch op."""
+
+    def __init__(self, sums, l1, reg, ssim_sum, lam, n):
+        self._sums, self._l1, self._reg, self._ssim, self._lam, self._n, self._t = sums, l1, reg, ssim_sum, lam, n, None
+
+    @property
+    def l1(self):
+        return self._l1 if self._l1 is not None else self._sums[0] / self._n
+
+    def tensor(self):
+        if self._t is None:
+            v = self.l1
+            if self._reg is not None:
+                v = v + self._reg[0]
+            if self._ssim is not None:
+                v = v + self._lam * (1.0 - (self._ssim[0] / self._n).float())
+            self._t = v
+        return self._t
+
+    def detach(self):
+        return self.tensor().detach()
+
+    def item(self):
+        return self.tensor().item()
+
+    def __float__(self):
+        return float(self.tensor())

@@ -31,19 +31,21 @@ class Trainer:
         if fused and stage == "fine" and opt.batch_size == 1:
             from .fused_step import FusedStep
             self.fused = FusedStep(gaussians, opt, hyper, self.background)
-        # fused steps whose overflow word has not been read yet: (iteration, camera, ring slot, event), oldest first
-        self._pending = deque()
+        # every fused step since the last verified one: (serial, iteration, camera); and the overflow-word read-backs in flight:
+        # (serial of the last step they cover, ring slot, event)
+        self._log = deque()
+        self._checks = deque()
         self._serial = 0
         self.replayed = 0    # iterations replayed after a binning overflow (diagnostics)
 
     # The host enqueues a fused step without knowing whether the step's binning buffer will be large enough (it is sized
     # from earlier frames; waiting for the count would be the reference's per-iteration sync, rasterizer_impl.cu:282).
-    # A step that does not fit sets a sticky device word that turns its own and every later Adam / statistics launch into
-    # no-ops (FusedStep.flags).  The host reads the word FLAG_LAG steps later -- a fixed lag, so that all ranks of a
-    # multi-GPU run reach the same decision at the same step -- and, if it is set, clears it and replays the logged
-    # iterations from the first skipped one with exactly sized buffers.  The model therefore always equals what a fully
-    # synchronous run would have produced.
-    FLAG_LAG = 8
+    # A step that does not fit leaves its tag in a sticky device word; from then on every Adam / statistics launch is a no-op
+    # (FusedStep.flags).  The host copies the word back every CHECK_EVERY steps and looks at a copy FLAG_LAG read-backs later
+    # -- a fixed lag, so that all ranks of a multi-GPU run reach the same decision at the same step -- and, if it is set,
+    # clears it and replays the logged iterations from the tagged one on with exactly sized buffers.  The model therefore
+    # always equals what a fully synchronous run would have produced.
+    CHECK_EVERY, FLAG_LAG = 4, 2
 
     def _boundary(self, iteration):
         """Iterations whose host logic reads or restructures model state (densify / prune / opacity reset / SH bump): every
@@ -52,30 +54,39 @@ class Trainer:
         return (iteration % o.densification_interval == 0 or iteration % o.pruning_interval == 0
                 or iteration % o.opacity_reset_interval == 0 or iteration % 1000 == 0)
 
+    def _post_check(self):
+        if self._log and (not self._checks or self._checks[-1][0] != self._log[-1][0]):
+            slot = len(self._checks) % self.fused.RING if not self._checks else (self._checks[-1][1] + 1) % self.fused.RING
+            self._checks.append((self._log[-1][0], slot, self.fused.post_flag(slot)))
+
     def _poll(self, lag):
-        while len(self._pending) > lag:
-            it, cam, slot, ev = self._pending[0]
+        while len(self._checks) > lag:
+            upto, slot, ev = self._checks.popleft()
             ev.synchronize()
-            if int(self.fused.flag_ring[slot]) != 0:
-                self._recover()
+            tag = int(self.fused.flag_ring[slot])
+            if tag != 0:
+                self._recover(tag)
                 return
-            self._pending.popleft()
+            while self._log and self._log[0][0] <= upto:
+                self._log.popleft()
 
     def drain(self):
         """Every step enqueued so far has been applied to the model (replaying the ones an overflow skipped)."""
         if self.fused is not None:
+            self._post_check()
             self._poll(0)
 
-    def _recover(self):
+    def _recover(self, tag):
         torch.cuda.synchronize()
-        entries = list(self._pending)
-        self._pending.clear()
-        ring = self.fused.flag_ring
-        bad = next(i for i, e in enumerate(entries) if int(ring[e[2]]) != 0)   # the word is sticky: all later ones are set too
-        redo = entries[bad:]
+        self._checks.clear()
+        # the step tagged `tag` overflowed; it and every later one were no-ops on the device; all earlier ones are in
+        entries = list(self._log)
+        self._log.clear()
+        first = next((i for i, e in enumerate(entries) if ((e[0] & 0x7FFFFFFF) + 1) == tag), 0)
+        redo = entries[first:]
         self.g.optimizer.rewind(len(redo))      # the host counted steps the device skipped
         self.fused.flags.zero_()
-        for it, cam, _, _ in redo:
+        for _, it, cam in redo:
             self.g.update_learning_rate(it)
             self.fused.exact_next()
             self._step_fused(it, cam, replay=True)
@@ -98,6 +109,8 @@ class Trainer:
                 self.drain()
                 self.fused.exact_next()
             else:
+                if len(self._log) and len(self._log) % self.CHECK_EVERY == 0:
+                    self._post_check()
                 self._poll(self.FLAG_LAG)
         g.update_learning_rate(iteration)
         if iteration % 1000 == 0:
@@ -150,6 +163,9 @@ class Trainer:
 
     def _step_fused(self, iteration, cam, replay=False):
         with torch.no_grad():
+            if not replay:
+                self._serial += 1
+            self.fused.next_tag = (self._serial & 0x7FFFFFFF) + 1
             loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale)
             self.g.optimizer.skip_flag = self._skip = self.fused.flags
             if self.dist is not None:
@@ -159,16 +175,14 @@ class Trainer:
                 self.dist.seed_for(iteration)
             visibility = None          # the statistics kernel derives it from the radii (update_densification_stats)
             if self.sync_every_step:
-                if torch.isnan(loss).any():
+                if torch.isnan(loss.tensor()).any():
                     raise FloatingPointError("loss is nan")
                 self.ema_loss = 0.4 * loss.item() + 0.6 * self.ema_loss
-            self.last = {"loss": loss, "l1": self.fused.last["l1"], "points": self.g._xyz.shape[0]}
+            self.last = {"loss": loss, "points": self.g._xyz.shape[0]}
         loss = self._after_backward(iteration, loss, radii, visibility, vsp_grad)
         self._skip = None
         if not replay:
-            slot = self._serial % self.fused.RING
-            self._serial += 1
-            self._pending.append((iteration, cam, slot, self.fused.post_flag(slot)))
+            self._log.append((self._serial, iteration, cam))
         return loss
 
     def _after_backward(self, iteration, loss, radii, visibility, vsp_grad):

@@ -77,6 +77,9 @@ typedef struct MomRasterArgs {
      * backward reads -- cov3D[P][6], clamped[P], final_T[H*W], n_contrib[H*W] -- is not written (about 28 B per Gaussian and
      * 8 B per pixel).  mom_raster_backward on such a forward is an error the caller must not make. */
     int forward_only;
+    /* What mom_raster_forward_render leaves in *status_dev when this call's binning overflows (0 = 1): a caller that runs
+     * ahead of the GPU numbers its calls here and later reads WHICH call overflowed first. */
+    uint32_t overflow_tag;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
@@ -100,10 +103,11 @@ int mom_raster_forward_geometry(const MomRasterArgs* a, void* geom, void* image,
  * (result identical to the reference's global sort of (tile<<32|depth) keys:
  * rasterizer_impl.cu:70-111,301-318) and alpha compositing (renderCUDA,
  * forward.cu:261-379).  `capacity` is the instance capacity the binning buffer
- * was sized for; if the true count exceeds it nothing beyond capacity is written,
- * bit 0 is OR-ed into *status_dev and the image is incomplete.  The word is STICKY: the call
- * only ever sets bits, the caller zeroes it (before the first call, and after it has dealt
- * with an overflow), so a host that reads it late cannot miss one.
+ * was sized for; if the true count exceeds it nothing beyond capacity is written, the image
+ * is incomplete, and if *status_dev (may be null) is still 0 it receives a->overflow_tag (1
+ * when that is 0).  The word is STICKY: the call never clears it, the caller zeroes it (before
+ * the first call, and after it has dealt with an overflow), so a host that reads it late cannot
+ * miss an overflow and learns which call overflowed first.
  * out_color [3,H,W], out_depth [1,H,W]. */
 int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning, size_t capacity, void* image,
                               float* out_color, float* out_depth, uint32_t* status_dev, mom_stream_t stream);
@@ -249,6 +253,8 @@ int mom_adam_step(const MomAdamTensor* tensors, int count, double beta1, double 
  * sums2[0] = sum |img-gt|, sums2[1] = sum (img-gt)^2 over n elements (zeroed by the call);
  * dimg (may be null) = sign(img-gt)/n = d mean|img-gt| / d img. */
 int mom_l1_loss(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream);
+/* the same without zeroing sums2 first: for a caller that keeps them in memory it clears anyway */
+int mom_l1_loss_acc(size_t n, const float* img, const float* gt, float* dimg, float* sums2, mom_stream_t stream);
 
 /* ---- Row selection for densify / prune (scene/gaussian_model.py:409-482 _prune_optimizer, cat_tensors_to_optimizer,
  * prune_points; :511-581 densify_and_split, densify_and_clone, prune: `tensor[mask]` once per parameter, per Adam moment and
@@ -314,6 +320,7 @@ typedef struct MomRegPlane {
     float w_smooth, w_l1, grad_scale;
 } MomRegPlane;
 int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom_stream_t stream);
+int mom_plane_regulation_acc(const MomRegPlane* planes, int count, float* value, mom_stream_t stream);   /* value is not zeroed first */
 
 /* ---- fused deformation MLP (scene/deformation.py:53-65,97-135; W = 64, defor_depth = 0, heads pos/scales/rot) ----
  *   h0 = W0 feat + b0 ;  o_k = W2_k relu(W1_k relu(h0) + b1_k) + b2_k  for k in {pos, scales, rot}

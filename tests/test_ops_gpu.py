@@ -392,7 +392,7 @@ def test_densify_and_prune_round_matches_mask_indexing_on_the_gpu():
                 out["m_" + grp["name"]], out["v_" + grp["name"]] = st["exp_avg"], st["exp_avg_sq"]
         snap = {k: v.detach().cpu().clone() for k, v in out.items()}
         loss = trainer.step(5101, cams=[trainer.cams[0]])      # the model still trains after the surgery
-        assert torch.isfinite(loss).all()
+        assert np.isfinite(float(loss))
         return (n0, n1, n2), snap
 
     (a0, a1, a2), hip = run(True)
