@@ -1,10 +1,10 @@
 """Per-kernel means of the counters in rocprofv3 --pmc counter_collection CSVs (one row per dispatch and counter):
     python tools/pmc_sq.py gpurun_out/<tag>/pass*_counter_collection.csv [--json out.json]
 Prints one line per kernel with the mean of every counter over its dispatches (the first 5 dispatches of a kernel are
-warm-up and left out), the launch count and, when SQ_BUSY_CYCLES and SQ_INSTS_VALU are both present, VALU instructions issued
-per SIMD-cycle: SQ_INSTS_VALU / (SQ_BUSY_CYCLES / 32 shader engines * 1024 SIMDs / 4) -- a wave64 VALU instruction occupies its
-SIMD's issue port for 4 of the quad-cycles that counter ticks in (MI355X_MICROARCH.md: SQ_* cycle counters count quad-cycles,
-SQ_BUSY_CYCLES is summed over the 32 shader engines)."""
+warm-up and left out), the launch count and, when SQ_BUSY_CYCLES and SQ_INSTS_VALU are both present, the fraction of the
+kernel's SIMD-cycles in which a VALU instruction occupied the issue port: 4 * SQ_INSTS_VALU / (SQ_BUSY_CYCLES / 32 * 1024) --
+a wave64 VALU instruction holds its SIMD's port for 4 cycles, SQ_BUSY_CYCLES counts shader cycles summed over the 32 shader
+engines (it reproduces the kernel's duration at 2.1-2.4 GHz), there are 1024 SIMDs."""
 import collections
 import csv
 import json
@@ -38,8 +38,8 @@ def main():
         t = table[k]
         extra = ""
         if "SQ_BUSY_CYCLES" in t and "SQ_INSTS_VALU" in t and t["SQ_BUSY_CYCLES"] > 0:
-            simd_quad_cycles = t["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
-            t["valu_issue_frac"] = t["SQ_INSTS_VALU"] / simd_quad_cycles
+            simd_cycles = t["SQ_BUSY_CYCLES"] / 32.0 * 1024.0
+            t["valu_issue_frac"] = 4.0 * t["SQ_INSTS_VALU"] / simd_cycles
             extra = f"  valu_issue_frac {t['valu_issue_frac']:.3f}"
         print(f"{k:34s} " + "  ".join(f"{c} {v:.4g}" for c, v in sorted(t.items()) if c not in ("valu_issue_frac",)) + extra)
     if out_json:

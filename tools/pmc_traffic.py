@@ -27,7 +27,8 @@ import sys
 
 # kernel symbol -> the name bench.py / profiling.py use
 NAMES = {
-    "render_bwd_kernel": "render_bwd", "render_fwd_kernel": "render_fwd", "hexplane_bwd4_kernel": "hexplane_bwd",
+    "render_bwd_kernel": "render_bwd", "render_fwd_kernel": "render_fwd", "hexplane_bwd5_gather_kernel": "hexplane_bwd_gather",
+    "hexplane_bwd5_scatter_kernel": "hexplane_bwd_scatter",
     "hexplane_fwd4_kernel": "hexplane_fwd", "adam_kernel": "adam", "l1_kernel": "l1_loss",
     "preprocess_fwd_kernel": "preprocess_fwd", "preprocess_bwd_kernel": "preprocess_bwd", "tile_sort_kernel": "tile_sort",
     "deform_fwd_kernel": "mlp_fwd", "deform_bwd_dx_kernel": "mlp_bwd_dx", "deform_bwd_dw_kernel": "mlp_bwd_dw",
