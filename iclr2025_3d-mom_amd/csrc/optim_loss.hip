@@ -130,25 +130,35 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __rest
         // value terms s_h for h in its range and writes the gradient of its rows (needs s_{h-2} .. s_h => rows h-2 .. h+2).
         const float cs = (H > 2 && P.w_smooth != 0.f) ? P.w_smooth / ((float)(H - 2) * (float)row) : 0.f;
         const float cl = P.w_l1 != 0.f ? P.w_l1 / ((float)H * (float)row) : 0.f;
-        auto T = [&](int h) { return (h >= 0 && h < H) ? t[(size_t)h * row + col] : 0.f; };
+        // all kRegRows + 4 rows of the column and the kRegRows gradient values are loaded up front: 36 independent loads in
+        // flight per thread instead of a chain of dependent ones (the strip is latency bound: 35 MB per launch)
+        float tv[kRegRows + 4], gv[kRegRows];
+#pragma unroll
+        for (int k = 0; k < kRegRows + 4; k++) {
+            const int h = h_begin - 2 + k;
+            tv[k] = (h >= 0 && h < H) ? t[(size_t)h * row + col] : 0.f;
+        }
+        if (g) {
+#pragma unroll
+            for (int k = 0; k < kRegRows; k++) gv[k] = (h_begin + k < h_end) ? g[(size_t)(h_begin + k) * row + col] : 0.f;
+        }
         auto S = [&](int h, float a0, float a1, float a2) { return (h >= 0 && h + 2 < H) ? (a2 - 2.f * a1 + a0) : 0.f; };
-        float tm2 = T(h_begin - 2), tm1 = T(h_begin - 1), t0 = T(h_begin), t1 = T(h_begin + 1);
-        float sm2 = S(h_begin - 2, tm2, tm1, t0), sm1 = S(h_begin - 1, tm1, t0, t1);
-        for (int h = h_begin; h < h_end; h++) {
-            const float t2 = T(h + 2);
-            const float sh = S(h, t0, t1, t2);
-            val += cs * sh * sh;
-            float gr = 2.f * cs * (sm2 - 2.f * sm1 + sh);
-            if (cl != 0.f) {
-                const float d = 1.f - t0;
-                val += cl * fabsf(d);
-                gr += d > 0.f ? -cl : (d < 0.f ? cl : 0.f);
+#pragma unroll
+        for (int k = 0; k < kRegRows; k++) {
+            const int h = h_begin + k;
+            if (h < h_end) {
+                // tv[k] = t[h-2], tv[k+1] = t[h-1], tv[k+2] = t[h], tv[k+3] = t[h+1], tv[k+4] = t[h+2]
+                const float sm2 = S(h - 2, tv[k], tv[k + 1], tv[k + 2]), sm1 = S(h - 1, tv[k + 1], tv[k + 2], tv[k + 3]);
+                const float sh = S(h, tv[k + 2], tv[k + 3], tv[k + 4]);
+                val += cs * sh * sh;
+                float gr = 2.f * cs * (sm2 - 2.f * sm1 + sh);
+                if (cl != 0.f) {
+                    const float d = 1.f - tv[k + 2];
+                    val += cl * fabsf(d);
+                    gr += d > 0.f ? -cl : (d < 0.f ? cl : 0.f);
+                }
+                if (g) g[(size_t)h * row + col] = gv[k] + gr * P.grad_scale;
             }
-            if (g) g[(size_t)h * row + col] += gr * P.grad_scale;
-            sm2 = sm1;
-            sm1 = sh;
-            t0 = t1;
-            t1 = t2;
         }
     }
     const float tot = block_sum(val, s);
