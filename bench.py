@@ -279,12 +279,19 @@ def main():
         DGR.set_sync_mode("async", capacity_hint=int(R * 1.6) + 65536)
     # per-camera instance counts (R is data dependent: SURVEY 8d asks for it with every timing).  One untimed pass over the
     # cameras this rank will draw; each step's count is read after a synchronisation.
-    r_of_cam = {}
+    # R is the REFERENCE's instance count -- every tile of every splat's rectangle (duplicateWithKeys) -- which is what the
+    # algorithmic bytes are defined on; the default binning drops the instances that cannot contribute, and that smaller
+    # count is reported beside it (instances_binned).  So: two passes, the first with keep_all_tiles.
+    r_of_cam, binned_of_cam = {}, {}
     if trainer.fused is not None:
-        for i in range(1, 1 + len(cams)):        # every rank makes the same number of calls (the steps hold collectives)
-            one(i)
-            torch.cuda.synchronize()
-            r_of_cam[id(cam_of(i))] = int(trainer.fused.nr_host[0])
+        for keep_all, table in ((True, r_of_cam), (False, binned_of_cam)):
+            trainer.fused.keep_all_tiles = keep_all
+            trainer.fused.exact_next()
+            for i in range(1, 1 + len(cams)):    # every rank makes the same number of calls (the steps hold collectives)
+                one(i)
+                torch.cuda.synchronize()
+                table[id(cam_of(i))] = int(trainer.fused.nr_host[0])
+        trainer.fused.exact_next()
     prof = importlib.import_module("iclr2025_3d-mom_amd.profiling")
 
     def timed(first, steps, profile_kernel=None):
@@ -315,7 +322,12 @@ def main():
             dt = float(tt[0])
         rs = [instances_of(first + i) for i in range(steps)]
         rs = [r for r in rs if r is not None]
+        bs = [binned_of_cam.get(id(cam_of(first + i))) for i in range(steps)]
+        bs = [b for b in bs if b is not None]
+        binned_mean[0] = sum(bs) / len(bs) if bs else None
         return dt, loss, (sum(rs) / len(rs) if rs else float(R))
+
+    binned_mean = [None]
 
     scale = world if a.shard == "camera" else 1
     nxt = 1 + len(cams)
@@ -331,7 +343,7 @@ def main():
         assert torch.isfinite(loss_s).all(), "loss is not finite (steady leg)"
         b = step_bytes(cfg["P"], r_mean, npix, a.lambda_dssim)
         steady = {"value": a.steady_steps * scale / dts, "unit": "steps/s", "steps": a.steady_steps, "warmup": a.steady_warmup,
-                  "ms_per_step": 1e3 * dts / a.steady_steps, "instances_R_mean": r_mean,
+                  "ms_per_step": 1e3 * dts / a.steady_steps, "instances_R_mean": r_mean, "instances_binned_mean": binned_mean[0],
                   "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": b, "achieved": b * a.steady_steps / dts / 1e9,
                                     "peak": 8000.0, "unit": "GB/s", "frac": b * a.steady_steps / dts / 1e9 / 8000.0,
                                     "formula": "P*2751 + R*172 + Npix*84 + 116 MB (SURVEY 8d); per GPU"}}
@@ -347,7 +359,10 @@ def main():
         "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak" if a.shard == "camera" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "gaussians": cfg["P"], "frames": cfg["F"], "width": cfg["W"],
-                   "height": cfg["H"], "instances_R": r_mean, "instances_R_is": "mean over the cameras of the timed steps",
+                   "height": cfg["H"], "instances_R": r_mean,
+                   "instances_R_is": "the reference's count (every tile of every splat's rectangle), mean over the cameras of the timed steps",
+                   "instances_binned": binned_mean[0],
+                   "instances_binned_is": "what the default binning keeps: instances that can reach alpha >= 1/255 in their tile",
                    "sh_degree": 3, "step_path": a.path, "batch_size": 1,
                    "lambda_dssim": a.lambda_dssim, "parallelism": (f"camera-batch x{world}" if a.shard == "camera" else f"tile-row x{world}") if world > 1 else "single",
                    "ranks_seen": ranks_seen, "host_sync": a.sync_mode, "final_loss": float(loss), "densify_in_window": bool(a.with_densify),

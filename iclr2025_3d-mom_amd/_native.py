@@ -30,7 +30,8 @@ class MomRasterArgs(C.Structure):
                 ("tan_fovx", C.c_float), ("tan_fovy", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int),
                 ("tile_row0", C.c_int), ("tile_row1", C.c_int),     # tile-row shard: 0,0 = every row
                 ("forward_only", C.c_int),                          # no backward will follow: skip the state only it reads
-                ("overflow_tag", C.c_uint)]                         # what an overflow of this call leaves in *status_dev
+                ("overflow_tag", C.c_uint),                         # what an overflow of this call leaves in *status_dev
+                ("keep_all_tiles", C.c_int)]                        # !=0: bin the whole rectangle like the reference (tests)
 
 
 class MomRasterGrads(C.Structure):

@@ -11,7 +11,8 @@
 // ---- private scratch layouts -------------------------------------------------
 // geom (per Gaussian):
 //   rec[P][3] float4 : {x, y, depth, tiles_touched bits} {conic.x, conic.y, conic.z, opacity} {r, g, b, radius bits}
-//   cov3D[P][6] float, clamped[P] uchar4, gacc[P][12] float (backward accumulators)
+//   cov3D[P][6] float, clamped[P] uchar4, gacc[P][12] float (backward accumulators), reach[P] u64 (tile cull: bit i =
+//   tile i of the splat's rectangle is binned; written by tile_hist, read by tile_scatter)
 // image: hdr[64] u32, tile_counts[tiles] u32, tile_cursor[tiles] u32, ranges[tiles] uint2, n_contrib[H*W] u32,
 //        final_T[H*W] f32
 // binning: keys[cap] u64, point_list[cap] u32   (sized once the instance count is known)
@@ -20,6 +21,7 @@ struct GeomView {
     float* cov3D;
     uchar4* clamped;
     float* gacc;
+    unsigned long long* reach;
 };
 struct ImageView {
     uint32_t* hdr;  // [0] = num_rendered, [1] = status bits
@@ -43,11 +45,13 @@ static inline size_t geom_view(char* base, int P, GeomView* v)
     size_t o_cov = off; off = mom_align_up(off + (size_t)P * 24);
     size_t o_cl = off; off = mom_align_up(off + (size_t)P * 4);
     size_t o_ga = off; off = mom_align_up(off + (size_t)P * 48);
+    size_t o_re = off; off = mom_align_up(off + (size_t)P * 8);
     if (v) {
         v->rec = (float4*)(base + o_rec);
         v->cov3D = (float*)(base + o_cov);
         v->clamped = (uchar4*)(base + o_cl);
         v->gacc = (float*)(base + o_ga);
+        v->reach = (unsigned long long*)(base + o_re);
     }
     return off + MOM_ALIGN;
 }
@@ -141,6 +145,52 @@ __device__ __forceinline__ float mom_exp(float x)
     e = __builtin_fmaf(x, L2E_LO, e);
     float r = __builtin_amdgcn_exp2f(t);
     return __builtin_fmaf(r * 0.6931471805599453f, e, r);
+}
+
+// ---- which pixels can a splat reach? ----------------------------------------------------------------------------------
+// A splat is composited at a pixel only if alpha = min(0.99, opacity * exp(power)) >= 1/255, i.e. only if
+// power >= ln(1 / (255 opacity)).  mom_power_bound is that bound lowered by a margin that dwarfs the rounding of logf, of
+// the product and of mom_exp (all below 1e-6 here).  The exponent is concave, so its maximum over a rectangle of pixel
+// centres is 0 if the splat's centre is inside and otherwise lies on an edge, at the clamped stationary point of the
+// edge's 1-D quadratic: mom_rect_reach evaluates that on the continuous rectangle, with a second margin, and therefore
+// keeps every (splat, pixel) pair the exact per-pixel tests of the compositing kernels could accept.  Those tests still
+// run on whatever is kept, so culling by this predicate never changes a result.  Anything degenerate (non-positive conic
+// diagonal, NaN anywhere) counts as reachable; written as !(best < bound) so that a NaN falls through.
+__device__ __forceinline__ float mom_power_bound(float opacity) { return -logf(255.0f * opacity) - 1e-3f; }
+__device__ __forceinline__ float mom_edge_max(float fixed, float lo, float hi, float q_fixed, float q_free, float inv_q_free, float b)
+{
+    // max over t in [lo, hi] of  -0.5 (q_fixed fixed^2 + q_free t^2) - b fixed t.  The stationary point uses a hardware
+    // reciprocal (1 ulp): the quadratic is flat there, so its error is second order and far inside the caller's margin.
+    // Contraction off: the tile histogram and the tile scatter must take the same decision for the same (splat, tile).
+#pragma clang fp contract(off)
+    const float t = fminf(fmaxf(-b * fixed * inv_q_free, lo), hi);
+    return -0.5f * (q_fixed * fixed * fixed + q_free * t * t) - b * fixed * t;
+}
+// centre (cx, cy), conic (a, b, c), bound = mom_power_bound(opacity), inv_a = 1/a, inv_c = 1/c (hardware reciprocals are
+// enough); pixel centres xa..xb by ya..yb.  The caller has checked a > 0 and c > 0.
+// Only the edges FACING the centre are evaluated: with p a maximiser on the rectangle and q the centre, concavity gives
+// f((1-e) p + e q) >= f(p), so if p were on an edge facing away a step towards q would stay inside and be no worse.  The
+// facing x edge is x = clamp(cx, xa, xb) (the line through the centre when cx is inside the columns, also a valid
+// candidate), and the same for y; both evaluate to 0 when the centre is inside the rectangle.
+__device__ __forceinline__ bool mom_rect_reach(float cx, float cy, float a, float b, float c, float bound, float inv_a, float inv_c,
+                                               float xa, float xb, float ya, float yb)
+{
+#pragma clang fp contract(off)
+    const float dxl = cx - xb, dxh = cx - xa;        // dx = cx - px over the rectangle's columns
+    const float dyl = cy - yb, dyh = cy - ya;
+#ifdef MOM_FOUR_EDGES
+    float best;
+    if (cx >= xa && cx <= xb && cy >= ya && cy <= yb) {
+        best = 0.f;
+    } else {
+        best = fmaxf(fmaxf(mom_edge_max(dxl, dyl, dyh, a, c, inv_c, b), mom_edge_max(dxh, dyl, dyh, a, c, inv_c, b)),
+                     fmaxf(mom_edge_max(dyl, dxl, dxh, c, a, inv_a, b), mom_edge_max(dyh, dxl, dxh, c, a, inv_a, b)));
+    }
+#else
+    const float dxn = cx - fminf(fmaxf(cx, xa), xb), dyn = cy - fminf(fmaxf(cy, ya), yb);
+    const float best = fmaxf(mom_edge_max(dxn, dyl, dyh, a, c, inv_c, b), mom_edge_max(dyn, dxl, dxh, c, a, inv_a, b));
+#endif
+    return !(best < bound - 1e-3f);
 }
 
 __device__ __forceinline__ int mom_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

@@ -33,37 +33,136 @@ constexpr int kSortLdsCap = 8192;      // 64 KiB of 64-bit keys per workgroup: t
 constexpr int kSortSmallCap = MOM_SORT_SMALL;   // tiles up to this size go to the launch with the small LDS footprint
 constexpr int kMaxLdsTiles = 16384;    // 64 KiB LDS histogram
 
-// Calls f(tile, src_lane, src_payload) once for every (Gaussian, tile) instance of this wave's 64
-// Gaussians.  Lanes own small rectangles; large ones are walked by the whole wave (the owner's payload
-// is broadcast with v_readlane before the divergent loop).
+// What the tile cull needs of a splat (mom_rect_reach, mom_common.h).  cull == 0: every tile of the rectangle is kept, as
+// the reference does (MomRasterArgs.keep_all_tiles).
+struct Reach {
+    float cx, cy, a, b, c, bound, inv_a, inv_c;
+    int cull;
+};
+__device__ __forceinline__ bool tile_reached(const Reach& r, int tx, int ty)
+{
+    if (!r.cull) return true;
+    const float xa = (float)(tx * MOM_TILE), ya = (float)(ty * MOM_TILE);
+    return mom_rect_reach(r.cx, r.cy, r.a, r.b, r.c, r.bound, r.inv_a, r.inv_c, xa, xa + (float)(MOM_TILE - 1), ya,
+                          ya + (float)(MOM_TILE - 1));
+}
+__device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
+struct WaveSplat {       // one lane's splat, broadcast to the wave
+    int x0, y0, w, cnt;
+    uint32_t payload;
+    uint64_t mask;
+    Reach rc;
+};
+__device__ __forceinline__ WaveSplat bcast_splat(int x0, int y0, int w, int cnt, uint32_t payload, uint64_t mask, const Reach& rc, int src)
+{
+    WaveSplat o;
+    o.x0 = __builtin_amdgcn_readlane(x0, src);
+    o.y0 = __builtin_amdgcn_readlane(y0, src);
+    o.w = __builtin_amdgcn_readlane(w, src);
+    o.cnt = __builtin_amdgcn_readlane(cnt, src);
+    o.payload = (uint32_t)__builtin_amdgcn_readlane((int)payload, src);
+    o.mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mask >> 32), src) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, src);
+    o.rc.cx = bcast(rc.cx, src); o.rc.cy = bcast(rc.cy, src); o.rc.a = bcast(rc.a, src); o.rc.b = bcast(rc.b, src);
+    o.rc.c = bcast(rc.c, src); o.rc.bound = bcast(rc.bound, src); o.rc.inv_a = bcast(rc.inv_a, src);
+    o.rc.inv_c = bcast(rc.inv_c, src);
+    o.rc.cull = __builtin_amdgcn_readlane(rc.cull, src);
+    return o;
+}
+// i / w for 0 <= i, 1 <= w <= 64 * 64: (i + 0.5) / w is at least 0.5 / w away from an integer, far more than the error of
+// the hardware reciprocal and the product
+__device__ __forceinline__ int small_div(int i, float inv_w) { return (int)(((float)i + 0.5f) * inv_w); }
+
+// Pass 1 (tile_hist): decides, for every (Gaussian, tile) instance of this wave's 64 Gaussians, whether it is binned
+// (tile_reached), calls f(tile) for those that are, and returns the lane's own decisions as a mask: bit i = tile i of the
+// rectangle, row-major, for i < 64 (tile_scatter evaluates tiles beyond 64 again).  Lanes own small rectangles; large ones
+// are walked by the whole wave, one tile per lane, and the ballot IS the mask.
 template <class F>
-__device__ __forceinline__ void for_each_instance(int x0, int y0, int x1, int y1, int gx, uint32_t payload, F f)
+__device__ __forceinline__ uint64_t decide_instances(int x0, int y0, int x1, int y1, int gx, const Reach& rc, F f)
 {
     const int lane = mom_lane();
     const int w = x1 - x0;
     const int cnt = w * (y1 - y0);
+    uint64_t mask = 0;
     if (cnt <= kSmallRect) {
-        for (int i = 0; i < cnt; i++) f((y0 + i / w) * gx + x0 + i % w, lane, payload);
+        int tx = x0, ty = y0;
+        for (int i = 0; i < cnt; i++) {
+            if (tile_reached(rc, tx, ty)) {
+                mask |= 1ull << i;
+                f(ty * gx + tx);
+            }
+            if (++tx == x1) { tx = x0; ty++; }
+        }
     }
     unsigned long long big = __ballot(cnt > kSmallRect);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
-        const int bx0 = __builtin_amdgcn_readlane(x0, src);
-        const int by0 = __builtin_amdgcn_readlane(y0, src);
-        const int bw = __builtin_amdgcn_readlane(w, src);
-        const int bcnt = __builtin_amdgcn_readlane(cnt, src);
-        const uint32_t bpay = (uint32_t)__builtin_amdgcn_readlane((int)payload, src);
-        for (int i = lane; i < bcnt; i += MOM_WAVE) f((by0 + i / bw) * gx + bx0 + i % bw, src, bpay);
+        const WaveSplat b = bcast_splat(x0, y0, w, cnt, 0u, 0ull, rc, src);
+        const float inv_w = __builtin_amdgcn_rcpf((float)b.w);
+        for (int base = 0; base < b.cnt; base += MOM_WAVE) {
+            const int i = base + lane;
+            bool r = false;
+            if (i < b.cnt) {
+                const int q = small_div(i, inv_w);
+                const int tx = b.x0 + i - q * b.w, ty = b.y0 + q;
+                r = tile_reached(b.rc, tx, ty);
+                if (r) f(ty * gx + tx);
+            }
+            if (base == 0) {
+                const uint64_t bal = __ballot(r);
+                if (lane == src) mask = bal;
+            }
+        }
+    }
+    return mask;
+}
+
+// Pass 2 (tile_scatter): calls f(tile, src_lane, src_payload) for the instances pass 1 kept.  A lane walks the set bits of
+// its own mask when they are few; otherwise the wave takes one tile per lane.
+template <class F>
+__device__ __forceinline__ void for_each_kept(int x0, int y0, int x1, int y1, int gx, uint32_t payload, uint64_t mask, const Reach& rc, F f)
+{
+    const int lane = mom_lane();
+    const int w = x1 - x0;
+    const int cnt = w * (y1 - y0);
+    const bool own = cnt <= MOM_WAVE && __popcll(mask) <= kSmallRect;
+    if (own && cnt > 0) {
+        const float inv_w = __builtin_amdgcn_rcpf((float)w);
+        uint64_t m = mask;
+        while (m) {
+            const int i = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int q = small_div(i, inv_w);
+            f((y0 + q) * gx + x0 + i - q * w, lane, payload);
+        }
+    }
+    unsigned long long big = __ballot(!own && cnt > 0);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const WaveSplat b = bcast_splat(x0, y0, w, cnt, payload, mask, rc, src);
+        const float inv_w = __builtin_amdgcn_rcpf((float)b.w);
+        for (int base = 0; base < b.cnt; base += MOM_WAVE) {
+            const int i = base + lane;
+            if (i < b.cnt) {
+                const int q = small_div(i, inv_w);
+                const int tx = b.x0 + i - q * b.w, ty = b.y0 + q;
+                const bool r = base == 0 ? ((b.mask >> lane) & 1) : tile_reached(b.rc, tx, ty);
+                if (r) f(ty * gx + tx, src, b.payload);
+            }
+        }
     }
 }
 
 // ry0, ry1: the tile rows this launch bins (tile-row shard); a splat's rectangle is cut to them.
-__device__ __forceinline__ void load_rect(const float4* __restrict__ rec, int g, int P, int gx, int gy, int ry0, int ry1, int& x0,
-                                          int& y0, int& x1, int& y1, uint32_t& depth_bits)
+__device__ __forceinline__ void load_rect(const float4* __restrict__ rec, int g, int P, int gx, int gy, int ry0, int ry1, int cull,
+                                          int& x0, int& y0, int& x1, int& y1, uint32_t& depth_bits, Reach& rc)
 {
     x0 = y0 = x1 = y1 = 0;
     depth_bits = 0;
+    rc = Reach{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
     if (g < P) {
         const float4 r0 = rec[3 * (size_t)g];
         const int radius = __float_as_int(rec[3 * (size_t)g + 2].w);
@@ -73,13 +172,20 @@ __device__ __forceinline__ void load_rect(const float4* __restrict__ rec, int g,
             y1 = min(y1, ry1);
             if (y1 <= y0) x0 = y0 = x1 = y1 = 0;
             depth_bits = __float_as_uint(r0.z);
+            if (cull) {
+                const float4 r1 = rec[3 * (size_t)g + 1];
+                // a degenerate conic counts as reachable everywhere, like in the compositing kernels' strip test
+                if (r1.x > 0.f && r1.z > 0.f)
+                    rc = Reach{r0.x, r0.y, r1.x, r1.y, r1.z, mom_power_bound(r1.w), __builtin_amdgcn_rcpf(r1.x),
+                               __builtin_amdgcn_rcpf(r1.z), 1};
+            }
         }
     }
 }
 
 template <bool LDS_HIST>
-__global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int gx, int gy, int ry0, int ry1, const float4* __restrict__ rec,
-                                                       uint32_t* __restrict__ tile_counts)
+__global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int gx, int gy, int ry0, int ry1, int cull, const float4* __restrict__ rec,
+                                                       uint32_t* __restrict__ tile_counts, unsigned long long* __restrict__ reach)
 {
     extern __shared__ uint32_t s_cnt[];
     const int tiles = gx * gy;
@@ -91,13 +197,15 @@ __global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int g
         const int g = (blockIdx.x * chunks + c) * 256 + threadIdx.x;
         int x0, y0, x1, y1;
         uint32_t db;
-        load_rect(rec, g, P, gx, gy, ry0, ry1, x0, y0, x1, y1, db);
-        for_each_instance(x0, y0, x1, y1, gx, 0u, [&](int tile, int, uint32_t) {
+        Reach rc;
+        load_rect(rec, g, P, gx, gy, ry0, ry1, cull, x0, y0, x1, y1, db, rc);
+        const uint64_t mask = decide_instances(x0, y0, x1, y1, gx, rc, [&](int tile) {
             if (LDS_HIST)
                 atomicAdd(&s_cnt[tile], 1u);
             else
                 atomicAdd(&tile_counts[tile], 1u);
         });
+        if (g < P) reach[g] = mask;
     }
     if (LDS_HIST) {
         __syncthreads();
@@ -151,7 +259,8 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
 }
 
 template <bool LDS_HIST>
-__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, int gx, int gy, int ry0, int ry1, const float4* __restrict__ rec,
+__global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, int gx, int gy, int ry0, int ry1, int cull, const float4* __restrict__ rec,
+                                                          const unsigned long long* __restrict__ reach,
                                                           uint32_t* __restrict__ tile_cursor, uint64_t* __restrict__ keys,
                                                           uint32_t capacity, uint32_t* __restrict__ hdr, uint32_t* __restrict__ sticky,
                                                           uint32_t tag)
@@ -166,8 +275,9 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
             const int g = (blockIdx.x * chunks + c) * 256 + threadIdx.x;
             int x0, y0, x1, y1;
             uint32_t db;
-            load_rect(rec, g, P, gx, gy, ry0, ry1, x0, y0, x1, y1, db);
-            for_each_instance(x0, y0, x1, y1, gx, 0u, [&](int tile, int, uint32_t) { atomicAdd(&s_cnt[tile], 1u); });
+            Reach rc;
+        load_rect(rec, g, P, gx, gy, ry0, ry1, cull, x0, y0, x1, y1, db, rc);
+            for_each_kept(x0, y0, x1, y1, gx, 0u, g < P ? reach[g] : 0ull, rc, [&](int tile, int, uint32_t) { atomicAdd(&s_cnt[tile], 1u); });
         }
         __syncthreads();
         // reserve this workgroup's slice of every non-empty bucket
@@ -182,8 +292,9 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
         const int wave_g0 = g - mom_lane();
         int x0, y0, x1, y1;
         uint32_t db;
-        load_rect(rec, g, P, gx, gy, ry0, ry1, x0, y0, x1, y1, db);
-        for_each_instance(x0, y0, x1, y1, gx, db, [&](int tile, int src, uint32_t sdb) {
+        Reach rc;
+        load_rect(rec, g, P, gx, gy, ry0, ry1, cull, x0, y0, x1, y1, db, rc);
+        for_each_kept(x0, y0, x1, y1, gx, db, g < P ? reach[g] : 0ull, rc, [&](int tile, int src, uint32_t sdb) {
             const uint32_t pos = LDS_HIST ? atomicAdd(&s_cnt[tile], 1u) : atomicAdd(&tile_cursor[tile], 1u);
             if (pos < capacity)
                 keys[pos] = ((uint64_t)sdb << 32) | (uint32_t)(wave_g0 + src);
@@ -284,6 +395,7 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     const int tiles = gx * gy;
     int ry0, ry1;
     mom_tile_rows(a, gy, &ry0, &ry1);
+    const int cull = a->keep_all_tiles ? 0 : 1;
     // the header and the tile counters are adjacent in the image scratch (image_view): one memset for both
     if (hipMemsetAsync(im.hdr, 0, (size_t)((char*)(im.tile_counts + tiles) - (char*)im.hdr), s) != hipSuccess) return MOM_ELAUNCH;
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
@@ -291,10 +403,11 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
     mom_prof_begin(MOM_P_HIST, s);
     if (tiles <= kMaxLdsTiles)
-        hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy, ry0, ry1, g.rec,
-                           im.tile_counts);
+        hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy, ry0, ry1, cull,
+                           g.rec, im.tile_counts, g.reach);
     else
-        hipLaunchKernelGGL(tile_hist_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, ry0, ry1, g.rec, im.tile_counts);
+        hipLaunchKernelGGL(tile_hist_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, ry0, ry1, cull, g.rec,
+                           im.tile_counts, g.reach);
     mom_prof_end(MOM_P_HIST, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SCAN, s);
@@ -310,6 +423,7 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     const int tiles = gx * gy;
     int ry0, ry1;
     mom_tile_rows(a, gy, &ry0, &ry1);
+    const int cull = a->keep_all_tiles ? 0 : 1;
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
     if (chunks < 1) chunks = 1;
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
@@ -318,10 +432,10 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     mom_prof_begin(MOM_P_SCATTER, s);
     if (tiles <= kMaxLdsTiles)
         hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy,
-                           ry0, ry1, g.rec, im.tile_cursor, b.keys, cap, im.hdr, status_dev, tag);
+                           ry0, ry1, cull, g.rec, g.reach, im.tile_cursor, b.keys, cap, im.hdr, status_dev, tag);
     else
-        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, ry0, ry1, g.rec,
-                           im.tile_cursor, b.keys, cap, im.hdr, status_dev, tag);
+        hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(blocks), dim3(256), 0, s, a->P, chunks, gx, gy, ry0, ry1, cull, g.rec,
+                           g.reach, im.tile_cursor, b.keys, cap, im.hdr, status_dev, tag);
     mom_prof_end(MOM_P_SCATTER, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SORT, s);

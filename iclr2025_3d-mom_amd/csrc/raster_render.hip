@@ -80,12 +80,10 @@ __device__ __forceinline__ float reduce_scatter10(const float (&v)[10], int lane
     return m;
 }
 
-// A splat can reach alpha >= 1/255 at a pixel only if power >= ln(1 / (255 opacity)).  The staging thread stores that
-// bound, lowered by a margin that dwarfs the rounding of logf, of the product and of mom_exp (all below 1e-6 here),
-// in the LDS copy of the record (r0.w, whose tile count the compositing kernels do not use).  The loops then skip a
-// splat for the whole wave with `!__any(!(power < bound))` before paying for exp; every pair that survives still takes
-// the exact tests, so results do not change.  Written as !(power < bound) so that a NaN falls through to them.
-__device__ __forceinline__ float power_bound(float opacity) { return -logf(255.0f * opacity) - 1e-3f; }
+// The staging thread stores mom_power_bound(opacity) (mom_common.h) in the LDS copy of the record (r0.w, whose tile count
+// the compositing kernels do not use).  The loops then skip a splat for the whole wave with `!__any(!(power < bound))`
+// before paying for exp; every pair that survives still takes the exact tests, so results do not change.
+__device__ __forceinline__ float power_bound(float opacity) { return mom_power_bound(opacity); }
 
 // Exponent of the splat's Gaussian at a pixel.  render_fwd and render_bwd must round it identically, or a pair sitting on
 // the 1/255 threshold could be composited by one pass and not by the other; with contraction left to the compiler the
@@ -102,20 +100,11 @@ __device__ __forceinline__ float splat_power(const float4 r0, const float4 r1, f
 }
 
 // ---- per-wave splat lists ------------------------------------------------------------------------------------------
-// A wave owns a 16x4 strip of the tile, and about four fifths of the tile's splats cannot reach alpha >= 1/255 anywhere
-// in a given strip.  While a splat is staged into LDS its staging thread decides, per strip, whether ANY point of the
-// strip's rectangle can reach the splat's power bound: the exponent is concave, so its maximum over a rectangle is 0 if
-// the centre is inside and otherwise lies on an edge, at the clamped stationary point of the edge's 1-D quadratic.  Each
-// wave then compacts the indices of its reachable splats (ballot + rank) and loops over those only.  The test works on the
-// continuous rectangle with a margin, so it keeps every pair the exact per-pixel tests could accept, and those tests
-// still run: results are bit-identical.  Anything degenerate (non-positive conic diagonal, NaN) counts as reachable.
-__device__ __forceinline__ float edge_max(float fixed, float lo, float hi, float q_fixed, float q_free, float inv_q_free, float b)
-{
-    // max over t in [lo, hi] of  -0.5 (q_fixed fixed^2 + q_free t^2) - b fixed t.  The stationary point uses a hardware
-    // reciprocal (1 ulp): the quadratic is flat there, so its error is second order and far inside the caller's margin.
-    const float t = fminf(fmaxf(-b * fixed * inv_q_free, lo), hi);
-    return -0.5f * (q_fixed * fixed * fixed + q_free * t * t) - b * fixed * t;
-}
+// A wave owns a 16x4 strip of the tile, and about two thirds of the tile's splats (of those the binning kept: it applies the
+// same test to the whole tile) cannot reach alpha >= 1/255 anywhere in a given strip.  While a splat is staged into LDS its
+// staging thread decides, per strip, whether any point of the strip's rectangle can reach the splat's power bound
+// (mom_rect_reach, mom_common.h).  Each wave then compacts the indices of its reachable splats (ballot + rank) and loops
+// over those only.  The exact per-pixel tests still run: results are bit-identical.
 // Footprint of a wave inside the 16x16 tile: kFW x kFH pixels, kWX footprints across.  (16x4 strips: 16,4,1; 8x8 blocks: 8,8,2.)
 #ifndef MOM_FOOT_W
 #define MOM_FOOT_W 16
@@ -123,27 +112,26 @@ __device__ __forceinline__ float edge_max(float fixed, float lo, float hi, float
 constexpr int kFW = MOM_FOOT_W, kFH = 64 / kFW, kWX = 16 / kFW;
 __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const float4 r1, float x0, float y0)
 {
-    const float cx = r0.x, cy = r0.y, a = r1.x, b = r1.y, c = r1.z, bound = r0.w - 1e-3f;
+    const float a = r1.x, c = r1.z;
     if (!(a > 0.f) || !(c > 0.f)) return 0xFu;
     const float inv_a = __builtin_amdgcn_rcpf(a), inv_c = __builtin_amdgcn_rcpf(c);     // two reciprocals serve all 16 edges
     uint32_t m = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        const float xa = x0 + (float)(kFW * (w % kWX)), xb = xa + (float)(kFW - 1);
-        const float ya = y0 + (float)(kFH * (w / kWX)), yb = ya + (float)(kFH - 1);
-        const float dxl = cx - xb, dxh = cx - xa;        // dx = cx - px over the footprint's columns
-        const float dyl = cy - yb, dyh = cy - ya;
-        float best;
-        if (cx >= xa && cx <= xb && cy >= ya && cy <= yb) {
-            best = 0.f;
-        } else {
-            best = fmaxf(fmaxf(edge_max(dxl, dyl, dyh, a, c, inv_c, b), edge_max(dxh, dyl, dyh, a, c, inv_c, b)),
-                         fmaxf(edge_max(dyl, dxl, dxh, c, a, inv_a, b), edge_max(dyh, dxl, dxh, c, a, inv_a, b)));
-        }
-        m |= (!(best < bound)) ? (1u << w) : 0u;
+        const float xa = x0 + (float)(kFW * (w % kWX)), ya = y0 + (float)(kFH * (w / kWX));
+        m |= mom_rect_reach(r0.x, r0.y, a, r1.y, c, r0.w, inv_a, inv_c, xa, xa + (float)(kFW - 1), ya, ya + (float)(kFH - 1)) ? (1u << w) : 0u;
     }
     return m;
 }
+// Both compositing kernels gain from occupancy more than they lose to a tighter register budget (forward: 140 us at 8 waves
+// per SIMD against 168 us at 6, same instructions): the budget is pinned instead of left to the allocator, which moved it
+// by a wave or two from one unrelated edit to the next.
+#ifndef MOM_FWD_WAVES
+#define MOM_FWD_WAVES 8
+#endif
+#ifndef MOM_BWD_WAVES
+#define MOM_BWD_WAVES 6
+#endif
 // Splats staged per round (a multiple of 256; each thread stages kRound / 256 of them).
 #ifndef MOM_ROUND
 #define MOM_ROUND 256
@@ -168,7 +156,7 @@ __device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* 
     return n;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FWD_WAVES, MOM_FWD_WAVES)))
 render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0,
                   const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
@@ -262,7 +250,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_WAVES, MOM_BWD_WAVES)))
 render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0,
                   const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,

@@ -18,7 +18,7 @@ from .. import _native as N
 
 from collections import deque
 
-_state = {"mode": "exact", "cap_hint": 0, "last_R": None, "flag": None, "pending": deque()}
+_state = {"mode": "exact", "cap_hint": 0, "last_R": None, "flag": None, "pending": deque(), "keep_all_tiles": False}
 _FLAG_LAG = 4
 
 
@@ -55,6 +55,14 @@ def set_sync_mode(mode: str, capacity_hint: int = 0) -> None:
     _state["mode"] = mode
     if capacity_hint:
         _state["cap_hint"] = int(capacity_hint)
+
+
+def set_keep_all_tiles(on: bool) -> None:
+    """True: bin every tile of a splat's rectangle, as the reference does -- num_rendered and the tile lists are then the
+    reference's bit for bit (the parity tests of the sort use this).  False (default): instances that cannot reach
+    alpha >= 1/255 anywhere in their tile are not binned; images and gradients are bit-identical either way
+    (include/mom4d.h, MomRasterArgs.keep_all_tiles).  Forward and backward of one frame must run under the same setting."""
+    _state["keep_all_tiles"] = bool(on)
 
 
 def last_num_rendered():
@@ -94,6 +102,7 @@ def _args(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D
     a.scale_modifier = float(scale_modifier)
     a.tan_fovx, a.tan_fovy = float(tan_fovx), float(tan_fovy)
     a.prefiltered, a.debug = int(bool(prefiltered)), int(bool(debug))
+    a.keep_all_tiles = int(_state["keep_all_tiles"])
     return a, keep
 
 

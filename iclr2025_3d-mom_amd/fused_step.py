@@ -78,6 +78,7 @@ class FusedStep:
         self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
 
     RING = 64
+    keep_all_tiles = False            # True: bin whole rectangles like the reference (MomRasterArgs.keep_all_tiles; measurement only)
     HEADROOM, MARGIN = 1.5, 65536     # binning capacity = HEADROOM x an earlier frame's instance count + MARGIN
 
     def exact_next(self):
@@ -176,6 +177,7 @@ class FusedStep:
         a.scale_modifier = 1.0
         a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         a.prefiltered, a.debug = 0, 0
+        a.keep_all_tiles = int(self.keep_all_tiles)
         a.overflow_tag = self.next_tag          # what this step leaves in the sticky word if its binning overflows (Trainer numbers the steps)
         dc = self.dist
         rows = fwd_rows = None

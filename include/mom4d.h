@@ -80,6 +80,13 @@ typedef struct MomRasterArgs {
     /* What mom_raster_forward_render leaves in *status_dev when this call's binning overflows (0 = 1): a caller that runs
      * ahead of the GPU numbers its calls here and later reads WHICH call overflowed first. */
     uint32_t overflow_tag;
+    /* 0 (default): a (splat, tile) instance is binned only if the splat can reach alpha >= 1/255 at some pixel of the tile --
+     * a conservative bound on the compositing kernels' own per-pixel test (forward.cu:331-338 skips such pairs one pixel at a
+     * time), so colour, depth and every gradient are bit-identical to binning the whole rectangle, while num_rendered, the
+     * tile lists and n_contrib (positions in those lists) shrink: about 40 % of the instances at 960x540 / 200k.
+     * !=0: every tile of the splat's rectangle is binned, as duplicateWithKeys does (rasterizer_impl.cu:70-111): num_rendered
+     * and the lists are then the reference's, bit for bit.  The same value must be given to every stage of one frame. */
+    int keep_all_tiles;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
@@ -100,8 +107,8 @@ int mom_raster_forward_geometry(const MomRasterArgs* a, void* geom, void* image,
                                 uint32_t* num_rendered_dev, uint32_t* num_rendered_host, mom_stream_t stream);
 
 /* Forward, stage 2: scatter instances into their tiles, per-tile depth sort
- * (result identical to the reference's global sort of (tile<<32|depth) keys:
- * rasterizer_impl.cu:70-111,301-318) and alpha compositing (renderCUDA,
+ * (with keep_all_tiles: result identical to the reference's global sort of (tile<<32|depth) keys,
+ * rasterizer_impl.cu:70-111,301-318; by default: the same lists less the instances that cannot contribute) and alpha compositing (renderCUDA,
  * forward.cu:261-379).  `capacity` is the instance capacity the binning buffer
  * was sized for; if the true count exceeds it nothing beyond capacity is written, the image
  * is incomplete, and if *status_dev (may be null) is still 0 it receives a->overflow_tag (1

@@ -23,21 +23,28 @@ def _aligned(buf):
     return buf[off:]
 
 
-def hip_forward(s, shs=True, colors_precomp=None, cov3D_precomp=None, sh_degree=3, scale_modifier=1.0, debug=False):
+def hip_forward(s, shs=True, colors_precomp=None, cov3D_precomp=None, sh_degree=3, scale_modifier=1.0, debug=False,
+                keep_all_tiles=False):
+    """keep_all_tiles: bin like the reference (whole rectangles) instead of the default cull; hip_backward of the returned
+    state runs under the same setting."""
     dev = "cuda"
     P = s["means3D"].shape[0]
     args = (t(s["bg"]), t(s["means3D"]), t(colors_precomp), t(s["opacities"]),
             t(None if cov3D_precomp is not None else s["scales"]), t(None if cov3D_precomp is not None else s["rotations"]),
             scale_modifier, t(cov3D_precomp), t(s["viewmatrix"]), t(s["projmatrix"]), s["tanfovx"], s["tanfovy"], s["H"],
             s["W"], t(s["shs"] if (shs and colors_precomp is None) else None), sh_degree, t(s["campos"]), False, debug)
-    R, color, depth, radii, geom, binning, img = RC.rasterize_gaussians(*args)
-    torch.cuda.synchronize()
+    RC.set_keep_all_tiles(keep_all_tiles)
+    try:
+        R, color, depth, radii, geom, binning, img = RC.rasterize_gaussians(*args)
+        torch.cuda.synchronize()
+    finally:
+        RC.set_keep_all_tiles(False)
     lay = N.MomRasterLayout()
     N.lib().mom_raster_layout(P, s["W"], s["H"], R, C.byref(lay))
     W, H = s["W"], s["H"]
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     out = dict(R=R, color=color.cpu().numpy(), depth=depth.cpu().numpy(), radii=radii.cpu().numpy(), args=args,
-               bufs=(geom, binning, img))
+               bufs=(geom, binning, img), keep_all_tiles=keep_all_tiles)
     if P:
         g = _aligned(geom).cpu().numpy()
         rec = g[lay.geom_rec:lay.geom_rec + P * 48].view(np.float32).reshape(P, 12)
@@ -64,9 +71,13 @@ def hip_backward(fw, dL_dcolor, dL_ddepth=None):
      sh, degree, campos, _, debug) = a
     geom, binning, img = fw["bufs"]
     dd = torch.zeros((1, H, W), device="cuda") if dL_ddepth is None else t(dL_ddepth)
-    res = RC.rasterize_gaussians_backward(bg, means3D, t(fw["radii"]), colors, scales, rotations, scale_modifier,
-                                          cov3D_precomp, viewmatrix, projmatrix, tanx, tany, t(dL_dcolor), dd, sh, degree,
-                                          campos, geom, fw["R"], binning, img, debug)
-    torch.cuda.synchronize()
+    RC.set_keep_all_tiles(fw["keep_all_tiles"])
+    try:
+        res = RC.rasterize_gaussians_backward(bg, means3D, t(fw["radii"]), colors, scales, rotations, scale_modifier,
+                                              cov3D_precomp, viewmatrix, projmatrix, tanx, tany, t(dL_dcolor), dd, sh, degree,
+                                              campos, geom, fw["R"], binning, img, debug)
+        torch.cuda.synchronize()
+    finally:
+        RC.set_keep_all_tiles(False)
     names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
     return {n: r.cpu().numpy() for n, r in zip(names, res)}

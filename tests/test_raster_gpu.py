@@ -24,8 +24,42 @@ def _oracle(s, **kw):
                       s["tanfovx"], s["tanfovy"], s["bg"], **args)
 
 
+def _last_contributor(n_contrib, ranges, point_list, W, H):
+    """Gaussian index of every pixel's last contributor (-1: none), from a rasterizer state's own lists."""
+    gx = (W + 15) // 16
+    py, px = np.divmod(np.arange(W * H), W)
+    tile = (py // 16) * gx + px // 16
+    nc = n_contrib.astype(np.int64)
+    pos = ranges[tile, 0].astype(np.int64) + nc - 1
+    out = np.full(W * H, -1, dtype=np.int64)
+    has = nc > 0
+    out[has] = point_list[pos[has]]
+    return out
+
+
+def _cmp_lists_culled(fw, st, W, H):
+    """Default binning (MomRasterArgs.keep_all_tiles = 0): every tile's list is the reference's list, in the reference's
+    order, less instances that cannot reach alpha >= 1/255 in the tile.  That nothing contributing was dropped is shown by the
+    image / gradient comparisons (bit-identical to keep_all_tiles = 1, test_tile_cull_changes_no_output) and, here, by every
+    pixel's last contributor being the reference's."""
+    assert fw["R"] <= st.num_rendered
+    rg = fw["ranges"].astype(np.int64)
+    cnt = rg[:, 1] - rg[:, 0]
+    assert int(cnt.sum()) == fw["R"]
+    for t in range(rg.shape[0]):
+        mine = fw["point_list"][rg[t, 0]:rg[t, 1]]
+        ref = st.point_list[st.ranges[t, 0]:st.ranges[t, 1]]
+        assert len(mine) <= len(ref)
+        np.testing.assert_array_equal(ref[np.isin(ref, mine)], mine)          # an order-preserving subsequence
+    a = _last_contributor(fw["n_contrib"], fw["ranges"], fw["point_list"], W, H)
+    b = _last_contributor(st.n_contrib, st.ranges, st.point_list, W, H)
+    assert (a == b).mean() >= 0.999
+
+
 def _cmp_forward(fw, st, P, feat=None):
-    assert fw["R"] == st.num_rendered
+    culled = not fw["keep_all_tiles"]
+    if not culled:
+        assert fw["R"] == st.num_rendered
     np.testing.assert_array_equal(fw["radii"], st.radii)
     vis = st.radii > 0
     np.testing.assert_array_equal(fw["tiles_touched"], st.tiles_touched)
@@ -33,8 +67,11 @@ def _cmp_forward(fw, st, P, feat=None):
     np.testing.assert_array_equal(fw["depths"][vis].view(np.uint32), st.depths[vis].view(np.uint32))
     np.testing.assert_array_equal(fw["means2D"][vis].view(np.uint32), st.means2D[vis].view(np.uint32))
     np.testing.assert_array_equal(fw["conic_opacity"][vis].view(np.uint32), st.conic_opacity[vis].view(np.uint32))
-    np.testing.assert_array_equal(fw["ranges"], st.ranges)
-    np.testing.assert_array_equal(fw["point_list"], st.point_list)      # the whole sort, bit for bit
+    if culled:
+        _cmp_lists_culled(fw, st, fw["color"].shape[2], fw["color"].shape[1])
+    else:
+        np.testing.assert_array_equal(fw["ranges"], st.ranges)
+        np.testing.assert_array_equal(fw["point_list"], st.point_list)      # the whole sort, bit for bit
     np.testing.assert_array_equal(fw["clamped"][vis], st.clamped[vis])
     # with precomputed colours the reference leaves geomState.rgb untouched and renders from the input
     ref_rgb = st.rgb if feat is None else feat
@@ -43,8 +80,9 @@ def _cmp_forward(fw, st, P, feat=None):
     assert dc.mean() <= IMG_L1_TOL and dc.max() <= IMG_MAX_TOL, (dc.mean(), dc.max())
     dd = np.abs(fw["depth"] - st.out_depth)
     assert dd.mean() <= IMG_L1_TOL * max(1.0, float(st.depths.max())), dd.mean()
-    same = (fw["n_contrib"] == st.n_contrib).mean()
-    assert same >= 0.999, same
+    if not culled:
+        same = (fw["n_contrib"] == st.n_contrib).mean()
+        assert same >= 0.999, same
     assert np.abs(fw["final_T"] - st.final_T).mean() <= 1e-5
 
 
@@ -68,10 +106,11 @@ def test_wave_sum_selftest():
     (3, 64, 33, 17, {}),
     (4, 20000, 320, 180, dict(scale=(-5.0, -3.0))),
 ])
-def test_forward_parity(seed, P, W, H, kw):
+@pytest.mark.parametrize("keep_all_tiles", [True, False])
+def test_forward_parity(seed, P, W, H, kw, keep_all_tiles):
     from hip_helpers import hip_forward
     s = random_gaussians(P, seed=seed, W=W, H=H, **kw)
-    _cmp_forward(hip_forward(s), _oracle(s), P)
+    _cmp_forward(hip_forward(s, keep_all_tiles=keep_all_tiles), _oracle(s), P)
 
 
 def test_forward_parity_lower_sh_degree_and_scale_modifier():
@@ -107,8 +146,11 @@ def test_oversized_tile_bucket_uses_global_sort_path():
     s["means3D"][100:, 2] = np.abs(s["means3D"][100:, 2]) + 0.5
     s["means3D"][2000:2500, 2] = 3.0     # exact depth ties
     s["opacities"][:] = 0.02
-    fw, st = hip_forward(s), _oracle(s)
+    fw, st = hip_forward(s, keep_all_tiles=True), _oracle(s)
     assert (st.ranges[:, 1] - st.ranges[:, 0]).max() > 8192
+    _cmp_forward(fw, st, P)
+    fw = hip_forward(s)
+    assert (fw["ranges"][:, 1].astype(np.int64) - fw["ranges"][:, 0]).max() > 8192        # still the global path after the cull
     _cmp_forward(fw, st, P)
 
 
@@ -200,7 +242,13 @@ def test_full_size_properties(P, W, H, seed):
     s = random_gaussians(P, seed=seed, W=W, H=H, scale=(-6.0, -4.5))
     fw = hip_forward(s)
     R = fw["R"]
-    assert int(fw["tiles_touched"].sum()) == R == int(fw["tile_counts"].sum())
+    assert R == int(fw["tile_counts"].sum()) <= int(fw["tiles_touched"].sum())
+    # binning whole rectangles like the reference: the count is the sum of the rectangles; culling the instances that cannot
+    # reach 1/255 in their tile changed no pixel and no transmittance, bit for bit
+    fw_all = hip_forward(s, keep_all_tiles=True)
+    assert fw_all["R"] == int(fw_all["tiles_touched"].sum()) == int(fw_all["tile_counts"].sum()) and R < fw_all["R"]
+    for k in ("color", "depth", "final_T", "radii"):
+        np.testing.assert_array_equal(fw[k], fw_all[k])
     pl, rg = fw["point_list"], fw["ranges"]
     dbits = fw["depths"].view(np.uint32)
     pos = 0
@@ -226,7 +274,41 @@ def test_full_size_properties(P, W, H, seed):
     dcol = rng.standard_normal((3, H, W)).astype(np.float32)
     g1 = hip_backward(fw, dcol)
     g2 = hip_backward(fw, 2.0 * dcol)
+    g_all = hip_backward(fw_all, dcol)
     for k in g1:
         scale = float(np.abs(g1[k]).max())
         assert np.isfinite(g1[k]).all() and scale > 0, k
         assert np.abs(g2[k] - 2.0 * g1[k]).max() <= 2e-5 * scale, (k, float(np.abs(g2[k] - 2.0 * g1[k]).max()), scale)
+        # same per-pixel arithmetic with or without the cull; only the order of the float atomics can differ
+        assert np.abs(g_all[k] - g1[k]).max() <= 2e-5 * scale, (k, float(np.abs(g_all[k] - g1[k]).max()), scale)
+
+
+@pytest.mark.parametrize("seed,P,W,H,kw,opacity", [
+    (40, 3000, 160, 96, {}, None),
+    (41, 900, 100, 50, dict(scale=(-3.0, -0.5)), 0.03),      # large faint splats: most of each rectangle is out of reach
+    (42, 20000, 320, 180, dict(scale=(-5.0, -3.0)), None),
+    (43, 500, 64, 48, dict(scale=(-2.5, -0.5)), 0.004),      # opacity barely above 1/255: reach shrinks to the very centre
+    (44, 500, 64, 48, {}, 0.0039),                           # below 1/255: nothing is binned at all
+])
+def test_tile_cull_changes_no_output(seed, P, W, H, kw, opacity):
+    """MomRasterArgs.keep_all_tiles = 0 (default) against 1: the lists shrink; image, depth, transmittance and radii are
+    bit-identical; the gradients agree up to the order of their float atomics."""
+    from hip_helpers import hip_backward, hip_forward
+    s = random_gaussians(P, seed=seed, W=W, H=H, **kw)
+    if opacity is not None:
+        s["opacities"][:] = opacity
+    a, b = hip_forward(s), hip_forward(s, keep_all_tiles=True)
+    assert a["R"] < b["R"] == int(b["tiles_touched"].sum())
+    if opacity is not None and opacity < 1 / 255:
+        assert a["R"] == 0
+    for k in ("color", "depth", "final_T", "radii", "tiles_touched"):
+        np.testing.assert_array_equal(a[k], b[k])
+    np.testing.assert_array_equal(_last_contributor(a["n_contrib"], a["ranges"], a["point_list"], W, H),
+                                  _last_contributor(b["n_contrib"], b["ranges"], b["point_list"], W, H))
+    rng = np.random.default_rng(seed)
+    dcol = rng.standard_normal((3, H, W)).astype(np.float32)
+    ddep = (rng.standard_normal((1, H, W)) * 0.2).astype(np.float32)
+    ga, gb = hip_backward(a, dcol, ddep), hip_backward(b, dcol, ddep)
+    for k in ga:
+        scale = max(float(np.abs(gb[k]).max()), 1e-30)
+        assert np.abs(ga[k] - gb[k]).max() <= 2e-5 * scale, (k, float(np.abs(ga[k] - gb[k]).max()), scale)
