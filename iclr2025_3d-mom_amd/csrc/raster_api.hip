@@ -1,7 +1,7 @@
 // extern "C" entry points of the rasterizer (see include/mom4d.h).
 #include "mom_common.h"
 
-int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, hipStream_t s);
+int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, uint32_t* zero_words, int n_zero, hipStream_t s);
 int mom_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const ImageView& im, uint32_t* num_rendered_dev,
                              uint32_t* num_rendered_host, hipStream_t s);
@@ -85,7 +85,9 @@ int mom_raster_forward_geometry(const MomRasterArgs* a, void* geom, void* image,
     GeomView g; ImageView im;
     geom_view(mom_align_ptr(geom), a->P, &g);
     image_view(mom_align_ptr(image), a->W, a->H, &im);
-    rc = mom_launch_preprocess_fwd(a, g, radii, s);
+    // the header and the tile counters are adjacent in the image scratch (image_view): the projection kernel clears both
+    const int tiles = ((a->W + MOM_TILE - 1) / MOM_TILE) * ((a->H + MOM_TILE - 1) / MOM_TILE);
+    rc = mom_launch_preprocess_fwd(a, g, radii, im.hdr, (int)((im.tile_counts + tiles) - im.hdr), s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
     rc = mom_launch_binning_count(a, g, im, num_rendered_dev, num_rendered_host, s);

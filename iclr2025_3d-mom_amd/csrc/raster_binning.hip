@@ -396,8 +396,9 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     int ry0, ry1;
     mom_tile_rows(a, gy, &ry0, &ry1);
     const int cull = a->keep_all_tiles ? 0 : 1;
-    // the header and the tile counters are adjacent in the image scratch (image_view): one memset for both
-    if (hipMemsetAsync(im.hdr, 0, (size_t)((char*)(im.tile_counts + tiles) - (char*)im.hdr), s) != hipSuccess) return MOM_ELAUNCH;
+    // the header and the tile counters were cleared by the projection kernel (raster_api.hip): no fill launch here.  (Folding
+    // the scan into the histogram kernel too -- the last workgroup to finish scans -- was measured and dropped: with the
+    // device-scope fence the ticket needs, 782 workgroups each wrote the L2 back, 27 -> 72 us.)
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
     if (chunks < 1) chunks = 1;
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);

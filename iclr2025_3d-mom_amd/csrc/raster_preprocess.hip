@@ -50,9 +50,13 @@ struct PreArgs {
 };
 
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __restrict__ radii, float4* __restrict__ rec,
-                                                            float* __restrict__ cov3Ds, uchar4* __restrict__ clamped)
+                                                            float* __restrict__ cov3Ds, uchar4* __restrict__ clamped,
+                                                            uint32_t* __restrict__ zero_words, int n_zero)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    // the image scratch's header and tile counters, which the binning kernels behind this one accumulate into, are cleared
+    // here instead of by a fill launch of their own
+    for (int i = idx; i < n_zero; i += gridDim.x * 256) zero_words[i] = 0u;
     if (idx >= a.P) return;
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
@@ -195,7 +199,7 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means, cons
 }  // namespace
 
 // host launcher (called from raster_api.hip)
-int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, hipStream_t s)
+int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, uint32_t* zero_words, int n_zero, hipStream_t s)
 {
     PreArgs p;
     p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
@@ -211,7 +215,7 @@ int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* ra
     const int blocks = (a->P + 255) / 256;
     MomProfScope ps(MOM_P_PRE_FWD, s);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, s, p, radii, g.rec, a->forward_only ? nullptr : g.cov3D,
-                       a->forward_only ? nullptr : g.clamped);
+                       a->forward_only ? nullptr : g.clamped, zero_words, n_zero);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

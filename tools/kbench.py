@@ -17,6 +17,8 @@ steps = 60
 cfg = bench.CONFIGS[os.environ.get("KBENCH_CONFIG", "c2")]
 scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=True, lambda_dssim=0.0)
 cams = trainer.cams
+if os.environ.get("KBENCH_FREEZE"):   # the model never moves: variants whose gradients differ (experiments) still see one scene
+    g.optimizer.step = lambda *a, **k: None
 for i in range(70):
     trainer.step(5001 + i % 90, cams=[cams[i % len(cams)]])
 torch.cuda.synchronize()
