@@ -54,10 +54,26 @@ struct BwdArgs {
     float *dmeans2D, *dcolors, *dopacity, *dmeans3D, *dcov3D, *dsh, *dsh_rest, *dscales, *drot;
 };
 
+// STAGED (DC and rest stored apart, an odd row length): the workgroup's higher-order SH rows are copied to LDS with
+// coalesced loads, every thread reads its row there, writes the row's GRADIENT over it once it is done reading, and the
+// workgroup stores the gradient rows with coalesced writes.  In place, a thread's 180-byte row makes every load and
+// every store instruction touch 64 different cache lines.
+template <bool STAGED>
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
 {
+    extern __shared__ float s_sh[];
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
+    const int sh_stride = (a.M - 1) * 3;
+    const int block0 = blockIdx.x * 256;
+    const int n_stage = STAGED ? min(256, a.P - block0) * sh_stride : 0;
+    if (STAGED) {
+        const float* __restrict__ src = a.shs_rest + (size_t)block0 * sh_stride;
+        const int n4 = n_stage >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(s_sh)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (int i = 4 * n4 + threadIdx.x; i < n_stage; i += 256) s_sh[i] = src[i];
+        __syncthreads();
+    }
+    if (idx < a.P) {
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
     const bool vis = a.radii[idx] > 0;
@@ -81,7 +97,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     // SH gradient rows: one [P,M,3] tensor, or DC and rest apart (dshr[3*i+c] valid for i >= 1)
     const bool split = a.dsh_rest != nullptr;
     float* dsh = a.dsh ? a.dsh + (size_t)idx * (split ? 1 : a.M) * 3 : nullptr;
-    float* dshr = split ? a.dsh_rest + (size_t)idx * (a.M - 1) * 3 - 3 : dsh;
+    float* dshr = STAGED ? s_sh + threadIdx.x * sh_stride - 3 : (split ? a.dsh_rest + (size_t)idx * (a.M - 1) * 3 - 3 : dsh);
 
     if (vis) {
         const float mx = a.means3D[3 * idx], my = a.means3D[3 * idx + 1], mz = a.means3D[3 * idx + 2];
@@ -168,35 +184,18 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
             const float len = sqrtf(dox * dox + doy * doy + doz * doz);
             const float x = dox / len, y = doy / len, z = doz / len;
             const float* sh0 = a.shs + (size_t)idx * (a.shs_rest ? 1 : a.M) * 3;
-            const float* sh = a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0;
+            const float* sh = STAGED ? s_sh + threadIdx.x * sh_stride - 3
+                                     : (a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0);
             const uchar4 cl = a.clamped[idx];
             const float dRGB[3] = {cl.x ? 0.f : ga[6], cl.y ? 0.f : ga[7], cl.z ? 0.f : ga[8]};
             float ddir[3] = {0.f, 0.f, 0.f};
 #define SH(i, c) sh[(i) * 3 + (c)]
 #define DSH(i, s) { const float s__ = (s); dshr[(i) * 3 + 0] = s__ * dRGB[0]; dshr[(i) * 3 + 1] = s__ * dRGB[1]; dshr[(i) * 3 + 2] = s__ * dRGB[2]; }
             dsh[0] = bSH_C0 * dRGB[0]; dsh[1] = bSH_C0 * dRGB[1]; dsh[2] = bSH_C0 * dRGB[2];
+            // the direction gradient READS the coefficients; the coefficient gradients below may overwrite them (staged rows)
+            float xx = 0, yy = 0, zz = 0, xy = 0, yz = 0, xz = 0;
+            if (a.D > 1) { xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z; }
             if (a.D > 0) {
-                DSH(1, -bSH_C1 * y);
-                DSH(2, bSH_C1 * z);
-                DSH(3, -bSH_C1 * x);
-                float xx = 0, yy = 0, zz = 0, xy = 0, yz = 0, xz = 0;
-                if (a.D > 1) {
-                    xx = x * x; yy = y * y; zz = z * z; xy = x * y; yz = y * z; xz = x * z;
-                    DSH(4, bSH_C2[0] * xy);
-                    DSH(5, bSH_C2[1] * yz);
-                    DSH(6, bSH_C2[2] * (2.f * zz - xx - yy));
-                    DSH(7, bSH_C2[3] * xz);
-                    DSH(8, bSH_C2[4] * (xx - yy));
-                    if (a.D > 2) {
-                        DSH(9, bSH_C3[0] * y * (3.f * xx - yy));
-                        DSH(10, bSH_C3[1] * xy * z);
-                        DSH(11, bSH_C3[2] * y * (4.f * zz - xx - yy));
-                        DSH(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-                        DSH(13, bSH_C3[4] * x * (4.f * zz - xx - yy));
-                        DSH(14, bSH_C3[5] * z * (xx - yy));
-                        DSH(15, bSH_C3[6] * x * (xx - 3.f * yy));
-                    }
-                }
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     float dRdx = -bSH_C1 * SH(3, c), dRdy = -bSH_C1 * SH(1, c), dRdz = bSH_C1 * SH(2, c);
@@ -220,6 +219,27 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
                     ddir[0] += dRdx * dRGB[c];
                     ddir[1] += dRdy * dRGB[c];
                     ddir[2] += dRdz * dRGB[c];
+                }
+            }
+            if (a.D > 0) {
+                DSH(1, -bSH_C1 * y);
+                DSH(2, bSH_C1 * z);
+                DSH(3, -bSH_C1 * x);
+                if (a.D > 1) {
+                    DSH(4, bSH_C2[0] * xy);
+                    DSH(5, bSH_C2[1] * yz);
+                    DSH(6, bSH_C2[2] * (2.f * zz - xx - yy));
+                    DSH(7, bSH_C2[3] * xz);
+                    DSH(8, bSH_C2[4] * (xx - yy));
+                    if (a.D > 2) {
+                        DSH(9, bSH_C3[0] * y * (3.f * xx - yy));
+                        DSH(10, bSH_C3[1] * xy * z);
+                        DSH(11, bSH_C3[2] * y * (4.f * zz - xx - yy));
+                        DSH(12, bSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                        DSH(13, bSH_C3[4] * x * (4.f * zz - xx - yy));
+                        DSH(14, bSH_C3[5] * z * (xx - yy));
+                        DSH(15, bSH_C3[6] * x * (xx - 3.f * yy));
+                    }
                 }
             }
             // coefficients above the active degree receive zero gradient
@@ -288,6 +308,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
 #pragma unroll
         for (int i = 0; i < 4; i++) a.drot[4 * idx + i] = drot[i];
     }
+    }   // idx < P
+    if (STAGED) {
+        __syncthreads();
+        float* __restrict__ dst = a.dsh_rest + (size_t)block0 * sh_stride;
+        const int n4 = n_stage >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(s_sh)[i];
+        for (int i = 4 * n4 + threadIdx.x; i < n_stage; i += 256) dst[i] = s_sh[i];
+    }
 }
 
 }  // namespace
@@ -308,6 +336,12 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
     b.dcov3D = gr->dL_dcov3D; b.dsh = gr->dL_dsh; b.dsh_rest = a->shs_rest ? gr->dL_dsh_rest : nullptr; b.dscales = a->scales ? gr->dL_dscales : nullptr;
     b.drot = a->scales ? gr->dL_drotations : nullptr;
     MomProfScope ps(MOM_P_PRE_BWD, s);
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a->P + 255) / 256), dim3(256), 0, s, b);
+    const int sh_stride = (a->M - 1) * 3;
+    const bool staged = b.colors_from_sh && b.shs_rest && b.dsh_rest && (sh_stride & 1) && sh_stride <= 45 &&
+                        ((uintptr_t)b.shs_rest & 15) == 0 && ((uintptr_t)b.dsh_rest & 15) == 0;
+    if (staged)
+        hipLaunchKernelGGL(preprocess_bwd_kernel<true>, dim3((a->P + 255) / 256), dim3(256), (size_t)256 * sh_stride * 4, s, b);
+    else
+        hipLaunchKernelGGL(preprocess_bwd_kernel<false>, dim3((a->P + 255) / 256), dim3(256), 0, s, b);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

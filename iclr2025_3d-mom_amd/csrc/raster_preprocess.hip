@@ -49,14 +49,29 @@ struct PreArgs {
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
 };
 
+// STAGED: the higher-order SH coefficients of the workgroup's 256 Gaussians -- (M-1)*3 floats each, contiguous in memory --
+// are copied to LDS with coalesced 16-byte loads and each thread then reads its own row from there (row stride odd: no
+// bank conflicts).  Read in place, a thread's 180-byte row makes every load instruction touch 64 different cache lines.
+template <bool STAGED>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __restrict__ radii, float4* __restrict__ rec,
                                                             float* __restrict__ cov3Ds, uchar4* __restrict__ clamped,
                                                             uint32_t* __restrict__ zero_words, int n_zero)
 {
+    extern __shared__ float s_sh[];
     const int idx = blockIdx.x * 256 + threadIdx.x;
     // the image scratch's header and tile counters, which the binning kernels behind this one accumulate into, are cleared
     // here instead of by a fill launch of their own
     for (int i = idx; i < n_zero; i += gridDim.x * 256) zero_words[i] = 0u;
+    const int sh_stride = (a.M - 1) * 3;
+    if (STAGED) {
+        const int block0 = blockIdx.x * 256;
+        const int n = min(256, a.P - block0) * sh_stride;
+        const float* __restrict__ src = a.shs_rest + (size_t)block0 * sh_stride;
+        const int n4 = n >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(s_sh)[i] = reinterpret_cast<const float4*>(src)[i];
+        for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) s_sh[i] = src[i];
+        __syncthreads();
+    }
     if (idx >= a.P) return;
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
@@ -143,7 +158,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             dx = dx / len; dy = dy / len; dz = dz / len;
             // coefficient i of this Gaussian: one [P,M,3] tensor, or DC and rest stored apart
             const float* sh0 = a.shs + (size_t)idx * (a.shs_rest ? 1 : a.M) * 3;
-            const float* sh = a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0;   // sh[3*i+c] valid for i >= 1
+            const float* sh = STAGED ? s_sh + threadIdx.x * sh_stride - 3
+                                     : (a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0);   // sh[3*i+c] valid for i >= 1
             float res[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -214,8 +230,16 @@ int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* ra
     p.view = a->viewmatrix; p.proj = a->projmatrix; p.cam = a->campos;
     const int blocks = (a->P + 255) / 256;
     MomProfScope ps(MOM_P_PRE_FWD, s);
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(blocks), dim3(256), 0, s, p, radii, g.rec, a->forward_only ? nullptr : g.cov3D,
-                       a->forward_only ? nullptr : g.clamped, zero_words, n_zero);
+    // staged SH rows: DC and rest stored apart, colours from SH above degree 0, an odd row length, 16-byte aligned rows
+    const int sh_stride = (a->M - 1) * 3;
+    const bool staged = a->shs_rest && !a->colors_precomp && a->D > 0 && (sh_stride & 1) && sh_stride <= 45 &&
+                        ((uintptr_t)a->shs_rest & 15) == 0;
+    if (staged)
+        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(256), (size_t)256 * sh_stride * 4, s, p, radii, g.rec,
+                           a->forward_only ? nullptr : g.cov3D, a->forward_only ? nullptr : g.clamped, zero_words, n_zero);
+    else
+        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, p, radii, g.rec,
+                           a->forward_only ? nullptr : g.cov3D, a->forward_only ? nullptr : g.clamped, zero_words, n_zero);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
