@@ -55,20 +55,33 @@ struct MlpDev {
     float *dW0, *db0, *dW1[3], *db1[3], *dW2[3], *db2[3];
 };
 
-// cooperative load of all weights into LDS (workgroup of 256 threads)
+// Cooperative load of all weights into LDS (any workgroup size that is a multiple of 64, at least 256).  The four 64x64
+// matrices are fetched as float4 and ALL of a thread's fetches are issued before its first LDS store: written as a plain
+// copy loop the prologue paid one memory latency per iteration (16 k cycles of the forward kernel's 150 k).
 __device__ __forceinline__ void load_weights(const MlpDev& m, float* __restrict__ lds)
 {
-    const int nth = (int)blockDim.x;                             // 256 (backward) or the forward kernel's block size
+    const int nth = (int)blockDim.x;
     const float* Ws[4] = {m.W0, m.W1[0], m.W1[1], m.W1[2]};
     const float* bs[4] = {m.b0, m.b1[0], m.b1[1], m.b1[2]};
+    constexpr int kQuads = 4 * kHid * kHid / 4, kMaxPer = kQuads / 256;      // 4096 float4 in all; <= 16 per thread
+    float4 v[kMaxPer];
 #pragma unroll
-    for (int L = 0; L < 4; L++) {
-        for (int i = threadIdx.x; i < kHid * kHid; i += nth) {
-            const int o = i >> 6, k = i & 63;                       // W[out][in] row-major: coalesced along `in`
-            lds[kLW + L * kWFloats + k * kWStride + o] = Ws[L][i];
-        }
-        if (threadIdx.x < kHid) lds[kLB + L * kHid + threadIdx.x] = bs[L][threadIdx.x];
+    for (int j = 0; j < kMaxPer; j++) {
+        const int q = threadIdx.x + j * nth;                       // quad q: layer q >> 10, floats 4 (q & 1023) .. + 3 of it
+        if (q < kQuads) v[j] = reinterpret_cast<const float4*>(Ws[q >> 10])[q & 1023];
     }
+    float bias = 0.f;                                              // workgroups have at least 4 * kHid = 256 threads
+    if (threadIdx.x < 4 * kHid) bias = bs[threadIdx.x >> 6][threadIdx.x & 63];
+#pragma unroll
+    for (int j = 0; j < kMaxPer; j++) {
+        const int q = threadIdx.x + j * nth;
+        if (q < kQuads) {
+            const int L = q >> 10, i = 4 * (q & 1023), o = i >> 6, k = i & 63;       // W[out][in] row-major -> lds[in][out], stride 65
+            float* d = lds + kLW + L * kWFloats + k * kWStride + o;
+            d[0] = v[j].x; d[kWStride] = v[j].y; d[2 * kWStride] = v[j].z; d[3 * kWStride] = v[j].w;
+        }
+    }
+    if (threadIdx.x < 4 * kHid) lds[kLB + threadIdx.x] = bias;
     for (int i = threadIdx.x; i < 3 * 4 * kHid; i += nth) {
         const int head = i >> 8, n = (i >> 6) & 3, f = i & 63;
         const int nout = head == 2 ? 4 : 3;
@@ -504,12 +517,12 @@ extern "C" int mom_deform_forward(const MomDeformMLP* w, int P, const float* fea
     int rc = fill_dev(w, &d);
     if (rc) return rc;
     const int tiles = (P + 31) / 32;
-    // one workgroup per CU, any multiple of 64 threads up to 1024 (MOM_MLP_FWD_BLOCK); the weights stay in LDS (70 KB)
+    // one workgroup per CU, any multiple of 64 threads from 256 to 1024 (MOM_MLP_FWD_BLOCK); the weights stay in LDS (70 KB)
     static int block = 0;
     if (!block) {
         const char* e = getenv("MOM_MLP_FWD_BLOCK");
         block = e ? atoi(e) : 1024;
-        if (block < 64 || block > 1024 || (block & 63)) block = 1024;
+        if (block < 256 || block > 1024 || (block & 63)) block = 1024;      // load_weights needs at least 256 threads
     }
     const int waves_per_block = block / 64;
     int blocks = (tiles + waves_per_block - 1) / waves_per_block;
