@@ -547,6 +547,13 @@ extern "C" size_t mom_deform_backward_scratch_bytes(int P) { return (size_t)4 * 
 extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                                    const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream)
 {
+    return mom_deform_backward_split(w, P, feat, a0, dpts, dscales, drots, dfeat, scratch, stream, stream);
+}
+
+extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
+                                         const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream,
+                                         mom_stream_t dw_stream)
+{
     if (P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!feat || !a0 || !dpts || !dscales || !drots || !dfeat || !scratch) return MOM_EINVAL;
@@ -573,6 +580,15 @@ extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* fe
     hipLaunchKernelGGL(deform_bwd_dx_kernel, dim3(blocks), dim3(64 * kDxWaves), lds_a, (hipStream_t)stream, d, P, tiles, a0, dpts, dscales, drots,
                        dfeat, dH);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    hipStream_t ws = (hipStream_t)dw_stream;
+    if (ws != (hipStream_t)stream) {
+        // the weight-gradient kernel reads what dx wrote (dH) and nothing behind it on `stream` depends on it: it goes to the
+        // caller's second stream, behind an event, and overlaps whatever the caller enqueues on `stream` next
+        static hipEvent_t dx_done = nullptr;
+        if (!dx_done && hipEventCreateWithFlags(&dx_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
+        if (hipEventRecord(dx_done, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
+        if (hipStreamWaitEvent(ws, dx_done, 0) != hipSuccess) return MOM_ELAUNCH;
+    }
     // weight gradients: 1024 waves, each a contiguous (even-sized) range of gaussians
     const int waves = 1024;
     int chunk = (P + waves - 1) / waves;
@@ -586,10 +602,10 @@ extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* fe
     }
     const dim3 grid(waves / 4, 4 / nl);
     if (nl == 4)
-        hipLaunchKernelGGL(deform_bwd_dw_kernel<4>, grid, dim3(256), lds_b, (hipStream_t)stream, d, P, chunk, feat, a0, dH);
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<4>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH);
     else if (nl == 2)
-        hipLaunchKernelGGL(deform_bwd_dw_kernel<2>, grid, dim3(256), lds_b, (hipStream_t)stream, d, P, chunk, feat, a0, dH);
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<2>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH);
     else
-        hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, grid, dim3(256), lds_b, (hipStream_t)stream, d, P, chunk, feat, a0, dH);
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

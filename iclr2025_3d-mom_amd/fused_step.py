@@ -11,6 +11,7 @@ render_bwd / preprocess_bwd -> activations_bwd -> deform_bwd (dx, dw) -> hexplan
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -78,6 +79,8 @@ class FusedStep:
         self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
 
     RING = 64
+    OVERLAP_DW = os.environ.get("MOM_OVERLAP_DW", "1") != "0"     # the MLP weight-gradient kernel on a second stream, beside the HexPlane backward
+    side = None
     keep_all_tiles = False            # True: bin whole rectangles like the reference (MomRasterArgs.keep_all_tiles; measurement only)
     HEADROOM, MARGIN = 1.5, 65536     # binning capacity = HEADROOM x an earlier frame's instance count + MARGIN
 
@@ -294,9 +297,14 @@ class FusedStep:
             d_rot.copy_(self.grot)
             dc.start(self.early, "sum")
         # ---- deformation backward: pts = xyz + dx(...) so d xyz starts as d pts (already in gxyz); the HexPlane adds its share
-        N.check(lib.mom_deform_backward(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
-                                        d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
-                                        self.dh_scratch.data_ptr(), s), "deform_bwd")
+        # the MLP's weight-gradient kernel (matrix pipe) runs on a second stream beside the HexPlane backward (vector issue,
+        # memory latency); joined below, before anything reads the weight gradients
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        side = self.side.cuda_stream if self.OVERLAP_DW else s
+        N.check(lib.mom_deform_backward_split(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
+                                              d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
+                                              self.dh_scratch.data_ptr(), s, side), "deform_bwd")
         if porders is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (P, hp.levels)):
             self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
             self._hex_scratch_key = (P, hp.levels)
@@ -323,6 +331,8 @@ class FusedStep:
             arr = self._reg_arr[1]
             N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
             reg = self.regval
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
         if dc is not None and dc.mode == "camera":
             dc.start(self._dg_flat, "sum")     # xyz + deformation field; the caller waits (DistContext.finish) before Adam
         # ---- hand the gradients to the parameters

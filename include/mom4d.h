@@ -349,6 +349,14 @@ int mom_deform_forward(const MomDeformMLP* w, int P, const float* feat /* [P,64]
 size_t mom_deform_backward_scratch_bytes(int P);   /* 4 x [P,64] floats: the per-layer pre-activation gradients */
 int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                         const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream);
+/* The same with the weight-gradient kernel on a second stream: dfeat (and the thin output layers' gradients) are complete on
+ * `stream` as before; the 64x64 layers' weight / bias gradients are complete on `dw_stream`, which the call orders behind the
+ * part on `stream` that produces their input.  The caller joins `dw_stream` before reading those gradients or reusing
+ * `scratch`.  Lets the matrix-pipe bound weight-gradient kernel overlap the HexPlane backward, which is bound by vector issue
+ * and memory latency.  dw_stream == stream: identical to mom_deform_backward. */
+int mom_deform_backward_split(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
+                              const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream,
+                              mom_stream_t dw_stream);
 
 /* ---- rendered image -> 8-bit interleaved RGB (render_4DGS.py:64 torchvision.utils.save_image: x * 255 + 0.5, clamp, truncate;
  * CHW -> HWC) in one pass, so that a frame can leave the device as the bytes a PNG encoder takes.  img [C,H,W] floats, out [H,W,C]
