@@ -31,7 +31,8 @@ class MomRasterArgs(C.Structure):
                 ("tile_row0", C.c_int), ("tile_row1", C.c_int),     # tile-row shard: 0,0 = every row
                 ("forward_only", C.c_int),                          # no backward will follow: skip the state only it reads
                 ("overflow_tag", C.c_uint),                         # what an overflow of this call leaves in *status_dev
-                ("keep_all_tiles", C.c_int)]                        # !=0: bin the whole rectangle like the reference (tests)
+                ("keep_all_tiles", C.c_int),                        # !=0: bin the whole rectangle like the reference (tests)
+                ("l1_target", C.c_void_p), ("l1_grad", C.c_void_p), ("l1_sums", C.c_void_p)]   # optional L1 epilogue of the forward
 
 
 class MomRasterGrads(C.Structure):

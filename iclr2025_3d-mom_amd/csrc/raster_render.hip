@@ -138,6 +138,13 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
 #ifndef MOM_BWD_WAVES
 #define MOM_BWD_WAVES 6
 #endif
+// Optional loss epilogue of the forward kernel (MomRasterArgs.l1_target): target null = none.
+struct L1Epilogue {
+    const float* target;
+    float* grad;
+    float* sums;
+    float inv_n;
+};
 // Splats staged per round (a multiple of 256; each thread stages kRound / 256 of them).
 #ifndef MOM_ROUND
 #define MOM_ROUND 256
@@ -166,7 +173,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FW
 render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
                   const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-                  uint32_t capacity)
+                  uint32_t capacity, L1Epilogue l1)
 {
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
@@ -249,10 +256,40 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         if (final_T) final_T[pix] = T;                      // null in forward-only rendering: nothing will read them
         if (n_contrib) n_contrib[pix] = last_contributor;
         const size_t HW = (size_t)H * W;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[HW + pix] = C1 + T * bg[1];
-        out_color[2 * HW + pix] = C2 + T * bg[2];
+        C0 += T * bg[0];
+        C1 += T * bg[1];
+        C2 += T * bg[2];
+        out_color[pix] = C0;
+        out_color[HW + pix] = C1;
+        out_color[2 * HW + pix] = C2;
         out_depth[pix] = D;
+    }
+    if (l1.target) {
+        // L1 loss against a target image, its sums and its gradient, while the pixel is still in registers: what
+        // mom_l1_loss_acc computes from the stored image (same expressions; the sums' order of addition differs)
+        float a1 = 0.f, a2 = 0.f;
+        if (inside) {
+            const int pix = py * W + px;
+            const size_t HW = (size_t)H * W;
+            const float c[3] = {C0, C1, C2};
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const float d = c[k] - l1.target[k * HW + pix];
+                a1 += fabsf(d);
+                a2 += d * d;
+                l1.grad[k * HW + pix] = d > 0.f ? l1.inv_n : (d < 0.f ? -l1.inv_n : 0.f);
+            }
+        }
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        float* s_sum = reinterpret_cast<float*>(s_lists);     // the lists are dead
+        __syncthreads();
+        if (lane == 0) { s_sum[2 * wv] = a1; s_sum[2 * wv + 1] = a2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&l1.sums[0], (s_sum[0] + s_sum[2]) + (s_sum[4] + s_sum[6]));
+            atomicAdd(&l1.sums[1], (s_sum[1] + s_sum[3]) + (s_sum[5] + s_sum[7]));
+        }
     }
 }
 
@@ -406,9 +443,11 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     mom_tile_rows(a, gy, &ry0, &ry1);
     const int nt = gx * (ry1 - ry0);
     if (nt == 0) return MOM_OK;
+    L1Epilogue l1 = {a->l1_target, a->l1_grad, a->l1_sums, 1.0f / (3.0f * (float)a->W * (float)a->H)};
+    if (!l1.grad || !l1.sums) l1.target = nullptr;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx),
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
-                       out_depth, cap);
+                       out_depth, cap, l1);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

@@ -181,6 +181,9 @@ class FusedStep:
         a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         a.prefiltered, a.debug = 0, 0
         a.keep_all_tiles = int(self.keep_all_tiles)
+        fuse_l1 = not (self.dist is not None and self.dist.mode == "tile-row")
+        if fuse_l1:      # L1 (its gradient image and its sums) in the compositing kernel's epilogue; a row shard forms it per slab below
+            a.l1_target, a.l1_grad, a.l1_sums = gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr()
         a.overflow_tag = self.next_tag          # what this step leaves in the sticky word if its binning overflows (Trainer numbers the steps)
         dc = self.dist
         rows = fwd_rows = None
@@ -212,7 +215,8 @@ class FusedStep:
             dc.start(self.flags, "max")         # every rank skips (and later replays) the same steps
         # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
         n = self.color.numel()
-        N.check(lib.mom_l1_loss_acc(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
+        if not fuse_l1:
+            N.check(lib.mom_l1_loss_acc(n, self.color.data_ptr(), gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr(), s), "l1")
         # camera-batch shard: the batch loss is the mean over the ranks' cameras (train_4DGS.py:189-229), so every
         # gradient carries 1/world and the all-reduces below are plain sums (1/2, 1/4, 1/8 are exact in fp32)
         inv_world = 1.0 / dc.world if (dc is not None and dc.mode == "camera") else 1.0

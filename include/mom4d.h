@@ -87,6 +87,13 @@ typedef struct MomRasterArgs {
      * !=0: every tile of the splat's rectangle is binned, as duplicateWithKeys does (rasterizer_impl.cu:70-111): num_rendered
      * and the lists are then the reference's, bit for bit.  The same value must be given to every stage of one frame. */
     int keep_all_tiles;
+    /* Optional loss epilogue of the forward (train_4DGS.py:218 `Ll1 = l1_loss(image, gt_image)`): with l1_target [3,H,W] set,
+     * mom_raster_forward_render also leaves l1_grad [3,H,W] = sign(image - target) / (3 H W) and ADDS sum |image - target| and
+     * sum (image - target)^2 to l1_sums[0], [1] -- what mom_l1_loss_acc(3 H W, out_color, target, l1_grad, l1_sums) computes from
+     * the stored image, without its launch and its re-read of the image.  All three null: no epilogue. */
+    const float* l1_target;
+    float* l1_grad;
+    float* l1_sums;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
