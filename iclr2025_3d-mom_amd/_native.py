@@ -112,6 +112,8 @@ def _sig(lib):
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
     lib.mom_plane_regulation_acc.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
     lib.mom_deform_forward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
+    lib.mom_deform_forward_activated.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp,
+                                                 vp, vp, vp]
     lib.mom_deform_backward_scratch_bytes.restype = sz
     lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
     lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -155,7 +157,7 @@ EXPORTS = [
     "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
-    "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_backward_scratch_bytes", "mom_deform_backward", "mom_deform_backward_split",
+    "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_forward_activated", "mom_deform_backward_scratch_bytes", "mom_deform_backward", "mom_deform_backward_split",
     "mom_ssim_forward", "mom_ssim_backward", "mom_raster_backward_render", "mom_raster_backward_geometry",
     "mom_densify_stats", "mom_select_scratch_bytes", "mom_select_plan", "mom_select_apply",
     "mom_ssim_forward_slab", "mom_ssim_backward_slab",

@@ -180,13 +180,20 @@ __device__ __forceinline__ void out_layer(const float* __restrict__ W2l, const f
     }
 }
 
+// Optional activated copies of the forward's outputs (mom_deform_forward_activated): exp(scales), rots / |rots|,
+// sigmoid(opacity_raw) -- what mom_activations_forward computes from the stored outputs, without its launch.
+struct ActOut {
+    float *scales, *rots, *opacity;
+    const float* opacity_raw;
+};
+
 // All threads of a workgroup share ONE copy of the weights in LDS (70 KB).  With 256 threads two workgroups = 8 waves fit per
 // CU although the registers allow 16: a workgroup of up to 1024 threads gets up to 16 waves for the same LDS.
 __global__ void __launch_bounds__(1024)
 deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ xyz,
                   const float* __restrict__ scaling, const float* __restrict__ rotation, const float* __restrict__ flow,
                   float flow_coef, float* __restrict__ pts, float* __restrict__ scales, float* __restrict__ rots,
-                  float* __restrict__ a0_save)
+                  float* __restrict__ a0_save, ActOut act)
 {
     extern __shared__ float lds[];
     load_weights(m, lds);
@@ -225,6 +232,24 @@ deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
                     for (int k = 0; k < 4; k++) rots[4 * g + k] = rotation[4 * g + k] + o[k];
                 }
             }
+        }
+    }
+    // Activated copies (mom_deform_forward_activated), after the tile loop: inside it their temporaries pushed the kernel over
+    // its 128-register budget (100 bytes of scratch per lane, +15 us).  Each lane re-reads what it stored itself.
+    if (act.scales || act.rots || act.opacity) {
+        for (int t = wave; t < tiles; t += nwaves) {
+            const int g = t * 32 + col;
+            if (h != 0 || g >= P) continue;
+            if (act.scales) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) act.scales[3 * g + k] = expf(scales[3 * g + k]);
+            }
+            if (act.rots) {
+                const float4 q = *reinterpret_cast<const float4*>(rots + 4 * g);
+                const float n = mom_quat_norm(q.x, q.y, q.z, q.w);
+                *reinterpret_cast<float4*>(act.rots + 4 * g) = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+            }
+            if (act.opacity) act.opacity[g] = mom_sigmoid(act.opacity_raw[g]);
         }
     }
 }
@@ -510,6 +535,15 @@ extern "C" int mom_deform_forward(const MomDeformMLP* w, int P, const float* fea
                                   const float* rotation, const float* scene_flow, float flow_coef, float* pts, float* scales,
                                   float* rots, float* a0_save, mom_stream_t stream)
 {
+    return mom_deform_forward_activated(w, P, feat, xyz, scaling, rotation, scene_flow, flow_coef, pts, scales, rots, a0_save, nullptr,
+                                        nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mom_deform_forward_activated(const MomDeformMLP* w, int P, const float* feat, const float* xyz, const float* scaling,
+                                            const float* rotation, const float* scene_flow, float flow_coef, float* pts, float* scales,
+                                            float* rots, float* a0_save, const float* opacity_raw, float* scales_act, float* rots_act,
+                                            float* opacity_act, mom_stream_t stream)
+{
     if (P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!feat || !xyz || !scaling || !rotation || !scene_flow || !pts || !scales || !rots) return MOM_EINVAL;
@@ -536,9 +570,11 @@ extern "C" int mom_deform_forward(const MomDeformMLP* w, int P, const float* fea
             return MOM_ELAUNCH;
         attr_set = true;
     }
+    if ((opacity_act != nullptr) != (opacity_raw != nullptr)) return MOM_EINVAL;
+    const ActOut act = {scales_act, rots_act, opacity_act, opacity_raw};
     MomProfScope ps(MOM_P_MLP_FWD, (hipStream_t)stream);
     hipLaunchKernelGGL(deform_fwd_kernel, dim3(blocks), dim3(block), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, xyz, scaling,
-                       rotation, scene_flow, flow_coef, pts, scales, rots, a0_save);
+                       rotation, scene_flow, flow_coef, pts, scales, rots, a0_save, act);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

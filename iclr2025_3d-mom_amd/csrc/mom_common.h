@@ -193,5 +193,14 @@ __device__ __forceinline__ bool mom_rect_reach(float cx, float cy, float a, floa
     return !(best < bound - 1e-3f);
 }
 
+// The activations of gaussian_renderer.render() (scene/gaussian_model.py:60-75: exp, normalize, sigmoid), in one place so that
+// the stand-alone kernel (mom_activations_forward) and the MLP forward's epilogue (mom_deform_forward_activated) round alike.
+__device__ __forceinline__ float mom_quat_norm(float x, float y, float z, float w)
+{
+#pragma clang fp contract(off)
+    return fmaxf(sqrtf(x * x + y * y + z * z + w * w), 1e-12f);
+}
+__device__ __forceinline__ float mom_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
 __device__ __forceinline__ int mom_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 #endif

@@ -177,9 +177,9 @@ __global__ void __launch_bounds__(256) act_fwd_kernel(int P, const float* __rest
 #pragma unroll
     for (int k = 0; k < 3; k++) s[3 * i + k] = expf(sr[3 * i + k]);
     const float4 q = *reinterpret_cast<const float4*>(rr + 4 * i);
-    const float n = fmaxf(sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w), 1e-12f);
+    const float n = mom_quat_norm(q.x, q.y, q.z, q.w);
     *reinterpret_cast<float4*>(r + 4 * i) = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
-    o[i] = 1.0f / (1.0f + expf(-orr[i]));
+    o[i] = mom_sigmoid(orr[i]);
 }
 __global__ void __launch_bounds__(256)
 act_bwd_kernel(int P, const float* __restrict__ s, const float* __restrict__ rr, const float* __restrict__ o,

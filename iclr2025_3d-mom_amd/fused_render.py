@@ -88,11 +88,10 @@ class FusedRender:
         hp, keep, md = self._desc
         N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, float(cam.time),
                                          None if order is None else order.data_ptr(), self.feat.data_ptr(), s), "hexplane_fwd")
-        N.check(lib.mom_deform_forward(C.byref(md), P, self.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
-                                       flow.data_ptr(), float(delta_scale * cam.frame_num), self.pts.data_ptr(),
-                                       self.sc_d.data_ptr(), self.rot_d.data_ptr(), None, s), "deform_fwd")
-        N.check(lib.mom_activations_forward(P, self.sc_d.data_ptr(), self.rot_d.data_ptr(), opac.data_ptr(), self.sc.data_ptr(),
-                                            self.rot.data_ptr(), self.op.data_ptr(), s), "act_fwd")
+        N.check(lib.mom_deform_forward_activated(C.byref(md), P, self.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                                 flow.data_ptr(), float(delta_scale * cam.frame_num), self.pts.data_ptr(),
+                                                 self.sc_d.data_ptr(), self.rot_d.data_ptr(), None, opac.data_ptr(),
+                                                 self.sc.data_ptr(), self.rot.data_ptr(), self.op.data_ptr(), s), "deform_fwd")
         a = N.MomRasterArgs()
         a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H
         a.background, a.means3D = bg.data_ptr(), self.pts.data_ptr()

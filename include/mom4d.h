@@ -351,6 +351,14 @@ typedef struct MomDeformMLP {
 int mom_deform_forward(const MomDeformMLP* w, int P, const float* feat /* [P,64] */, const float* xyz, const float* scaling,
                        const float* rotation, const float* scene_flow, float flow_coef, float* pts, float* scales, float* rots,
                        float* a0_save, mom_stream_t stream);
+/* The same, also leaving the activated values the rasterizer takes (gaussian_renderer/__init__.py:96-99: scaling_activation = exp,
+ * rotation_activation = normalize, opacity_activation = sigmoid of the UNdeformed opacity) -- what mom_activations_forward would
+ * compute from scales / rots / opacity_raw, without its launch.  Any of scales_act, rots_act, opacity_act may be null;
+ * opacity_raw is required exactly when opacity_act is given. */
+int mom_deform_forward_activated(const MomDeformMLP* w, int P, const float* feat, const float* xyz, const float* scaling,
+                                 const float* rotation, const float* scene_flow, float flow_coef, float* pts, float* scales,
+                                 float* rots, float* a0_save, const float* opacity_raw, float* scales_act, float* rots_act,
+                                 float* opacity_act, mom_stream_t stream);
 /* d{pts,scales,rots}: gradients of the three outputs; writes dfeat [P,64]; weight/bias gradients accumulate into w->d*.
  * (The identity paths d xyz += dpts etc. are the caller's.) */
 size_t mom_deform_backward_scratch_bytes(int P);   /* 4 x [P,64] floats: the per-layer pre-activation gradients */
