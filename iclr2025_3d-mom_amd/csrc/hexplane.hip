@@ -217,7 +217,6 @@ __device__ __forceinline__ int time_sample(float c, int size, int& i0, int& i1, 
 // exact; ax = 1 - bx, ay = 1 - by are bit-identical to ATen's (x0+1) - ix (Sterbenz), so the four weights are
 // ATen's.  A corner that is outside gets weight exactly 0 and is redirected to the texel next to it.
 // =================================================================================================================
-constexpr int kChunk4 = 64;
 
 __device__ __forceinline__ float4 make_rec4(float cx, float cy, int Wd, int Hd)
 {
@@ -251,38 +250,58 @@ __device__ __forceinline__ Corner4 decode4(const float4 r, int Wd)
     return c;
 }
 
+__device__ __forceinline__ float ld_f32(const float* __restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);     // uniform base + 32-bit lane offset
+}
+
+// Forward record of one (point, plane), ready to use: the four corners' byte offsets and their four weights.  Decoding the
+// compact record above cost every channel lane a dozen instructions per (point, plane) -- half of the forward kernel's
+// instruction stream (25.5 M wave instructions per launch on 76 % of the issue cycles); it is done once per point here.
+__device__ __forceinline__ void make_rec_fwd(float cx, float cy, int Wd, int Hd, uint4& O, float4& Wt)
+{
+    const Corner4 c = decode4(make_rec4(cx, cy, Wd, Hd), Wd);
+    O = make_uint4((unsigned)c.o00 * 4u, (unsigned)c.o01 * 4u, (unsigned)c.o10 * 4u, (unsigned)c.o11 * 4u);
+    Wt = make_float4(c.w00, c.w01, c.w10, c.w11);
+}
+constexpr int kChunkF = 32;            // points per wave and chunk in the forward: each half-wave walks 16
+
 __global__ void __launch_bounds__(256)
 hexplane_fwd4_kernel(HexArgs a, int nchunks, const float* __restrict__ xyz, float* __restrict__ feat)
 {
-    __shared__ float4 s_rec[4][kChunk4][6];
+    __shared__ uint4 s_off[4][kChunkF][6];
+    __shared__ float4 s_wt[4][kChunkF][6];
     const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     const int lvl = blockIdx.y;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
     for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-        const int gi = chunk * kChunk4 + lane;
-        const int g_mine = gi < a.P ? (a.order ? (int)a.order[gi] : gi) : -1;
+        const int gi = chunk * kChunkF + lane;
+        const int g_mine = (lane < kChunkF && gi < a.P) ? (a.order ? (int)a.order[gi] : gi) : -1;
         __builtin_amdgcn_wave_barrier();
         if (g_mine >= 0) {
             float c[4];
             norm_coords(a, xyz, g_mine, c);
 #pragma unroll
-            for (int p = 0; p < 6; p++) s_rec[wv][lane][p] = make_rec4(c[kCombA[p]], c[kCombB[p]], a.res[lvl][kCombA[p]], a.res[lvl][kCombB[p]]);
+            for (int p = 0; p < 6; p++)
+                make_rec_fwd(c[kCombA[p]], c[kCombB[p]], a.res[lvl][kCombA[p]], a.res[lvl][kCombB[p]], s_off[wv][lane][p], s_wt[wv][lane][p]);
         }
         __builtin_amdgcn_wave_barrier();
-        const int npts = min(kChunk4, a.P - chunk * kChunk4);
-        const int n_half = max(0, min(32, npts - 32 * h));     // this half walks points [32h, 32h + n_half)
+        const int npts = min(kChunkF, a.P - chunk * kChunkF);
+        const int n_half = max(0, min(kChunkF / 2, npts - (kChunkF / 2) * h));     // this half walks points [16h, 16h + n_half)
         for (int i = 0; i < n_half; i++) {
-            const int g = __shfl(g_mine, 32 * h + i);
+            const int pt = (kChunkF / 2) * h + i;
+            const int g = __shfl(g_mine, pt);
             float prod = 1.f;
 #pragma unroll
             for (int p = 0; p < 6; p++) {
-                const Corner4 c = decode4(s_rec[wv][32 * h + i][p], a.res[lvl][kCombA[p]]);
+                const uint4 o = s_off[wv][pt][p];
+                const float4 w = s_wt[wv][pt][p];
                 const float* __restrict__ pl = a.planes[lvl][p] + ch;
                 float v = 0.f;
-                v += pl[c.o00] * c.w00;
-                v += pl[c.o01] * c.w01;
-                v += pl[c.o10] * c.w10;
-                v += pl[c.o11] * c.w11;
+                v += ld_f32(pl, o.x) * w.x;
+                v += ld_f32(pl, o.y) * w.y;
+                v += ld_f32(pl, o.z) * w.z;
+                v += ld_f32(pl, o.w) * w.w;
                 prod = prod * v;
             }
             feat[(size_t)g * (a.levels * 32) + lvl * 32 + ch] = prod;
@@ -332,10 +351,6 @@ __device__ __forceinline__ void make_rec5(float cx, float cy, int Wd, int Hd, un
     R2 = make_float4(ix - (float)x0, iy - (float)y0, gxm != 0.f ? gsx : 0.f, gym != 0.f ? gsy : 0.f);
 }
 
-__device__ __forceinline__ float ld_f32(const float* __restrict__ base, unsigned byte_off)
-{
-    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);     // uniform base + 32-bit lane offset
-}
 
 #ifndef HX_GATHER_WAVES
 #define HX_GATHER_WAVES 4
@@ -682,7 +697,7 @@ extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* x
     const long long units = (long long)P * hp->levels;
     MomProfScope ps(MOM_P_HEX_FWD, (hipStream_t)stream);
     if (!times) {
-        const int nchunks = (P + kChunk4 - 1) / kChunk4;
+        const int nchunks = (P + kChunkF - 1) / kChunkF;
         int blocks = (nchunks + 3) / 4;
         if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(hexplane_fwd4_kernel, dim3(blocks, hp->levels), dim3(256), 0, (hipStream_t)stream, a, nchunks, xyz, feat);
