@@ -199,8 +199,12 @@ deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
     load_weights(m, lds);
     __syncthreads();
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (int t = wave; t < tiles; t += nwaves) {
+    // Every workgroup takes a contiguous, equal (+-1) share of the tiles and deals it to its waves.  Dealing tiles to ALL the
+    // launch's waves in turn left the remainder with the first workgroups only: at 6250 tiles on 4096 waves 134 CUs worked
+    // through 8 tiles per SIMD while 122 had 4 -- the launch lasted 8 where the mean is 6.1.
+    const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
+    const int t_first = t_begin + (int)(threadIdx.x >> 6), t_step = (int)(blockDim.x >> 6);
+    for (int t = t_first; t < t_end; t += t_step) {
         const int g = t * 32 + col;
         const bool ok = g < P;
         f32x16 a0[2];
@@ -237,7 +241,7 @@ deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
     // Activated copies (mom_deform_forward_activated), after the tile loop: inside it their temporaries pushed the kernel over
     // its 128-register budget (100 bytes of scratch per lane, +15 us).  Each lane re-reads what it stored itself.
     if (act.scales || act.rots || act.opacity) {
-        for (int t = wave; t < tiles; t += nwaves) {
+        for (int t = t_first; t < t_end; t += t_step) {
             const int g = t * 32 + col;
             if (h != 0 || g >= P) continue;
             if (act.scales) {
@@ -278,13 +282,17 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     float* sA = lds + kLStage + wv * kStageFloats;
     float* sD = sA + kHid * kStageStride;              // dout[32 gaussians][4]
-    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    // Every workgroup takes a contiguous, equal (+-1) share of the tiles and deals it to its waves.  Dealing tiles to ALL the
+    // launch's waves in turn left the remainder with the first workgroups only: at 6250 tiles on 4096 waves 134 CUs worked
+    // through 8 tiles per SIMD while 122 had 4 -- the launch lasted 8 where the mean is 6.1.
+    const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
+    const int t_first = t_begin + (int)(threadIdx.x >> 6), t_step = (int)(blockDim.x >> 6);
     const size_t PH = (size_t)P * kHid;
     float dW2[3][4], db2[3];                           // lane = feature; db2: lane n < 4 holds output n
 #pragma unroll
     for (int k = 0; k < 3; k++) { db2[k] = 0.f; dW2[k][0] = dW2[k][1] = dW2[k][2] = dW2[k][3] = 0.f; }
 
-    for (int t = wave; t < tiles; t += nwaves) {
+    for (int t = t_first; t < t_end; t += t_step) {
         const int g = t * 32 + col;
         const bool ok = g < P;
         f32x16 a0[2], dA0[2];
