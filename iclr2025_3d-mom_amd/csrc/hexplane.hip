@@ -699,7 +699,9 @@ extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* x
     if (!times) {
         const int nchunks = (P + kChunkF - 1) / kChunkF;
         int blocks = (nchunks + 3) / 4;
-        if (blocks > 1024) blocks = 1024;
+        // one chunk per wave while that stays under 8192 workgroups per level: the dispatcher balances whole workgroups; a cap of
+        // 1024 (round 1) gave half of the waves two chunks and the rest one
+        if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(hexplane_fwd4_kernel, dim3(blocks, hp->levels), dim3(256), 0, (hipStream_t)stream, a, nchunks, xyz, feat);
         return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
     }
