@@ -14,7 +14,7 @@
 //   cov3D[P][6] float, clamped[P] uchar4, gacc[P][12] float (backward accumulators), reach[P] u64 (tile cull: bit i =
 //   tile i of the splat's rectangle is binned; written by tile_hist, read by tile_scatter)
 // image: hdr[64] u32, tile_counts[tiles] u32, tile_cursor[tiles] u32, ranges[tiles] uint2, n_contrib[H*W] u32,
-//        final_T[H*W] f32
+//        final_T[H*W] f32, tile_order[tiles] u32
 // binning: keys[cap] u64, point_list[cap] u32   (sized once the instance count is known)
 struct GeomView {
     float4* rec;
@@ -30,6 +30,7 @@ struct ImageView {
     uint2* ranges;
     uint32_t* n_contrib;
     float* final_T;
+    uint32_t* tile_order;   // [tiles]: the launch's tiles, heaviest first (tile_scan) -- the compositing kernels' workgroup i takes tile_order[i]
 };
 struct BinView {
     uint64_t* keys;
@@ -66,7 +67,9 @@ static inline size_t image_view(char* base, int W, int H, ImageView* v)
     size_t o_r = off; off = mom_align_up(off + tiles * 8);
     size_t o_n = off; off = mom_align_up(off + N * 4);
     size_t o_t = off; off = mom_align_up(off + N * 4);
+    size_t o_o = off; off = mom_align_up(off + tiles * 4);
     if (v) {
+        v->tile_order = (uint32_t*)(base + o_o);
         v->hdr = (uint32_t*)(base + o_h);
         v->tile_counts = (uint32_t*)(base + o_c);
         v->tile_cursor = (uint32_t*)(base + o_u);

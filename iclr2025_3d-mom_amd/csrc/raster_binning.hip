@@ -32,6 +32,7 @@ constexpr int kSortLdsCap = 8192;      // 64 KiB of 64-bit keys per workgroup: t
 #endif
 constexpr int kSortSmallCap = MOM_SORT_SMALL;   // tiles up to this size go to the launch with the small LDS footprint
 constexpr int kMaxLdsTiles = 16384;    // 64 KiB LDS histogram
+constexpr int kOrderBins = 128;        // weight classes of the tile order (32 instances each; the last one open-ended)
 
 // What the tile cull needs of a splat (mom_rect_reach, mom_common.h).  cull == 0: every tile of the rectangle is kept, as
 // the reference does (MomRasterArgs.keep_all_tiles).
@@ -220,10 +221,12 @@ __global__ void __launch_bounds__(256) tile_hist_kernel(int P, int chunks, int g
 __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32_t* __restrict__ tile_counts,
                                                         uint32_t* __restrict__ tile_cursor, uint2* __restrict__ ranges,
                                                         uint32_t* __restrict__ hdr, uint32_t* __restrict__ num_rendered_dev,
-                                                        uint32_t* __restrict__ num_rendered_host)
+                                                        uint32_t* __restrict__ num_rendered_host, int t0, int nt,
+                                                        uint32_t* __restrict__ tile_order)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_bin[kOrderBins + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
@@ -250,8 +253,34 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
         if (threadIdx.x == 1023) s_carry = start + n;
         __syncthreads();
     }
+    // The launch's tiles [t0, t0 + nt) in order of decreasing instance count (a counting sort over kOrderBins classes of 32
+    // instances; the order inside a class is whatever the atomics make it -- it only places work).  The compositing kernels
+    // take their tiles in this order: the dispatcher deals consecutive workgroups to different XCDs and CUs, so every CU gets
+    // tiles of every weight class, and the workgroups that start late, when the first ones retire, are the light ones.
+    for (int i = threadIdx.x; i <= kOrderBins; i += 1024) s_bin[i] = 0;
+    __syncthreads();
+    auto bin_of = [&](uint32_t n) { return kOrderBins - 1 - (int)min((uint32_t)(kOrderBins - 1), n >> 5); };
+    for (int t = t0 + threadIdx.x; t < t0 + nt; t += 1024) atomicAdd(&s_bin[bin_of(tile_counts[t]) + 1], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {                 // s_bin[b + 1] = size of class b  ->  s_bin[b] = first position of class b (one wave, two classes per lane)
+        static_assert(kOrderBins == 128, "two classes per lane of one wave");
+        const uint32_t c0 = s_bin[2 * lane + 1], c1 = s_bin[2 * lane + 2];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const uint32_t excl = incl - (c0 + c1);
+        s_bin[2 * lane] = excl;
+        s_bin[2 * lane + 1] = excl + c0;
+    }
+    __syncthreads();
+    for (int t = t0 + threadIdx.x; t < t0 + nt; t += 1024) tile_order[atomicAdd(&s_bin[bin_of(tile_counts[t])], 1u)] = (uint32_t)t;
     if (threadIdx.x == 0) {
         hdr[0] = s_carry;
+        hdr[3] = (uint32_t)t0;              // the range the order covers: a later launch over other rows ignores the order
+        hdr[4] = (uint32_t)nt;
         *num_rendered_dev = s_carry;
         // device-accessible pinned host memory: the count reaches the host without a copy command behind this kernel
         if (num_rendered_host) __hip_atomic_store(num_rendered_host, s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -362,11 +391,11 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int nthreads, int 
 // leaves the others to the sibling launch.  A single kernel sized for the worst case reserved 64 KB of LDS for every tile
 // and fitted two workgroups per CU, while the average tile at 960x540 has ~650 keys.
 template <int LO, int CAP>
-__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ point_list, uint32_t capacity)
+__global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
+                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, uint32_t capacity)
 {
     __shared__ uint64_t s_keys[CAP];
-    const uint2 r = ranges[blockIdx.x];
+    const uint2 r = ranges[tile_order[blockIdx.x]];         // the launch's tiles, heaviest first (tile_scan)
     uint32_t end = r.y < capacity ? r.y : capacity;
     if (r.x >= end) return;
     const int n = (int)(end - r.x);
@@ -413,7 +442,7 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SCAN, s);
     hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tiles, im.tile_counts, im.tile_cursor, im.ranges, im.hdr,
-                       num_rendered_dev, num_rendered_host);
+                       num_rendered_dev, num_rendered_host, gx * ry0, gx * (ry1 - ry0), im.tile_order);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
@@ -440,9 +469,12 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     mom_prof_end(MOM_P_SCATTER, s);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_SORT, s);
-    hipLaunchKernelGGL((tile_sort_kernel<0, kSortSmallCap>), dim3(tiles), dim3(256), 0, s, im.ranges, b.keys, b.point_list, cap);
-    if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
-    hipLaunchKernelGGL((tile_sort_kernel<kSortSmallCap, kSortLdsCap>), dim3(tiles), dim3(256), 0, s, im.ranges, b.keys, b.point_list,
+    const int nt = gx * (ry1 - ry0);      // the rows the geometry stage binned: the order covers exactly these tiles
+    if (nt == 0) return MOM_OK;
+    hipLaunchKernelGGL((tile_sort_kernel<0, kSortSmallCap>), dim3(nt), dim3(256), 0, s, im.ranges, im.tile_order, b.keys, b.point_list,
                        cap);
+    if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    hipLaunchKernelGGL((tile_sort_kernel<kSortSmallCap, kSortLdsCap>), dim3(nt), dim3(256), 0, s, im.ranges, im.tile_order, b.keys,
+                       b.point_list, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -28,6 +28,9 @@ __device__ __forceinline__ int remap_tile(int b, int nt, int C)
     return (q * 8 + xcd) * C + (slot - q * C);
 }
 static inline int tile_run(int gx) { return gx >= 8 ? gx / 4 : 1; }
+#ifndef MOM_TILE_ORDER
+#define MOM_TILE_ORDER 1
+#endif
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v)
@@ -171,14 +174,18 @@ __device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* 
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FWD_WAVES, MOM_FWD_WAVES)))
 render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
-                  const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
+                  const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
                   uint32_t capacity, L1Epilogue l1)
 {
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
     __shared__ uint16_t s_lists[4][kRound];
-    const int tile = t0 + remap_tile(blockIdx.x, nt, run);      // t0: first tile of this launch's rows (tile-row shard)
+    // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
+    // (the order was made for the rows of the forward's geometry stage, kept in header words 3 and 4; a launch over other rows -- the
+    // backward of a tile-row shard that rendered a halo -- falls back to the positional mapping)
+    const bool ordered = MOM_TILE_ORDER && order_hdr[3] == (uint32_t)t0 && order_hdr[4] == (uint32_t)nt;
+    const int tile = ordered ? (int)tile_order[blockIdx.x] : t0 + remap_tile(blockIdx.x, nt, run);
     const int tx = tile % gx, ty = tile / gx;
     const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
     const int ly = kFH * ((threadIdx.x >> 6) / kWX) + (threadIdx.x & 63) / kFW;
@@ -295,7 +302,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_WAVES, MOM_BWD_WAVES)))
 render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
-                  const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
+                  const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                   const float* __restrict__ dL_dpixel_depths, float* __restrict__ gacc, uint32_t capacity)
 {
@@ -303,7 +310,11 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     __shared__ uint32_t s_id[kRound];
     __shared__ uint8_t s_mask[kRound];
     __shared__ uint16_t s_lists[4][kRound];
-    const int tile = t0 + remap_tile(blockIdx.x, nt, run);      // t0: first tile of this launch's rows (tile-row shard)
+    // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
+    // (the order was made for the rows of the forward's geometry stage, kept in header words 3 and 4; a launch over other rows -- the
+    // backward of a tile-row shard that rendered a halo -- falls back to the positional mapping)
+    const bool ordered = MOM_TILE_ORDER && order_hdr[3] == (uint32_t)t0 && order_hdr[4] == (uint32_t)nt;
+    const int tile = ordered ? (int)tile_order[blockIdx.x] : t0 + remap_tile(blockIdx.x, nt, run);
     const int tx = tile % gx, ty = tile / gx;
     const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
     const int ly = kFH * ((threadIdx.x >> 6) / kWX) + (threadIdx.x & 63) / kFW;
@@ -445,7 +456,7 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     if (nt == 0) return MOM_OK;
     L1Epilogue l1 = {a->l1_target, a->l1_grad, a->l1_sums, 1.0f / (3.0f * (float)a->W * (float)a->H)};
     if (!l1.grad || !l1.sums) l1.target = nullptr;
-    hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx),
+    hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
                        out_depth, cap, l1);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
@@ -462,7 +473,7 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     mom_tile_rows(a, gy, &ry0, &ry1);
     const int nt = gx * (ry1 - ry0);
     if (nt == 0) return MOM_OK;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx),
+    hipLaunchKernelGGL(render_bwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
