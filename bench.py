@@ -394,7 +394,14 @@ def main():
             out["render_fps"] = render_fps(scene, g, trainer.pipe, trainer.background, trainer.delta_scale)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+        # RCCL announces itself through C stdio, which is block-buffered when stdout is a pipe or a file and would come out at
+        # exit, AFTER this line: push it out first so that the JSON line is the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
