@@ -229,10 +229,13 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
     __shared__ uint32_t s_bin[kOrderBins + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
+    for (int i = threadIdx.x; i <= kOrderBins; i += 1024) s_bin[i] = 0;
+    auto bin_of = [&](uint32_t n) { return kOrderBins - 1 - (int)min((uint32_t)(kOrderBins - 1), n >> 5); };
     __syncthreads();
     for (int base = 0; base < tiles; base += 1024) {
         const int t = base + threadIdx.x;
         const uint32_t n = t < tiles ? tile_counts[t] : 0u;
+        if (t >= t0 && t < t0 + nt) atomicAdd(&s_bin[bin_of(n) + 1], 1u);     // class sizes of the tile order (below)
         uint32_t incl = n;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -257,11 +260,6 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
     // instances; the order inside a class is whatever the atomics make it -- it only places work).  The compositing kernels
     // take their tiles in this order: the dispatcher deals consecutive workgroups to different XCDs and CUs, so every CU gets
     // tiles of every weight class, and the workgroups that start late, when the first ones retire, are the light ones.
-    for (int i = threadIdx.x; i <= kOrderBins; i += 1024) s_bin[i] = 0;
-    __syncthreads();
-    auto bin_of = [&](uint32_t n) { return kOrderBins - 1 - (int)min((uint32_t)(kOrderBins - 1), n >> 5); };
-    for (int t = t0 + threadIdx.x; t < t0 + nt; t += 1024) atomicAdd(&s_bin[bin_of(tile_counts[t]) + 1], 1u);
-    __syncthreads();
     if (threadIdx.x < 64) {                 // s_bin[b + 1] = size of class b  ->  s_bin[b] = first position of class b (one wave, two classes per lane)
         static_assert(kOrderBins == 128, "two classes per lane of one wave");
         const uint32_t c0 = s_bin[2 * lane + 1], c1 = s_bin[2 * lane + 2];
