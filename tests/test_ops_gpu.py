@@ -400,3 +400,76 @@ def test_densify_and_prune_round_matches_mask_indexing_on_the_gpu():
     assert (a0, a1, a2) == (b0, b1, b2) and a1 > a0 and a2 < a1, (a0, a1, a2, b0, b1, b2)
     for k in ref:
         assert torch.equal(hip[k], ref[k]), k
+
+
+import ctypes as C  # noqa: E402
+
+N = importlib.import_module("iclr2025_3d-mom_amd._native")
+
+
+def _mlp_state(P, seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.3).cuda()
+    params = [mk(64, 64), mk(64)]
+    for nout in (3, 3, 4):
+        params += [mk(64, 64), mk(64), mk(nout, 64), mk(nout)]
+    return params, mk
+
+
+@pytest.mark.parametrize("P", [33, 5000])
+def test_deform_forward_activated_equals_forward_plus_activation_kernel(P):
+    """mom_deform_forward_activated: the raw outputs are those of mom_deform_forward and the activated ones are, bit for bit,
+    what mom_activations_forward makes of them (both go through the same rounding-pinned helpers)."""
+    params, mk = _mlp_state(P, 100 + P)
+    feat, xyz, scal, rot, flow, opac = mk(P, 64) * 3, mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 3), mk(P, 1)
+    d = ops.DeformMLPFunction._desc(params)
+    lib, s = N.lib(), N.current_stream()
+    e = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+    pts, sc_d, rot_d = e(P, 3), e(P, 3), e(P, 4)
+    N.check(lib.mom_deform_forward(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(), flow.data_ptr(),
+                                   0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), None, s), "fwd")
+    sc, rt, op = e(P, 3), e(P, 4), e(P, 1)
+    N.check(lib.mom_activations_forward(P, sc_d.data_ptr(), rot_d.data_ptr(), opac.data_ptr(), sc.data_ptr(), rt.data_ptr(),
+                                        op.data_ptr(), s), "act")
+    pts2, sc_d2, rot_d2, sc2, rt2, op2 = e(P, 3), e(P, 3), e(P, 4), e(P, 3), e(P, 4), e(P, 1)
+    N.check(lib.mom_deform_forward_activated(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                             flow.data_ptr(), 0.7, pts2.data_ptr(), sc_d2.data_ptr(), rot_d2.data_ptr(), None,
+                                             opac.data_ptr(), sc2.data_ptr(), rt2.data_ptr(), op2.data_ptr(), s), "fwd_act")
+    torch.cuda.synchronize()
+    for a, b in ((pts, pts2), (sc_d, sc_d2), (rot_d, rot_d2), (sc, sc2), (rt, rt2), (op, op2)):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    # opacity_act without opacity_raw is refused
+    assert lib.mom_deform_forward_activated(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                            flow.data_ptr(), 0.7, pts2.data_ptr(), sc_d2.data_ptr(), rot_d2.data_ptr(), None, None,
+                                            None, None, op2.data_ptr(), s) == N.MOM_EINVAL
+
+
+def test_deform_backward_split_on_a_second_stream_equals_the_single_stream_call():
+    P = 7001
+    params, mk = _mlp_state(P, 7)
+    feat, xyz, scal, rot, flow = mk(P, 64) * 3, mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 3)
+    dpts, dsc, drot = mk(P, 3), mk(P, 3), mk(P, 4)
+    lib, s = N.lib(), N.current_stream()
+    side = torch.cuda.Stream()
+
+    def run(second):
+        grads = [torch.zeros_like(p) for p in params]
+        d = ops.DeformMLPFunction._desc(params, grads)
+        pts, sc_d, rot_d, a0 = (torch.empty(P, k, device="cuda") for k in (3, 3, 4, 64))
+        N.check(lib.mom_deform_forward(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                       flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), a0.data_ptr(), s), "fwd")
+        dfeat = torch.empty(P, 64, device="cuda")
+        scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device="cuda")
+        N.check(lib.mom_deform_backward_split(C.byref(d), P, feat.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(),
+                                              drot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s,
+                                              side.cuda_stream if second else s), "bwd")
+        if second:
+            torch.cuda.current_stream().wait_stream(side)      # the caller's join
+        torch.cuda.synchronize()
+        return dfeat, grads
+
+    f1, g1 = run(False)
+    f2, g2 = run(True)
+    assert torch.equal(f1, f2)
+    for a, b in zip(g1, g2):         # float atomics: same terms, possibly another order
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
