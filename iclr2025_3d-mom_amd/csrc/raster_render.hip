@@ -141,6 +141,9 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
 #ifndef MOM_BWD_WAVES
 #define MOM_BWD_WAVES 6
 #endif
+#ifndef MOM_BWD_MIN
+#define MOM_BWD_MIN 4
+#endif
 // Optional loss epilogue of the forward kernel (MomRasterArgs.l1_target): target null = none.
 struct L1Epilogue {
     const float* target;
@@ -149,17 +152,24 @@ struct L1Epilogue {
     float inv_n;
 };
 // Splats staged per round (a multiple of 256; each thread stages kRound / 256 of them).
+// The backward stages 512 (297 against 307 us: fewer rounds, each with two barriers and a list build, for tiles that still hold
+// ~330 splats on average), the forward 256 (139 against 147 us at 512: it stops early and wastes part of its last round).
 #ifndef MOM_ROUND
 #define MOM_ROUND 256
 #endif
+#ifndef MOM_ROUND_BWD
+#define MOM_ROUND_BWD 512
+#endif
 constexpr int kRound = MOM_ROUND, kRoundChunks = kRound / 64;
+constexpr int kRoundB = MOM_ROUND_BWD, kRoundChunksB = kRoundB / 64;
 // Compacts, for wave `wv`, the indices j < kRound whose mask has bit wv: afterwards lane k of list[c] holds entry 64 c + k of
 // the wave's list (in increasing j, so the compositing order is kept); returns the list length.
-__device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* s_list, int wv, int lane, int (&list)[kRoundChunks])
+template <int CHUNKS>
+__device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* s_list, int wv, int lane, int (&list)[CHUNKS])
 {
     int n = 0;
 #pragma unroll
-    for (int c = 0; c < kRoundChunks; c++) {
+    for (int c = 0; c < CHUNKS; c++) {
         const int j = 64 * c + lane;
         const bool bit = (s_mask[j] >> wv) & 1;
         const uint64_t bal = __ballot(bit);
@@ -168,7 +178,7 @@ __device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* 
         n += __popcll(bal);
     }
 #pragma unroll
-    for (int c = 0; c < kRoundChunks; c++) list[c] = s_list[64 * c + lane];
+    for (int c = 0; c < CHUNKS; c++) list[c] = s_list[64 * c + lane];
     return n;
 }
 
@@ -300,16 +310,16 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_WAVES, MOM_BWD_WAVES)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_MIN, MOM_BWD_WAVES)))   // LDS (31 KB) allows 5 workgroups per CU
 render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
                   const float* __restrict__ dL_dpixel_depths, float* __restrict__ gacc, uint32_t capacity)
 {
-    __shared__ float4 s_rec[kRound * 3];
-    __shared__ uint32_t s_id[kRound];
-    __shared__ uint8_t s_mask[kRound];
-    __shared__ uint16_t s_lists[4][kRound];
+    __shared__ float4 s_rec[kRoundB * 3];
+    __shared__ uint32_t s_id[kRoundB];
+    __shared__ uint8_t s_mask[kRoundB];
+    __shared__ uint16_t s_lists[4][kRoundB];
     // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
     // (the order was made for the rows of the forward's geometry stage, kept in header words 3 and 4; a launch over other rows -- the
     // backward of a tile-row shard that rendered a halo -- falls back to the positional mapping)
@@ -327,7 +337,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     if (range.y > capacity) range.y = capacity;
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
-    const int rounds = (toDo + kRound - 1) / kRound;
+    const int rounds = (toDo + kRoundB - 1) / kRoundB;
 
     const int pix = inside ? py * W + px : 0;
     const size_t HW = (size_t)H * W;
@@ -353,11 +363,11 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);
 
-    for (int i = 0; i < rounds; i++, toDo -= kRound) {
+    for (int i = 0; i < rounds; i++, toDo -= kRoundB) {
         __syncthreads();
 #pragma unroll
-        for (int sl = 0; sl < kRound / 256; sl++) {
-            const int slot = threadIdx.x + 256 * sl, progress = i * kRound + slot;
+        for (int sl = 0; sl < kRoundB / 256; sl++) {
+            const int slot = threadIdx.x + 256 * sl, progress = i * kRoundB + slot;
             uint32_t reach = 0;
             if (range.x + progress < range.y) {
                 const uint32_t id = point_list[range.y - progress - 1];
@@ -374,10 +384,10 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         }
         __syncthreads();
         // this wave's splats of the round, still back to front (render_fwd explains the lists)
-        int list[kRoundChunks];
+        int list[kRoundChunksB];
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
 #pragma unroll
-        for (int c = 0; c < kRoundChunks; c++) {
+        for (int c = 0; c < kRoundChunksB; c++) {
           const int nk = min(64, n_w - 64 * c);
           for (int k = 0; k < nk; k++) {
             const int j = __builtin_amdgcn_readlane(list[c], k);
