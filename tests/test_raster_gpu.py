@@ -361,3 +361,26 @@ def test_l1_epilogue_of_the_forward_equals_the_l1_kernel():
     np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6)
     ref = (c0 - gt).double()
     np.testing.assert_allclose(s1.cpu().numpy(), [float(ref.abs().sum()), float((ref * ref).sum())], rtol=2e-6)
+
+
+def test_tile_cull_with_degenerate_splats():
+    """Opacity 0, negative, NaN, above 1; needle-thin and huge splats; a NaN position: whatever the compositing kernels make of
+    them, they make the same of them with and without the tile cull (bit patterns compared, NaNs included)."""
+    from hip_helpers import hip_forward
+    P, W, H = 600, 96, 64
+    s = random_gaussians(P, seed=91, W=W, H=H)
+    op = s["opacities"]
+    op[0:40] = 0.0
+    op[40:80] = -0.3
+    op[80:90] = np.nan
+    op[90:130] = 1.7
+    op[130:170] = 1.0 / 255.0
+    op[170:210] = np.nextafter(np.float32(1.0 / 255.0), np.float32(0))
+    s["scales"][210:250, 0] = -9.0           # exp(-9): needles
+    s["scales"][250:270] = 1.5               # splats larger than the image
+    s["means3D"][270:274, 0] = np.nan
+    a, b = hip_forward(s), hip_forward(s, keep_all_tiles=True)
+    assert a["R"] <= b["R"]
+    for k in ("color", "depth", "final_T"):
+        np.testing.assert_array_equal(a[k].view(np.uint32), b[k].view(np.uint32))
+    np.testing.assert_array_equal(a["radii"], b["radii"])
