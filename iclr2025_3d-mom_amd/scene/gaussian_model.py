@@ -19,6 +19,8 @@ _PER_POINT = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
 
 
 class GaussianModel:
+    EMPTY_CACHE_AFTER_PRUNE = False
+
     def setup_functions(self):
         def build_covariance_from_scaling_rotation(scaling, scaling_modifier, rotation):
             L = build_scaling_rotation(scaling_modifier * scaling, rotation)
@@ -367,7 +369,10 @@ class GaussianModel:
         if max_screen_size:
             mask = mask | (self.max_radii2D > max_screen_size) | (self.get_scaling.max(dim=1).values > 0.1 * extent)
         self.prune_points(mask)
-        if torch.cuda.is_available():
+        # The reference empties the caching allocator here (scene/gaussian_model.py:692).  It changes no result; on this path it
+        # made the next densify round re-acquire its buffers from the driver -- 30 ms per large allocation, 80-90 ms per round,
+        # a third of the training time at a 100-iteration cadence (tools/boundary_cost.py).  EMPTY_CACHE_AFTER_PRUNE restores it.
+        if self.EMPTY_CACHE_AFTER_PRUNE and torch.cuda.is_available():
             torch.cuda.empty_cache()
 
     def densify(self, max_grad, min_opacity, extent, max_screen_size, density_threshold, displacement_scale, model_path=None,
