@@ -214,8 +214,10 @@ def parse_args(argv=None):
                     help="skip the extra single-GPU legs (steady state, training with lambda_dssim 0.2, render FPS)")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state leg (SURVEY 8d: >= 200)")
     ap.add_argument("--steady-warmup", type=int, default=50, help="warm-up of the steady-state leg (SURVEY 8d: 50)")
-    ap.add_argument("--path", default="fused", choices=["fused", "autograd"],
-                    help="fused: explicit launch sequence (fused_step.py); autograd: render() + loss.backward()")
+    ap.add_argument("--path", default="fused", choices=["fused", "autograd", "autograd-per-op"],
+                    help="fused: explicit launch sequence (fused_step.py); autograd: render() + loss.backward(), the way the "
+                         "reference's own loop drives the modules (render() is one autograd node, fused_autograd.py); "
+                         "autograd-per-op: the same through one autograd node per operator")
     return ap.parse_args(argv)
 
 
@@ -247,6 +249,8 @@ def main():
     dev = torch.device("cuda", local)
     DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
     scene, g, trainer, op = build_state(cfg, dev, fused=(a.path == "fused"), lambda_dssim=a.lambda_dssim)
+    if a.path == "autograd-per-op":
+        trainer.pipe.per_op_autograd = True
     cams = trainer.cams
     for c in cams:                       # inputs resident in HBM before the timed region: the cameras' matrices and
         c.device_tensors(dev)            # ground-truth images are uploaded here, not on first use inside it

@@ -1,0 +1,259 @@
+"""gaussian_renderer.render() under autograd as ONE autograd node.
+
+The reference's own training loop (train_4DGS.py:189-297) calls render(), forms the loss in torch, calls loss.backward() and
+optimizer.step().  Through the per-op mirror (HexPlane op, MLP op, activations, rasterizer op ...) that is ~40 small torch
+launches and as many autograd nodes per iteration and the host becomes the bottleneck (3.8 ms per iteration at 200 k Gaussians
+where the kernels need 1.3 ms).  Here the whole fine-stage forward of one camera is one Function whose forward is the launch
+sequence of fused_render.py (with the state a backward needs kept) and whose backward is the second half of fused_step.py:
+rasterizer backward -> activations -> MLP -> HexPlane, every parameter gradient returned at once.  The loss, the
+regularisers, the statistics and Adam stay where the reference has them.
+
+Every call owns its buffers (they come from torch's caching allocator), so several cameras can be rendered before the
+backward -- the reference's batch loop -- and images may be kept.  Binning capacity follows the rasterizer module's sync mode
+(diff_gaussian_rasterization._C.set_sync_mode): "exact" waits for the frame's instance count like the reference's cudaMemcpy;
+"async" sizes from earlier frames and reports an overflow through the module's sticky flag.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _native as N
+from . import ops
+from .diff_gaussian_rasterization import _C as RC
+
+
+DIRECT_GRADS = True      # False: return the parameter gradients through the autograd graph (hooks on the parameters then fire)
+
+
+class _State:
+    __slots__ = ("a", "keep", "P", "W", "H", "cam_time", "order", "porders", "feat", "a0", "pts", "sc_d", "rot_d", "sc", "rot", "op",
+                 "color", "depth", "radii", "geom", "img", "binning", "cap", "xyz", "scal", "rotq", "opac", "flow", "coef", "planes",
+                 "mlp", "field", "f_dc", "f_rest")
+
+
+def applies(cam, pc, pipe, stage, override_color, cam_type):
+    """Same conditions as the no-grad fast path: fine stage, the shipped deformation configuration, SH colours and covariances
+    computed by the rasterizer, an ordinary camera, everything on the GPU -- and gradients wanted."""
+    if not torch.is_grad_enabled() or stage != "fine" or override_color is not None or cam_type == "PanopticSports":
+        return False
+    if pipe.compute_cov3D_python or pipe.convert_SHs_python or not hasattr(cam, "device_tensors"):
+        return False
+    if not pc.get_xyz.is_cuda or pc.get_xyz.shape[0] == 0 or ops.BACKEND.name != "hip":
+        return False
+    if getattr(pipe, "per_op_autograd", False):
+        return False
+    dn = getattr(pc._deformation, "deformation_net", None)
+    return dn is not None and hasattr(dn, "_fusable") and dn._fusable() and pc._features_rest.shape[1] == 15
+
+
+def field_params(pc):
+    """(planes, MLP tensors) of the deformation field, cached on the model until a parameter object is replaced (walking the
+    nn.Module tree costs 70 us per call)."""
+    dn = pc._deformation.deformation_net
+    c = getattr(dn, "_fa_params", None)
+    if c is None or c[0] is not dn.grid.grids[0][0] or c[1] is not dn.feature_out[0].weight:
+        planes, mlp = [p for lv in dn.grid.grids for p in lv], dn._fused_params()
+        c = dn._fa_params = (planes[0], mlp[0], planes, mlp)
+    return c[2], c[3]
+
+
+def _forward_desc(pc, field, planes, mlp):
+    """HexPlane / MLP descriptors of the forward (pointers and shapes only): rebuilt when a parameter or the aabb moves."""
+    key = (tuple(p.data_ptr() for p in planes), tuple(p.data_ptr() for p in mlp), tuple(field.aabb_host()))
+    c = getattr(pc, "_fa_desc", None)
+    if c is None or c[0] != key:
+        hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in field.grids], field.aabb, None, aabb_host=field.aabb_host())
+        md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], None)
+        c = pc._fa_desc = (key, hp, keep, md)
+    return c[1], c[2], c[3]
+
+
+def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
+    lib, s = N.lib(), N.current_stream()
+    st = _State()
+    dev = pc._xyz.device
+    P = st.P = pc._xyz.shape[0]
+    W, H = st.W, st.H = int(cam.image_width), int(cam.image_height)
+    view, proj, campos, _ = cam.device_tensors(dev)
+    dn = pc._deformation.deformation_net
+    field = st.field = dn.grid
+    st.planes, st.mlp = field_params(pc)
+    xyz, scal, rotq, opac = pc._xyz.detach(), pc._scaling.detach(), pc._rotation.detach(), pc._opacity.detach()
+    st.f_dc, st.f_rest = pc._features_dc.detach(), pc._features_rest.detach()
+    for t in (xyz, scal, rotq, opac, st.f_dc, st.f_rest):
+        if not t.is_contiguous():
+            raise N.MomError("fused render(): the Gaussian parameters must be contiguous")
+    flow = pc._scene_flow if pc._scene_flow.is_contiguous() else pc._scene_flow.contiguous()
+    st.xyz, st.scal, st.rotq, st.opac, st.flow = xyz, scal, rotq, opac, flow
+    st.cam_time = float(cam.time)
+    st.coef = float(delta_scale * cam.frame_num)
+    st.order = field._processing_order(xyz)
+    st.porders = field._plane_orders(xyz)
+    f = dict(dtype=torch.float32, device=dev)
+    e = lambda *sh: torch.empty(*sh, **f)
+    st.feat, st.a0 = e(P, 64), e(P, 64)
+    st.pts, st.sc_d, st.rot_d = e(P, 3), e(P, 3), e(P, 4)
+    st.sc, st.rot, st.op = e(P, 3), e(P, 4), e(P, 1)
+    st.color, st.depth = e(3, H, W), e(1, H, W)
+    st.radii = torch.empty(P, dtype=torch.int32, device=dev)
+    st.geom = torch.empty(lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
+    st.img = torch.empty(lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
+    hp, keep, md = _forward_desc(pc, field, st.planes, st.mlp)
+    optr = None if st.order is None else st.order.data_ptr()
+    N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, st.cam_time, optr, st.feat.data_ptr(), s), "hexplane_fwd")
+    N.check(lib.mom_deform_forward_activated(C.byref(md), P, st.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rotq.data_ptr(),
+                                             flow.data_ptr(), st.coef, st.pts.data_ptr(), st.sc_d.data_ptr(), st.rot_d.data_ptr(),
+                                             st.a0.data_ptr(), opac.data_ptr(), st.sc.data_ptr(), st.rot.data_ptr(), st.op.data_ptr(), s),
+            "deform_fwd")
+    a = st.a = N.MomRasterArgs()
+    a.P, a.D, a.M, a.W, a.H = P, pc.active_sh_degree, 16, W, H
+    a.background, a.means3D = bg.data_ptr(), st.pts.data_ptr()
+    a.shs, a.shs_rest = st.f_dc.data_ptr(), st.f_rest.data_ptr()
+    a.colors_precomp, a.opacities = None, st.op.data_ptr()
+    a.scales, a.rotations, a.cov3D_precomp = st.sc.data_ptr(), st.rot.data_ptr(), None
+    a.viewmatrix, a.projmatrix, a.campos = view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+    a.scale_modifier = float(scaling_modifier)
+    a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    a.prefiltered, a.debug = 0, int(bool(debug))
+    st.keep = (bg, view, proj, campos, keep)
+    nr_dev = torch.empty(1, dtype=torch.int32, device=dev)
+    nr_host = torch.empty(1, dtype=torch.int32).pin_memory()
+    N.check(lib.mom_raster_forward_geometry(C.byref(a), st.geom.data_ptr(), st.img.data_ptr(), st.radii.data_ptr(), nr_dev.data_ptr(),
+                                            nr_host.data_ptr(), s), "raster_geometry")
+    # binning capacity exactly as diff_gaussian_rasterization._C.rasterize_gaussians sizes it
+    state = RC._state
+    if state["mode"] == "exact":
+        torch.cuda.current_stream().synchronize()
+        cap, flag = int(nr_host[0]), None
+    else:
+        flag = RC.overflow_flag(dev)
+        RC._check_overflow(RC._FLAG_LAG)
+        prev = state["last_R"]
+        if prev is not None:
+            state["cap_hint"] = max(state["cap_hint"], int(int(prev[0]) * 1.5) + 4096)
+        cap = max(state["cap_hint"], 4096)
+    state["last_R"] = nr_host
+    st.cap = cap
+    st.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
+    N.check(lib.mom_raster_forward_render(C.byref(a), st.geom.data_ptr(), st.binning.data_ptr(), cap, st.img.data_ptr(),
+                                          st.color.data_ptr(), st.depth.data_ptr(), None if flag is None else flag.data_ptr(), s),
+            "raster_render")
+    if flag is not None:
+        status_host = torch.empty(1, dtype=torch.int32).pin_memory()
+        status_host.copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        state["pending"].append((ev, status_host, nr_host))
+    return st
+
+
+def _field_grads(st, f):
+    """Gradient storage of the deformation field -- the planes in their channel-last storage order, then the MLP tensors, one
+    flat zeroed buffer -- with the backward descriptors that point into it.  One set is cached on the field and reused from
+    iteration to iteration (the reference's loop drops the gradients with zero_grad(set_to_none=True), so the parameters let go
+    of it); while the parameters still hold it -- a second camera of a batch -- a temporary set is made."""
+    field = st.field
+    key = (tuple(p.data_ptr() for p in st.planes), tuple(p.data_ptr() for p in st.mlp), tuple(field.aabb_host()))
+    c = getattr(field, "_fa_grads", None)
+    if c is not None and c[0] == key and st.planes[0].grad is not c[2][0]:
+        c[1].zero_()
+        return c[1:]
+    n = sum(p.numel() for p in st.planes + st.mlp)
+    flat = torch.zeros(n, **f)
+    off, gplanes, gmlp = 0, [], []
+    for p in st.planes:
+        shape = ops.plane_storage(p).shape
+        gplanes.append(flat[off:off + p.numel()].view(shape).permute(2, 0, 1).unsqueeze(0))
+        off += p.numel()
+    for p in st.mlp:
+        gmlp.append(flat[off:off + p.numel()].view(p.shape))
+        off += p.numel()
+    levels, k = [], 0
+    for lv in field.grids:
+        levels.append(gplanes[k:k + len(lv)])
+        k += len(lv)
+    hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in field.grids], field.aabb, levels, aabb_host=field.aabb_host())
+    md = ops.DeformMLPFunction._desc([p.detach() for p in st.mlp], gmlp)
+    out = (flat, gplanes, gmlp, hp, keep, md)
+    if c is None or c[0] != key:
+        field._fa_grads = (key,) + out
+    return out
+
+
+def _backward(st, dcolor, ddepth):
+    lib, s = N.lib(), N.current_stream()
+    P, dev = st.P, st.color.device
+    f = dict(dtype=torch.float32, device=dev)
+    e = lambda *sh: torch.empty(*sh, **f)
+    dcol = dcolor.contiguous().float()
+    ddep = None if ddepth is None else ddepth.contiguous().float()
+    g2d, gcol, gop_act, gxyz, gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 3), e(P, 6)
+    gdc, grest = e(P, 1, 3), e(P, 15, 3)
+    gsc_act, grot_act, gsc, grot, gop = e(P, 3), e(P, 4), e(P, 3), e(P, 4), e(P, 1)
+    gr = N.MomRasterGrads()
+    gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = g2d.data_ptr(), gcol.data_ptr(), gop_act.data_ptr()
+    gr.dL_dmeans3D, gr.dL_dcov3D = gxyz.data_ptr(), gcov.data_ptr()
+    gr.dL_dsh, gr.dL_dsh_rest = gdc.data_ptr(), grest.data_ptr()
+    gr.dL_dscales, gr.dL_drotations = gsc_act.data_ptr(), grot_act.data_ptr()
+    N.check(lib.mom_raster_backward(C.byref(st.a), st.radii.data_ptr(), st.geom.data_ptr(), st.binning.data_ptr(), st.cap,
+                                    st.img.data_ptr(), dcol.data_ptr(), None if ddep is None else ddep.data_ptr(), C.byref(gr), s),
+            "raster_bwd")
+    N.check(lib.mom_activations_backward(P, st.sc.data_ptr(), st.rot_d.data_ptr(), st.op.data_ptr(), gsc_act.data_ptr(),
+                                         grot_act.data_ptr(), gop_act.data_ptr(), gsc.data_ptr(), grot.data_ptr(), gop.data_ptr(), s),
+            "act_bwd")
+    flat, gplanes, gmlp, hp, keep, md = _field_grads(st, f)
+    dfeat = e(P, 64)
+    scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+    # pts = xyz + dx(...): d xyz starts as d pts (already in gxyz); scale / rotation residuals likewise
+    N.check(lib.mom_deform_backward(C.byref(md), P, st.feat.data_ptr(), st.a0.data_ptr(), gxyz.data_ptr(), gsc.data_ptr(),
+                                    grot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s), "deform_bwd")
+    porders = st.porders
+    hscratch = None
+    if porders is not None:
+        hscratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
+    N.check(lib.mom_hexplane_backward(C.byref(hp), P, st.xyz.data_ptr(), None, st.cam_time,
+                                      None if st.order is None else st.order.data_ptr(), dfeat.data_ptr(), gxyz.data_ptr(),
+                                      None if porders is None else porders[0].data_ptr(),
+                                      None if porders is None else porders[1].data_ptr(),
+                                      None if hscratch is None else hscratch.data_ptr(), s), "hexplane_bwd")
+    return g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp
+
+
+class FusedRenderFunction(torch.autograd.Function):
+    """(image, depth, radii) = render of one camera; inputs after the six plain arguments: the 2-D gradient holder, the six
+    Gaussian parameter tensors, the 12 HexPlane planes, the 14 MLP tensors."""
+
+    @staticmethod
+    def forward(ctx, pc, cam, bg, delta_scale, scaling_modifier, debug, screenspace, xyz, f_dc, f_rest, scaling, rotation, opacity,
+                *field):
+        st = _forward(pc, cam, bg, delta_scale, scaling_modifier, debug)
+        ctx.st, ctx.pc = st, pc
+        ctx.mark_non_differentiable(st.radii)
+        return st.color, st.depth, st.radii
+
+    @staticmethod
+    def backward(ctx, dcolor, ddepth, _dradii):
+        st = ctx.st
+        ctx.st = None                                  # the call's buffers go back to the allocator after this backward
+        g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp = _backward(st, dcolor, ddepth)
+        if DIRECT_GRADS:
+            # The 32 parameter gradients are handed to the parameters here (set, or added to what an earlier camera of the
+            # batch left) instead of being returned: 32 AccumulateGrad nodes cost the autograd engine more host time than the
+            # whole forward.  Only the 2-D gradient holder, a non-leaf, goes back through the graph.
+            pc = ctx.pc
+            for p, g in zip((pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity, *st.planes, *st.mlp),
+                            (gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp)):
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            return (None, None, None, None, None, None, g2d) + (None,) * (6 + len(gplanes) + len(gmlp))
+        return (None, None, None, None, None, None, g2d, gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp)
+
+
+def render(cam, pc, pipe, bg, delta_scale, scaling_modifier, screenspace_points):
+    planes, mlp = field_params(pc)
+    return FusedRenderFunction.apply(pc, cam, bg, 1 if delta_scale is None else delta_scale, scaling_modifier, pipe.debug,
+                                     screenspace_points, pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation,
+                                     pc._opacity, *planes, *mlp)

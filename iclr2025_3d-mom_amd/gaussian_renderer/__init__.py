@@ -46,6 +46,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         screenspace_points.retain_grad()
     except Exception:
         pass
+    from .. import fused_autograd
+    if fused_autograd.applies(viewpoint_camera, pc, pipe, stage, override_color, cam_type):
+        # the whole fine-stage forward of this camera as ONE autograd node (fused_autograd.py); pipe.per_op_autograd = True keeps
+        # the op-by-op path below
+        image, depth, radii = fused_autograd.render(viewpoint_camera, pc, pipe, bg_color, delta_scale, scaling_modifier,
+                                                    screenspace_points)
+        return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii,
+                "depth": depth, "flow_loss": 0}
 
     if cam_type != "PanopticSports":
         if hasattr(viewpoint_camera, "device_tensors"):

@@ -1,0 +1,77 @@
+"""gaussian_renderer.render() as ONE autograd node (fused_autograd.py) against the operator-by-operator autograd path
+(pipe.per_op_autograd = True): same image up to the last ulps of the activations (that path applies torch's exp / normalize /
+sigmoid, this one the kernels'), same gradients up to that and the order of float atomics; several cameras
+rendered before one backward (the reference's batch loop, train_4DGS.py:189-229) accumulate like separate backwards."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CFG = dict(P=20000, F=6, W=320, H=192, time_res=12, name="small")
+
+
+def _params(g):
+    dn = g._deformation.deformation_net
+    ps = {"xyz": g._xyz, "f_dc": g._features_dc, "f_rest": g._features_rest, "scaling": g._scaling, "rotation": g._rotation,
+          "opacity": g._opacity}
+    for l, lv in enumerate(dn.grid.grids):
+        for k, p in enumerate(lv):
+            ps[f"plane_{l}_{k}"] = p
+    for k, p in enumerate(dn._fused_params()):
+        ps[f"mlp_{k}"] = p
+    return ps
+
+
+def _run(per_op, cam_ids, keep_images=False):
+    import bench
+    render = importlib.import_module("iclr2025_3d-mom_amd.gaussian_renderer").render
+    scene, g, trainer, op = bench.build_state(CFG, torch.device("cuda"), fused=False, lambda_dssim=0.0)
+    trainer.pipe.per_op_autograd = per_op
+    ps = _params(g)
+    for p in ps.values():
+        p.grad = None
+    gen = torch.Generator("cpu").manual_seed(5)
+    wgt = torch.rand(3, CFG["H"], CFG["W"], generator=gen).cuda()
+    pkgs = [render(trainer.cams[c], g, trainer.pipe, trainer.background, stage="fine", cam_type=scene.dataset_type,
+                   delta_scale=trainer.delta_scale) for c in cam_ids]
+    images = [pk["render"].clone() for pk in pkgs]
+    loss = sum(((pk["render"] * wgt).sum() + 0.3 * pk["depth"].sum()) for pk in pkgs)
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().clone() for k, p in ps.items()}
+    vsp = [pk["viewspace_points"].grad.detach().clone() for pk in pkgs]
+    radii = [pk["radii"].clone() for pk in pkgs]
+    return float(loss), images, grads, vsp, radii
+
+
+def _close(a, b, tol=3e-5):
+    scale = max(float(b.abs().max()), 1e-30)
+    return float((a - b).abs().max()) <= tol * scale
+
+
+def test_one_node_equals_per_op_autograd():
+    l0, im0, g0, v0, r0 = _run(True, [2])
+    l1, im1, g1, v1, r1 = _run(False, [2])
+    assert float((im0[0] - im1[0]).abs().max()) <= 5e-6 and float((r0[0] != r1[0]).float().mean()) <= 1e-4
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert _close(v1[0], v0[0], tol=2e-3)
+    for k in g0:
+        assert g1[k].shape == g0[k].shape, k
+        assert [s for s, n in zip(g1[k].stride(), g1[k].shape) if n > 1] == [s for s, n in zip(g0[k].stride(), g0[k].shape) if n > 1], k
+        assert torch.isfinite(g1[k]).all() and _close(g1[k], g0[k], tol=2e-3), (k, float((g1[k] - g0[k]).abs().max()), float(g0[k].abs().max()))
+
+
+def test_a_batch_of_cameras_before_one_backward_accumulates():
+    _, im_a, g_a, v_a, _ = _run(False, [1])
+    _, im_b, g_b, v_b, _ = _run(False, [4])
+    _, im_ab, g_ab, v_ab, _ = _run(False, [1, 4])
+    assert torch.equal(im_ab[0], im_a[0]) and torch.equal(im_ab[1], im_b[0])     # the first image survives the second render
+    assert _close(v_ab[0], v_a[0]) and _close(v_ab[1], v_b[0])
+    for k in g_ab:
+        assert _close(g_ab[k], g_a[k] + g_b[k], tol=5e-5), k

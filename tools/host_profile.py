@@ -21,10 +21,11 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--top", type=int, default=30)
+    ap.add_argument("--autograd", action="store_true", help="the render() + loss.backward() path instead of the fused step")
     a = ap.parse_args()
     import torch
     cfg = bench.CONFIGS[a.config]
-    scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda", 0), fused=True)
+    scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda", 0), fused=not a.autograd)
     cams = trainer.cams
     for c in cams:
         c.device_tensors(torch.device("cuda", 0))      # as bench.py: inputs resident before timing
