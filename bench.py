@@ -230,6 +230,11 @@ def main():
     if force_spawn:
         os.environ["MOM_FORCE_DIST"] = "1"
     launch.main_or_spawn(a.gpus, os.path.abspath(__file__), sys.argv[1:], force=force_spawn)
+    # stdout carries the ONE JSON line and nothing else: everything the mirrored modules print (they print what the reference
+    # prints) and everything C libraries write to fd 1 (RCCL's banner) goes to stderr from here on
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     cfg = CONFIGS[a.config]
@@ -398,14 +403,8 @@ def main():
             out["render_fps"] = render_fps(scene, g, trainer.pipe, trainer.background, trainer.delta_scale)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        # RCCL announces itself through C stdio, which is block-buffered when stdout is a pipe or a file and would come out at
-        # exit, AFTER this line: push it out first so that the JSON line is the last line of stdout
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
