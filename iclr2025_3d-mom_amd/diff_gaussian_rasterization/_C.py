@@ -22,6 +22,21 @@ _state = {"mode": "exact", "cap_hint": 0, "last_R": None, "flag": None, "pending
 _FLAG_LAG = 4
 
 
+_PIN_RING = 256
+
+
+def pinned_word():
+    """A pinned int32 word from a ring (page-locked allocations are slow and can stall the device: none per call).  A word is
+    handed out again 256 calls later -- far beyond the few calls for which the rasterizer state refers to it."""
+    ring = _state.get("pin_ring")
+    if ring is None:
+        ring = _state["pin_ring"] = torch.zeros(_PIN_RING, dtype=torch.int32).pin_memory()
+        _state["pin_next"] = 0
+    i = _state["pin_next"]
+    _state["pin_next"] = (i + 1) % _PIN_RING
+    return ring[i:i + 1]
+
+
 def overflow_flag(device):
     """The sticky int32 device word async-mode forwards OR their overflow bit into (created on first use).  Point
     ops.FusedAdam.skip_flag at it and no optimizer step taken after an overflow reaches the model."""
@@ -130,7 +145,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                     projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, debug)
     stream = N.current_stream()
     nr_dev = torch.empty((1,), dtype=torch.int32, device=dev)
-    nr_host = torch.empty((1,), dtype=torch.int32).pin_memory()
+    nr_host = pinned_word()
     N.check(lib.mom_raster_forward_geometry(C.byref(a), geom.data_ptr(), img.data_ptr(), radii.data_ptr(),
                                             nr_dev.data_ptr(), nr_host.data_ptr(), stream), "mom_raster_forward_geometry")
     if _state["mode"] == "exact":
@@ -150,7 +165,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
                                           flag.data_ptr() if _state["mode"] == "async" else None, stream),
             "mom_raster_forward_render")
     if _state["mode"] == "async":
-        status_host = torch.empty((1,), dtype=torch.int32).pin_memory()
+        status_host = pinned_word()
         status_host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

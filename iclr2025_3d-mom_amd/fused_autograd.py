@@ -118,7 +118,7 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
     a.prefiltered, a.debug = 0, int(bool(debug))
     st.keep = (bg, view, proj, campos, keep)
     nr_dev = torch.empty(1, dtype=torch.int32, device=dev)
-    nr_host = torch.empty(1, dtype=torch.int32).pin_memory()
+    nr_host = RC.pinned_word()
     N.check(lib.mom_raster_forward_geometry(C.byref(a), st.geom.data_ptr(), st.img.data_ptr(), st.radii.data_ptr(), nr_dev.data_ptr(),
                                             nr_host.data_ptr(), s), "raster_geometry")
     # binning capacity exactly as diff_gaussian_rasterization._C.rasterize_gaussians sizes it
@@ -140,7 +140,7 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
                                           st.color.data_ptr(), st.depth.data_ptr(), None if flag is None else flag.data_ptr(), s),
             "raster_render")
     if flag is not None:
-        status_host = torch.empty(1, dtype=torch.int32).pin_memory()
+        status_host = RC.pinned_word()
         status_host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--autograd", action="store_true", help="the render() + loss.backward() path instead of the fused step")
     a = ap.parse_args()
     import torch
+    if a.autograd:
+        torch.autograd.set_multithreading_enabled(False)        # the backward's Python runs on this thread: the profiler sees it
     cfg = bench.CONFIGS[a.config]
     scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda", 0), fused=not a.autograd)
     cams = trainer.cams
