@@ -111,6 +111,7 @@ def _sig(lib):
     lib.mom_l1_loss_acc.argtypes = [sz, vp, vp, vp, vp, vp]
     lib.mom_plane_regulation.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
     lib.mom_plane_regulation_acc.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp]
+    lib.mom_plane_regulation_grad.argtypes = [C.POINTER(MomRegPlane), i32, vp, vp, vp]
     lib.mom_deform_forward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]
     lib.mom_deform_forward_activated.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp,
                                                  vp, vp, vp]
@@ -162,7 +163,7 @@ EXPORTS = [
     "mom_densify_stats", "mom_select_scratch_bytes", "mom_select_plan", "mom_select_apply",
     "mom_ssim_forward_slab", "mom_ssim_backward_slab",
     "mom_hexplane_backward_scratch_bytes", "mom_hexplane_orders_scratch_bytes", "mom_hexplane_orders", "mom_image_to_rgb8",
-    "mom_l1_loss_acc", "mom_plane_regulation_acc",
+    "mom_l1_loss_acc", "mom_plane_regulation_acc", "mom_plane_regulation_grad",
 ]
 
 

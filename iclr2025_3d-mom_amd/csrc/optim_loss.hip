@@ -105,12 +105,14 @@ struct RegArgs {
     MomRegPlane p[MOM_REG_MAX_PLANES];
     unsigned block_start[MOM_REG_MAX_PLANES + 1];
     int count;
+    const float* upstream;     // device scalar multiplied into every gradient (null: 1): the loss weight that autograd hands down
 };
 
 constexpr int kRegRows = 16;   // rows of H per workgroup (plus a 2-row halo on each side)
 
 __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __restrict__ out /* [0] = value */)
 {
+    const float up = a.upstream ? *a.upstream : 1.f;
     __shared__ float s[4];
     int pi = 0;
     while (pi + 1 < a.count && blockIdx.x >= a.block_start[pi + 1]) pi++;
@@ -157,7 +159,7 @@ __global__ void __launch_bounds__(256) plane_reg_kernel(RegArgs a, float* __rest
                     val += cl * fabsf(d);
                     gr += d > 0.f ? -cl : (d < 0.f ? cl : 0.f);
                 }
-                if (g) g[(size_t)h * row + col] = gv[k] + gr * P.grad_scale;
+                if (g) g[(size_t)h * row + col] = gv[k] + gr * (P.grad_scale * up);
             }
         }
     }
@@ -300,6 +302,12 @@ extern "C" int mom_plane_regulation(const MomRegPlane* planes, int count, float*
 
 extern "C" int mom_plane_regulation_acc(const MomRegPlane* planes, int count, float* value, mom_stream_t stream)
 {
+    return mom_plane_regulation_grad(planes, count, value, nullptr, stream);
+}
+
+extern "C" int mom_plane_regulation_grad(const MomRegPlane* planes, int count, float* value, const float* upstream,
+                                         mom_stream_t stream)
+{
     if (count < 0 || count > MOM_REG_MAX_PLANES || !value || (count && !planes)) return MOM_EINVAL;
     RegArgs a;
     unsigned blocks = 0;
@@ -311,6 +319,7 @@ extern "C" int mom_plane_regulation_acc(const MomRegPlane* planes, int count, fl
     }
     a.block_start[count] = blocks;
     a.count = count;
+    a.upstream = upstream;
     MomProfScope ps(MOM_P_REG, (hipStream_t)stream);
     if (blocks) hipLaunchKernelGGL(plane_reg_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, value);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;

@@ -376,17 +376,37 @@ class PlaneRegFunction(torch.autograd.Function):
     def backward(ctx, g):
         planes = ctx.saved_tensors
         w_smooth, w_l1 = ctx.w
-        grads = [torch.zeros_like(p) for p in planes]
-        arr = (N.MomRegPlane * len(planes))()
-        gs = float(g)  # the loss weight is a python scalar in the reference loop (train_4DGS.py:217-218)
-        for i, p in enumerate(planes):
-            st, gt_ = plane_storage(p), plane_storage(grads[i])
-            arr[i].plane, arr[i].grad = st.data_ptr(), gt_.data_ptr()
-            arr[i].H, arr[i].W = st.shape[0], st.shape[1]
-            arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), gs
-        val = torch.empty(1, dtype=torch.float32, device=planes[0].device)
-        N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), N.current_stream()), "mom_plane_regulation")
+        # One flat zeroed buffer and the kernel descriptor, cached between iterations while the planes have let go of last
+        # iteration's gradients (zero_grad(set_to_none=True)); the upstream weight stays on the device (float(g) was a host
+        # synchronisation in every iteration).
+        key = tuple(p.data_ptr() for p in planes) + tuple(w_smooth) + tuple(w_l1)
+        c = PlaneRegFunction._cache
+        busy = c is not None and planes[0].grad is not None and planes[0].grad.data_ptr() == c[2][0].data_ptr()
+        if c is None or c[0] != key or busy:
+            flat = torch.zeros(sum(p.numel() for p in planes), dtype=torch.float32, device=planes[0].device)
+            off, grads = 0, []
+            arr = (N.MomRegPlane * len(planes))()
+            for i, p in enumerate(planes):
+                st = plane_storage(p)
+                gv = flat[off:off + p.numel()].view(st.shape)
+                off += p.numel()
+                grads.append(gv.permute(2, 0, 1).unsqueeze(0))
+                arr[i].plane, arr[i].grad = st.data_ptr(), gv.data_ptr()
+                arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+                arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), 1.0
+            val = torch.empty(1, dtype=torch.float32, device=planes[0].device)
+            c = (key, flat, grads, arr, val)
+            if not busy:
+                PlaneRegFunction._cache = c
+        else:
+            c[1].zero_()
+        _, flat, grads, arr, val = c
+        up = g.detach().reshape(1).float()
+        N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), N.current_stream()),
+                "mom_plane_regulation")
         return (None, None, *grads)
+
+    _cache = None
 
 
 def plane_regulation(planes, w_smooth, w_l1):

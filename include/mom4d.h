@@ -335,6 +335,9 @@ typedef struct MomRegPlane {
 } MomRegPlane;
 int mom_plane_regulation(const MomRegPlane* planes, int count, float* value, mom_stream_t stream);
 int mom_plane_regulation_acc(const MomRegPlane* planes, int count, float* value, mom_stream_t stream);   /* value is not zeroed first */
+/* _acc with every gradient also multiplied by *upstream, a DEVICE scalar (null: 1): the weight autograd hands down to the
+ * regulariser's backward, without reading it back to the host first. */
+int mom_plane_regulation_grad(const MomRegPlane* planes, int count, float* value, const float* upstream, mom_stream_t stream);
 
 /* ---- fused deformation MLP (scene/deformation.py:53-65,97-135; W = 64, defor_depth = 0, heads pos/scales/rot) ----
  *   h0 = W0 feat + b0 ;  o_k = W2_k relu(W1_k relu(h0) + b1_k) + b2_k  for k in {pos, scales, rot}

@@ -6,7 +6,7 @@ out=$PWD/gpurun_out/$tag
 mkdir -p $out
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $out -o run -- python3 $repo/tools/kbench.py render_bwd > $out/kbench.log 2> $out/err.log
+rocprofv3 --kernel-trace --output-format csv -d $out -o run -- python3 $repo/${STEP_SCRIPT:-tools/kbench.py} render_bwd > $out/kbench.log 2> $out/err.log
 f=$(find $out -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY' | tee $out/timeline.txt
 import csv, re, sys
