@@ -376,12 +376,19 @@ class PlaneRegFunction(torch.autograd.Function):
     def backward(ctx, g):
         planes = ctx.saved_tensors
         w_smooth, w_l1 = ctx.w
-        # One flat zeroed buffer and the kernel descriptor, cached between iterations while the planes have let go of last
-        # iteration's gradients (zero_grad(set_to_none=True)); the upstream weight stays on the device (float(g) was a host
-        # synchronisation in every iteration).
-        key = tuple(p.data_ptr() for p in planes) + tuple(w_smooth) + tuple(w_l1)
+        # The kernel ADDS the regulariser's share into a plane's gradient.  Planes that already hold one of the right layout (the
+        # render node ran first) are accumulated into in place; the others get a view of one flat zeroed buffer, which becomes
+        # their gradient.  Handing the gradients to the planes here, instead of returning them, also spares the engine twelve
+        # AccumulateGrad nodes and -- a plane has two consumers, this op and render() -- twelve elementwise additions
+        # (DIRECT_GRADS = False returns them through the graph).  The buffer and the descriptor are cached between iterations
+        # while the planes have let go of last iteration's gradients (zero_grad(set_to_none=True)); the upstream weight stays on
+        # the device (float(g) was a host synchronisation in every iteration).
+        held = [p.grad if PlaneRegFunction.DIRECT_GRADS else None for p in planes]
+        in_place = [h is not None and _same_layout(h, p) and _dense(h) for h, p in zip(held, planes)]
+        key = (tuple(p.data_ptr() for p in planes), tuple(w_smooth), tuple(w_l1),
+               tuple(h.data_ptr() if ip else 0 for h, ip in zip(held, in_place)))
         c = PlaneRegFunction._cache
-        busy = c is not None and planes[0].grad is not None and planes[0].grad.data_ptr() == c[2][0].data_ptr()
+        busy = c is not None and any(h is not None and h.data_ptr() == v.data_ptr() for h, v in zip(held, c[2]))
         if c is None or c[0] != key or busy:
             flat = torch.zeros(sum(p.numel() for p in planes), dtype=torch.float32, device=planes[0].device)
             off, grads = 0, []
@@ -391,7 +398,8 @@ class PlaneRegFunction(torch.autograd.Function):
                 gv = flat[off:off + p.numel()].view(st.shape)
                 off += p.numel()
                 grads.append(gv.permute(2, 0, 1).unsqueeze(0))
-                arr[i].plane, arr[i].grad = st.data_ptr(), gv.data_ptr()
+                target = plane_storage(held[i]) if in_place[i] else gv
+                arr[i].plane, arr[i].grad = st.data_ptr(), target.data_ptr()
                 arr[i].H, arr[i].W = st.shape[0], st.shape[1]
                 arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), 1.0
             val = torch.empty(1, dtype=torch.float32, device=planes[0].device)
@@ -404,9 +412,18 @@ class PlaneRegFunction(torch.autograd.Function):
         up = g.detach().reshape(1).float()
         N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), N.current_stream()),
                 "mom_plane_regulation")
+        if PlaneRegFunction.DIRECT_GRADS:
+            for p, gp, ip in zip(planes, grads, in_place):
+                if not ip:
+                    if p.grad is None:
+                        p.grad = gp
+                    else:
+                        p.grad.add_(gp)
+            return (None, None) + (None,) * len(planes)
         return (None, None, *grads)
 
     _cache = None
+    DIRECT_GRADS = True
 
 
 def plane_regulation(planes, w_smooth, w_l1):
