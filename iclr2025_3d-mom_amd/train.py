@@ -135,10 +135,13 @@ class Trainer:
             radii_l.append(pkg["radii"].unsqueeze(0))
             vis_l.append(pkg["visibility_filter"].unsqueeze(0))
             vsp_l.append(pkg["viewspace_points"])
-        radii = torch.cat(radii_l, 0).max(dim=0).values
-        visibility = torch.cat(vis_l).any(dim=0)
-        image = torch.cat(images, 0)
-        gt = torch.cat(gts, 0)
+        if len(cams) == 1:      # a batch of one: the reference's cat / max / any over the batch dimension are identities
+            radii, visibility, image, gt = radii_l[0][0], vis_l[0][0], images[0], gts[0]
+        else:
+            radii = torch.cat(radii_l, 0).max(dim=0).values
+            visibility = torch.cat(vis_l).any(dim=0)
+            image = torch.cat(images, 0)
+            gt = torch.cat(gts, 0)
 
         Ll1 = l1_loss(image, gt[:, :3, :, :])
         loss = Ll1
