@@ -14,7 +14,7 @@ from .utils.loss_utils import l1_loss, psnr_from_last_l1, ssim
 
 class Trainer:
     def __init__(self, scene, gaussians, opt, hyper, pipe, stage="fine", delta_scale=1, white_background=False,
-                 sync_every_step=True, fused=False, gc_freeze=True):
+                 sync_every_step=True, fused=False, gc_freeze=False):
         self.scene, self.g, self.opt, self.hyper, self.pipe, self.stage = scene, gaussians, opt, hyper, pipe, stage
         self.delta_scale = delta_scale
         dev = gaussians._xyz.device
@@ -38,8 +38,9 @@ class Trainer:
         self._serial = 0
         self.replayed = 0    # iterations replayed after a binning overflow (diagnostics)
         if gc_freeze:
-            # Everything alive now -- the scene, its cameras, the model, torch itself -- stays for the whole run: move it out of
-            # the cyclic collector's reach.  Otherwise a full collection walks that heap every few hundred iterations and the
+            # (opt-in: a training script sets it once its scene and model exist; it is process-wide.)  Everything alive now --
+            # the scene, its cameras, the model, torch itself -- stays for the whole run: move it out of the cyclic collector's
+            # reach.  Otherwise a full collection walks that heap every few hundred iterations and the
             # training loop stands still for 100-150 ms each time (tools/probe/autograd_rate.py: 4.9 against 1.5 ms per
             # iteration over a 40-iteration window that contains one).
             import gc

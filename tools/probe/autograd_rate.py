@@ -3,7 +3,7 @@ synchronisation; if the enqueue alone takes as long as the whole, the host sets 
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
-scene, g, trainer, op = bench.build_state(bench.CONFIGS["c2"], torch.device("cuda"), fused=False)
+scene, g, trainer, op = bench.build_state(bench.CONFIGS["c2"], torch.device("cuda"), fused=False, gc_freeze=os.environ.get("GC") != "on")
 if os.environ.get("PER_OP") == "1":
     trainer.pipe.per_op_autograd = True
 DGR = __import__("importlib").import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
