@@ -244,6 +244,9 @@ class FusedRenderFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dcolor, ddepth, _dradii):
         st = ctx.st
+        if st is None:
+            raise RuntimeError("render(): a second backward through the same call -- its buffers were released after the first "
+                               "(render again, or set pipe.per_op_autograd = True for retain_graph use)")
         ctx.st = None                                  # the call's buffers go back to the allocator after this backward
         g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp, in_place = _backward(st, dcolor, ddepth)
         if DIRECT_GRADS:
