@@ -119,6 +119,11 @@ def _sig(lib):
     lib.mom_deform_backward_scratch_bytes.argtypes = [i32]
     lib.mom_deform_backward.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_deform_backward_split.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_deform_field_supported.argtypes = [C.POINTER(MomHexPlane)]
+    lib.mom_deform_field_scratch_bytes.restype = sz
+    lib.mom_deform_field_scratch_bytes.argtypes = [C.POINTER(MomHexPlane)]
+    lib.mom_deform_field_forward.argtypes = [C.POINTER(MomHexPlane), C.POINTER(MomDeformMLP), i32, vp, C.c_float, vp, vp, vp, vp,
+                                             C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_select_scratch_bytes.restype = sz
     lib.mom_select_scratch_bytes.argtypes = [i32]
@@ -164,6 +169,7 @@ EXPORTS = [
     "mom_ssim_forward_slab", "mom_ssim_backward_slab",
     "mom_hexplane_backward_scratch_bytes", "mom_hexplane_orders_scratch_bytes", "mom_hexplane_orders", "mom_image_to_rgb8",
     "mom_l1_loss_acc", "mom_plane_regulation_acc", "mom_plane_regulation_grad",
+    "mom_deform_field_supported", "mom_deform_field_scratch_bytes", "mom_deform_field_forward",
 ]
 
 

@@ -25,167 +25,10 @@
 // MFMA operands are plain coalesced 256-byte loads (lane = feature), every byte is read exactly once, the four
 // 64x64 results live in 256 accumulator registers for the wave's whole range, and the bias gradients fall out of
 // the A operands for free.  No atomics until one float atomic per weight per workgroup at the very end.
-#include "mom_common.h"
+#include "deform_mlp_dev.h"
 #include <stdlib.h>
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kHid = 64;
-constexpr int kWStride = 65;                         // LDS row stride of a weight matrix ([in][out])
-constexpr int kWFloats = kHid * kWStride;            // one layer
-constexpr int kStageStride = 33;                     // staging rows: [feature][32 gaussians + 1 pad]
-constexpr int kStageFloats = kHid * kStageStride + 4 * 32;       // sA | dout[32][4]
-constexpr int kDxWaves = 8;                          // waves per workgroup of the dx kernel (they share one copy of the weights)
-
-// LDS map (floats)
-constexpr int kLW = 0;                               // [4][64][65]
-constexpr int kLB = kLW + 4 * kWFloats;              // [4][64]
-constexpr int kLW2 = kLB + 4 * kHid;                 // [3][4][64] (rows >= nout are zero)
-constexpr int kLB2 = kLW2 + 3 * 4 * kHid;            // [3][4]
-constexpr int kLFwdTotal = kLB2 + 16;
-constexpr int kLStage = kLFwdTotal;                  // [kDxWaves][kStageFloats]   (backward only)
-constexpr int kLBwdTotal = kLStage + kDxWaves * kStageFloats;
-
-__device__ __forceinline__ int fmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-struct MlpDev {
-    const float *W0, *b0, *W1[3], *b1[3], *W2[3], *b2[3];
-    float *dW0, *db0, *dW1[3], *db1[3], *dW2[3], *db2[3];
-};
-
-// Cooperative load of all weights into LDS (any workgroup size that is a multiple of 64, at least 256).  The four 64x64
-// matrices are fetched as float4 and ALL of a thread's fetches are issued before its first LDS store: written as a plain
-// copy loop the prologue paid one memory latency per iteration (16 k cycles of the forward kernel's 150 k).
-__device__ __forceinline__ void load_weights(const MlpDev& m, float* __restrict__ lds)
-{
-    const int nth = (int)blockDim.x;
-    const float* Ws[4] = {m.W0, m.W1[0], m.W1[1], m.W1[2]};
-    const float* bs[4] = {m.b0, m.b1[0], m.b1[1], m.b1[2]};
-    constexpr int kQuads = 4 * kHid * kHid / 4, kMaxPer = kQuads / 256;      // 4096 float4 in all; <= 16 per thread
-    float4 v[kMaxPer];
-#pragma unroll
-    for (int j = 0; j < kMaxPer; j++) {
-        const int q = threadIdx.x + j * nth;                       // quad q: layer q >> 10, floats 4 (q & 1023) .. + 3 of it
-        if (q < kQuads) v[j] = reinterpret_cast<const float4*>(Ws[q >> 10])[q & 1023];
-    }
-    float bias = 0.f;                                              // workgroups have at least 4 * kHid = 256 threads
-    if (threadIdx.x < 4 * kHid) bias = bs[threadIdx.x >> 6][threadIdx.x & 63];
-#pragma unroll
-    for (int j = 0; j < kMaxPer; j++) {
-        const int q = threadIdx.x + j * nth;
-        if (q < kQuads) {
-            const int L = q >> 10, i = 4 * (q & 1023), o = i >> 6, k = i & 63;       // W[out][in] row-major -> lds[in][out], stride 65
-            float* d = lds + kLW + L * kWFloats + k * kWStride + o;
-            d[0] = v[j].x; d[kWStride] = v[j].y; d[2 * kWStride] = v[j].z; d[3 * kWStride] = v[j].w;
-        }
-    }
-    if (threadIdx.x < 4 * kHid) lds[kLB + threadIdx.x] = bias;
-    for (int i = threadIdx.x; i < 3 * 4 * kHid; i += nth) {
-        const int head = i >> 8, n = (i >> 6) & 3, f = i & 63;
-        const int nout = head == 2 ? 4 : 3;
-        lds[kLW2 + i] = n < nout ? m.W2[head][n * kHid + f] : 0.f;
-    }
-    if (threadIdx.x < 12) {
-        const int head = threadIdx.x >> 2, n = threadIdx.x & 3;
-        const int nout = head == 2 ? 4 : 3;
-        lds[kLB2 + threadIdx.x] = n < nout ? m.b2[head][n] : 0.f;
-    }
-}
-
-// out[mt] += sum_k A(mt,k) in[k].  TRANS=false: A = W (out = W in).  TRANS=true: A = W^T (din = W^T dout).
-template <bool TRANS>
-__device__ __forceinline__ void layer64(const float* __restrict__ Wl, const f32x16 (&in)[2], f32x16 (&out)[2], int col, int h)
-{
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int kt = 0; kt < 2; kt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int k = 32 * kt + fmap(r, h), mrow = 32 * mt + col;
-                const float a = TRANS ? Wl[mrow * kWStride + k] : Wl[k * kWStride + mrow];
-                out[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[kt][r], out[mt], 0, 0, 0);
-                if (r == 15) __builtin_amdgcn_sched_barrier(0);   // bound the scheduler's look-ahead (register budget)
-            }
-}
-
-__device__ __forceinline__ void init_bias(const float* __restrict__ b, f32x16 (&t)[2], int h)
-{
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) t[mt][r] = b[32 * mt + fmap(r, h)];
-}
-__device__ __forceinline__ void zero_tile(f32x16 (&t)[2])
-{
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) t[mt][r] = 0.f;
-}
-__device__ __forceinline__ void relu_tile(f32x16 (&t)[2])
-{
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) t[mt][r] = fmaxf(t[mt][r], 0.f);
-}
-
-// feat [P][64] row-major <-> T layout (lane = gaussian column, registers = features)
-__device__ __forceinline__ void load_feat(const float* __restrict__ feat, int g, bool ok, int h, f32x16 (&t)[2])
-{
-    const float* row = feat + (size_t)(ok ? g : 0) * kHid;
-#pragma unroll
-    for (int kt = 0; kt < 2; kt++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            float4 v = *reinterpret_cast<const float4*>(row + 32 * kt + 8 * q + 4 * h);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            t[kt][4 * q + 0] = v.x;
-            t[kt][4 * q + 1] = v.y;
-            t[kt][4 * q + 2] = v.z;
-            t[kt][4 * q + 3] = v.w;
-        }
-}
-__device__ __forceinline__ void store_feat(float* __restrict__ feat, int g, bool ok, int h, const f32x16 (&t)[2])
-{
-    if (!ok) return;
-    float* row = feat + (size_t)g * kHid;
-#pragma unroll
-    for (int kt = 0; kt < 2; kt++)
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            *reinterpret_cast<float4*>(row + 32 * kt + 8 * q + 4 * h) =
-                make_float4(t[kt][4 * q + 0], t[kt][4 * q + 1], t[kt][4 * q + 2], t[kt][4 * q + 3]);
-}
-
-// thin output layer on the VALU: o[n] = b2[n] + sum_f W2[n][f] a1[f]; the two lane halves hold complementary feature
-// subsets of the same gaussian, so they exchange partial sums
-__device__ __forceinline__ void out_layer(const float* __restrict__ W2l, const float* __restrict__ b2l, const f32x16 (&a1)[2], int h,
-                                          float (&o)[4])
-{
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-        float p = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float4 w = *reinterpret_cast<const float4*>(W2l + n * kHid + 32 * mt + 8 * q + 4 * h);
-                p += w.x * a1[mt][4 * q] + w.y * a1[mt][4 * q + 1] + w.z * a1[mt][4 * q + 2] + w.w * a1[mt][4 * q + 3];
-            }
-        o[n] = p + __shfl_xor(p, 32) + b2l[n];
-    }
-}
-
-// Optional activated copies of the forward's outputs (mom_deform_forward_activated): exp(scales), rots / |rots|,
-// sigmoid(opacity_raw) -- what mom_activations_forward computes from the stored outputs, without its launch.
-struct ActOut {
-    float *scales, *rots, *opacity;
-    const float* opacity_raw;
-};
 
 // All threads of a workgroup share ONE copy of the weights in LDS (70 KB).  With 256 threads two workgroups = 8 waves fit per
 // CU although the registers allow 16: a workgroup of up to 1024 threads gets up to 16 waves for the same LDS.
@@ -259,15 +102,6 @@ deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-// stage a T-layout tile as [feature][gaussian] rows
-__device__ __forceinline__ void stage_tile(float* __restrict__ s, const f32x16 (&t)[2], int col, int h)
-{
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[(32 * mt + fmap(r, h)) * kStageStride + col] = t[mt][r];
-}
-
 // (A) activations backward: dH for the four layers, d(features), output-layer weight gradients
 // 512 threads: two waves per SIMD share one copy of the weights (142 KB of LDS with the staging tiles), so that one wave's vector
 // and memory phases -- the thin output layers, the dH stores -- run under the other's MFMAs (4 waves: 288 us for dx + dW, 8: 276)
@@ -525,19 +359,6 @@ deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat,
 }
 
 }  // namespace
-
-static int fill_dev(const MomDeformMLP* w, MlpDev* d)
-{
-    if (!w || !w->W0 || !w->b0) return MOM_EINVAL;
-    d->W0 = w->W0; d->b0 = w->b0;
-    d->dW0 = w->dW0; d->db0 = w->db0;
-    for (int i = 0; i < 3; i++) {
-        if (!w->W1[i] || !w->b1[i] || !w->W2[i] || !w->b2[i]) return MOM_EINVAL;
-        d->W1[i] = w->W1[i]; d->b1[i] = w->b1[i]; d->W2[i] = w->W2[i]; d->b2[i] = w->b2[i];
-        d->dW1[i] = w->dW1[i]; d->db1[i] = w->db1[i]; d->dW2[i] = w->dW2[i]; d->db2[i] = w->db2[i];
-    }
-    return MOM_OK;
-}
 
 extern "C" int mom_deform_forward(const MomDeformMLP* w, int P, const float* feat, const float* xyz, const float* scaling,
                                   const float* rotation, const float* scene_flow, float flow_coef, float* pts, float* scales,

@@ -14,7 +14,7 @@
 // Arithmetic follows ATen's grid_sampler_2d (unnormalise with align_corners, clip to the
 // border, nw/ne/sw/se weights, accumulation order nw,ne,sw,se) so that results agree with the
 // reference's torch ops to rounding.
-#include "mom_common.h"
+#include "hexplane_dev.h"
 #include <stdlib.h>
 
 namespace {
@@ -26,24 +26,6 @@ struct PlaneSample {
     float ix, iy;
     int ixn, iyn;
 };
-
-__device__ __forceinline__ float unnorm_clip(float c, int size, float& gmul)
-{
-    // align_corners=True: ((c+1)/2)*(size-1); border: clip to [0, size-1] with zero gradient when clipped
-    float v = ((c + 1.f) / 2.f) * (float)(size - 1);
-    gmul = (float)(size - 1) / 2.f;
-    if (v <= 0.f) {
-        v = 0.f;
-        gmul = 0.f;
-    } else {
-        const float mx = (float)(size - 1);
-        if (v >= mx) {
-            v = mx;
-            gmul = 0.f;
-        }
-    }
-    return v;
-}
 
 __device__ __forceinline__ PlaneSample make_sample(float cx, float cy, int Wd, int Hd)
 {
@@ -64,27 +46,6 @@ __device__ __forceinline__ PlaneSample make_sample(float cx, float cy, int Wd, i
     s.i10 = (x0in && y1in) ? y1 * Wd + x0 : -1;
     s.i11 = (x1in && y1in) ? y1 * Wd + x1 : -1;
     return s;
-}
-
-struct HexArgs {
-    int P, levels;
-    int res[4][4];
-    const float* planes[4][6];
-    float* grads[4][6];
-    float a0[3], a1[3];  // aabb rows exactly as the reference stores them (row 0 = xyz_max, row 1 = xyz_min)
-    float time;
-    const float* times;  // optional per-point timestamps [P]; null -> `time` for every point
-    const uint32_t* order;  // optional processing order (a permutation of 0..P-1, e.g. Morton order); null -> identity
-};
-
-__constant__ int kCombA[6] = {0, 0, 0, 1, 1, 2};
-__constant__ int kCombB[6] = {1, 2, 3, 2, 3, 3};
-
-__device__ __forceinline__ void norm_coords(const HexArgs& a, const float* __restrict__ xyz, int g, float c[4])
-{
-#pragma unroll
-    for (int k = 0; k < 3; k++) c[k] = (xyz[3 * g + k] - a.a0[k]) * (2.0f / (a.a1[k] - a.a0[k])) - 1.0f;
-    c[3] = a.times ? a.times[g] : a.time;
 }
 
 // grid: one half-wave per (Gaussian, level); blockDim 256 = 8 half-waves
@@ -191,19 +152,6 @@ hexplane_bwd_kernel(HexArgs a, const float* __restrict__ xyz, const float* __res
     }
 }
 
-
-// ---- helpers shared by the chunked kernels -------------------------------------------------------------------
-__device__ __forceinline__ int time_sample(float c, int size, int& i0, int& i1, float& w0, float& w1)
-{
-    float gm;
-    const float v = unnorm_clip(c, size, gm);
-    const int x0 = (int)floorf(v), x1 = x0 + 1;
-    w0 = (float)x1 - v;
-    w1 = v - (float)x0;
-    i0 = (x0 >= 0 && x0 < size) ? x0 : -1;
-    i1 = (x1 >= 0 && x1 < size) ? x1 : -1;
-    return 0;
-}
 
 // =================================================================================================================
 // Chunked kernels: sample parameters are computed ONCE per (point, level) -- by one lane, in "phase A" of a chunk of
@@ -675,16 +623,6 @@ invert_perm_kernel(int n, const unsigned* __restrict__ order, unsigned* __restri
 // buffer pair that holds the result, or a negative MOM_E* code
 int mom_sort_pairs_u32(int n, int bits, unsigned* keys[2], unsigned* vals[2], unsigned* counts, hipStream_t s);
 size_t mom_sort_pairs_counts_bytes(int n);
-
-static void fill_args(const MomHexPlane* hp, int P, const float* times, float time, const uint32_t* order, bool grads, HexArgs* a)
-{
-    a->P = P; a->levels = hp->levels; a->time = time; a->times = times; a->order = order;
-    for (int l = 0; l < 4; l++)
-        for (int k = 0; k < 4; k++) a->res[l][k] = hp->res[l][k];
-    for (int l = 0; l < 4; l++)
-        for (int p = 0; p < 6; p++) { a->planes[l][p] = hp->planes[l][p]; a->grads[l][p] = grads ? hp->grads[l][p] : nullptr; }
-    for (int k = 0; k < 3; k++) { a->a0[k] = hp->aabb[k]; a->a1[k] = hp->aabb[3 + k]; }
-}
 
 extern "C" int mom_hexplane_forward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
                                     const uint32_t* order, float* feat, mom_stream_t stream)

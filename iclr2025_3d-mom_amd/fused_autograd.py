@@ -100,12 +100,8 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
     st.geom = torch.empty(lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
     st.img = torch.empty(lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
     hp, keep, md = _forward_desc(pc, field, st.planes, st.mlp)
-    optr = None if st.order is None else st.order.data_ptr()
-    N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, st.cam_time, optr, st.feat.data_ptr(), s), "hexplane_fwd")
-    N.check(lib.mom_deform_forward_activated(C.byref(md), P, st.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rotq.data_ptr(),
-                                             flow.data_ptr(), st.coef, st.pts.data_ptr(), st.sc_d.data_ptr(), st.rot_d.data_ptr(),
-                                             st.a0.data_ptr(), opac.data_ptr(), st.sc.data_ptr(), st.rot.data_ptr(), st.op.data_ptr(), s),
-            "deform_fwd")
+    ops.field_forward(hp, md, P, xyz, st.cam_time, st.order, scal, rotq, flow, st.coef, st.pts, st.sc_d, st.rot_d, st.feat, st.a0,
+                      opac, st.sc, st.rot, st.op, s)
     a = st.a = N.MomRasterArgs()
     a.P, a.D, a.M, a.W, a.H = P, pc.active_sh_degree, 16, W, H
     a.background, a.means3D = bg.data_ptr(), st.pts.data_ptr()

@@ -86,12 +86,8 @@ class FusedRender:
             md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], None)
             self._desc, self._desc_key = (hp, keep, md), dkey
         hp, keep, md = self._desc
-        N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, float(cam.time),
-                                         None if order is None else order.data_ptr(), self.feat.data_ptr(), s), "hexplane_fwd")
-        N.check(lib.mom_deform_forward_activated(C.byref(md), P, self.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
-                                                 flow.data_ptr(), float(delta_scale * cam.frame_num), self.pts.data_ptr(),
-                                                 self.sc_d.data_ptr(), self.rot_d.data_ptr(), None, opac.data_ptr(),
-                                                 self.sc.data_ptr(), self.rot.data_ptr(), self.op.data_ptr(), s), "deform_fwd")
+        ops.field_forward(hp, md, P, xyz, float(cam.time), order, scal, rot, flow, float(delta_scale * cam.frame_num), self.pts,
+                          self.sc_d, self.rot_d, None, None, opac, self.sc, self.rot, self.op, s, scratch_feat=self.feat)
         a = N.MomRasterArgs()
         a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H
         a.background, a.means3D = bg.data_ptr(), self.pts.data_ptr()

@@ -162,13 +162,10 @@ class FusedStep:
             self._desc = (hp, keep, md)
             self._desc_key, self._reg_arr = dkey, None
         hp, keep, md = self._desc
-        N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.feat.data_ptr(), s), "hexplane_fwd")
         coef = float(delta_scale * cam.frame_num)
-        # the activations (exp / normalize / sigmoid) ride in the MLP kernel's epilogue
-        N.check(lib.mom_deform_forward_activated(C.byref(md), P, self.feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
-                                                 flow.data_ptr(), coef, self.pts.data_ptr(), self.sc_d.data_ptr(),
-                                                 self.rot_d.data_ptr(), self.a0.data_ptr(), opac.data_ptr(), self.sc.data_ptr(),
-                                                 self.rot.data_ptr(), self.op.data_ptr(), s), "deform_fwd")
+        # HexPlane lookup + MLP + the activations (exp / normalize / sigmoid) in one kernel (csrc/deform_field.hip)
+        ops.field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, self.pts, self.sc_d, self.rot_d, self.feat, self.a0,
+                          opac, self.sc, self.rot, self.op, s)
         # ---- rasterizer forward (async: capacity from the previous iterations, checked below)
         a = N.MomRasterArgs()
         a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H

@@ -146,6 +146,44 @@ def morton_order(xyz):
     return order
 
 
+# --------------------------------------------------------------------------- deformation field in one pass
+import os as _os
+
+FUSE_FIELD = _os.environ.get("MOM_FUSE_FIELD", "1") != "0"     # HexPlane lookup fused into the MLP kernels (csrc/deform_field.hip)
+FIELD_ORDER = _os.environ.get("MOM_FIELD_ORDER", "1") != "0"   # the fused kernels walk the Morton order (else the index order)
+_field_scratch = {}
+
+
+def field_scratch(hp, device):
+    """The per-frame table of time lines of the fused deformation kernels (73 KB at the shipped resolutions), one per device."""
+    n = N.lib().mom_deform_field_scratch_bytes(C.byref(hp))
+    t = _field_scratch.get(device)
+    if t is None or t.numel() < n:
+        t = _field_scratch[device] = torch.empty(n, dtype=torch.uint8, device=device)
+    return t
+
+
+def field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, pts, sc_d, rot_d, feat, a0, opac, sc, rot_act, op, s,
+                  scratch_feat=None):
+    """deform_network.forward for one timestamp: the fused kernel when the field's shape allows it, else HexPlane + MLP.
+    feat / a0: [P,64] tensors that receive the features and relu(h0) for the backward, or None (no backward follows; the
+    two-kernel path then needs `scratch_feat` for the features)."""
+    lib = N.lib()
+    q = lambda t: None if t is None else t.data_ptr()
+    if FUSE_FIELD and lib.mom_deform_field_supported(C.byref(hp)):
+        N.check(lib.mom_deform_field_forward(C.byref(hp), C.byref(md), P, xyz.data_ptr(), float(time),
+                                             q(order) if FIELD_ORDER else None, scal.data_ptr(),
+                                             rot.data_ptr(), flow.data_ptr(), float(coef), pts.data_ptr(), sc_d.data_ptr(),
+                                             rot_d.data_ptr(), q(feat), q(a0), q(opac), q(sc), q(rot_act), q(op),
+                                             field_scratch(hp, xyz.device).data_ptr(), s), "deform_field_fwd")
+        return
+    f = feat if feat is not None else scratch_feat
+    N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, float(time), q(order), f.data_ptr(), s), "hexplane_fwd")
+    N.check(lib.mom_deform_forward_activated(C.byref(md), P, f.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                             flow.data_ptr(), float(coef), pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), q(a0),
+                                             q(opac), q(sc), q(rot_act), q(op), s), "deform_fwd")
+
+
 # --------------------------------------------------------------------------- fused deformation MLP
 class DeformMLPFunction(torch.autograd.Function):
     """(pts, scales, rots) = fused trunk + pos/scales/rotations heads + residual adds

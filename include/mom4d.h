@@ -376,6 +376,22 @@ int mom_deform_backward_split(const MomDeformMLP* w, int P, const float* feat, c
                               const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream,
                               mom_stream_t dw_stream);
 
+/* ---- deformation field in one pass (the render() case: ONE timestamp for every point) ----
+ * deform_network.forward = HexPlaneField lookup + trunk + heads (scene/deformation.py:97-153, scene/hexplane.py:160-183) as a
+ * single persistent kernel: the 64 features of a tile of 32 Gaussians go from the texel gathers through LDS straight into the
+ * matrix-core operand, feat[P,64] crosses HBM only if the caller asks for a copy (feat_save, for the backward's weight
+ * gradients).  The three space-time planes are first collapsed to per-frame lines (one tiny launch into `scratch`,
+ * mom_deform_field_scratch_bytes).  Same outputs and activated copies as mom_hexplane_forward + mom_deform_forward_activated;
+ * `order` (optional) is the processing order as in mom_hexplane_forward.  Needs levels == 2, channels == 32 and resolutions
+ * <= 1024 (mom_deform_field_supported); other shapes take the two separate calls. */
+int mom_deform_field_supported(const MomHexPlane* hp);
+size_t mom_deform_field_scratch_bytes(const MomHexPlane* hp);
+int mom_deform_field_forward(const MomHexPlane* hp, const MomDeformMLP* w, int P, const float* xyz, float time,
+                             const uint32_t* order, const float* scaling, const float* rotation, const float* scene_flow,
+                             float flow_coef, float* pts, float* scales, float* rots, float* feat_save, float* a0_save,
+                             const float* opacity_raw, float* scales_act, float* rots_act, float* opacity_act, void* scratch,
+                             mom_stream_t stream);
+
 /* ---- rendered image -> 8-bit interleaved RGB (render_4DGS.py:64 torchvision.utils.save_image: x * 255 + 0.5, clamp, truncate;
  * CHW -> HWC) in one pass, so that a frame can leave the device as the bytes a PNG encoder takes.  img [C,H,W] floats, out [H,W,C]
  * bytes; C <= 4. */

@@ -1,0 +1,125 @@
+"""The deformation field in one pass (csrc/deform_field.hip: HexPlane lookup fused into the MLP kernels, space-time planes
+collapsed to per-frame lines) against the two-kernel path it replaces and against the oracle's torch-op sequence
+(oracle/torch_ref.py = 12 grid_sample + nn.Linear, reference scene/hexplane.py:73-106,160-183, scene/deformation.py:97-153)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as tr
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module("iclr2025_3d-mom_amd.ops")
+N = importlib.import_module("iclr2025_3d-mom_amd._native")
+HexPlaneField = importlib.import_module("iclr2025_3d-mom_amd.scene.hexplane").HexPlaneField
+
+
+def _field(res, seed=0):
+    torch.manual_seed(seed)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 4, 'output_coordinate_dim': 32, 'resolution': list(res)}
+    f = HexPlaneField(1.6, cfg, [1, 2])
+    f.set_aabb([1.0, 1.2, 1.4], [-1.0, -1.2, -1.4])
+    with torch.no_grad():
+        for g in f.grids:
+            for p in g:
+                p.add_(torch.randn_like(p) * 0.2)
+    return f
+
+
+def _points(n, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    pts = (torch.rand(n, 3, generator=g) * 2 - 1) * torch.tensor([1.1, 1.3, 1.5])   # some outside the box (border clipping)
+    pts[0] = torch.tensor([1.0, 1.2, 1.4])      # exact corners
+    pts[1] = torch.tensor([-1.0, -1.2, -1.4])
+    return pts
+
+
+def _mlp(seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: (torch.randn(*s, generator=g) * 0.3)
+    params = [mk(64, 64), mk(64)]
+    for nout in (3, 3, 4):
+        params += [mk(64, 64), mk(64), mk(nout, 64), mk(nout)]
+    return params, mk
+
+
+def _run_forward(f, params, P, xyz, scal, rot, flow, opac, t, order, fused):
+    lib, s = N.lib(), N.current_stream()
+    hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in f.grids], f.aabb, None, aabb_host=f.aabb_host())
+    md = ops.DeformMLPFunction._desc(params)
+    e = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+    out = dict(pts=e(P, 3), sc_d=e(P, 3), rot_d=e(P, 4), feat=e(P, 64), a0=e(P, 64), sc=e(P, 3), rot=e(P, 4), op=e(P, 1))
+    old = ops.FUSE_FIELD
+    ops.FUSE_FIELD = fused
+    try:
+        ops.field_forward(hp, md, P, xyz, t, order, scal, rot, flow, 0.7, out["pts"], out["sc_d"], out["rot_d"], out["feat"],
+                          out["a0"], opac, out["sc"], out["rot"], out["op"], s)
+    finally:
+        ops.FUSE_FIELD = old
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("res,P,t", [((64, 64, 64, 25), 5003, 0.37), ((8, 8, 8, 5), 257, 0.0), ((16, 12, 10, 7), 33, 1.0),
+                                     ((64, 64, 64, 150), 20000, 0.9931)])
+@pytest.mark.parametrize("with_order", [False, True])
+def test_fused_forward_equals_the_two_kernel_path_and_the_oracle(res, P, t, with_order):
+    f = _field(res)
+    params_cpu, mk = _mlp(P)
+    xyz = _points(P)
+    scal, rot, flow, opac = mk(P, 3), mk(P, 4), mk(P, 3), mk(P, 1)
+    fg = f.cuda()
+    params = [p.cuda() for p in params_cpu]
+    cu = [t_.cuda() for t_ in (xyz, scal, rot, flow, opac)]
+    order = ops.morton_order(cu[0]) if with_order else None
+    a = _run_forward(fg, params, P, *cu, t, order, fused=True)
+    b = _run_forward(fg, params, P, *cu, t, order, fused=False)
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+    # the lines reassociate the time planes' bilinear sums: features agree to a few ulp of their scale
+    fs = float(b["feat"].abs().max())
+    assert float((a["feat"] - b["feat"]).abs().max()) <= 2e-6 * max(1.0, fs)
+    for k in ("pts", "sc_d", "rot_d", "sc", "rot", "op"):
+        np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # a0 = relu(h0): a unit within rounding of 0 may take the other branch; everything else agrees
+    d = (a["a0"] - b["a0"]).abs()
+    assert float(d.max()) <= 5e-5 * max(1.0, float(b["a0"].abs().max()))
+    # oracle: the reference's torch ops on the CPU
+    feat_ref = tr.hexplane_features(xyz, t, f.aabb.detach().cpu(), [[p.detach().cpu().contiguous() for p in g] for g in f.grids])
+    np.testing.assert_allclose(a["feat"].cpu().numpy(), feat_ref.numpy(), rtol=2e-5, atol=5e-6)
+    o_ref = tr.deform_mlp(feat_ref, xyz, scal, rot, flow, 0.7, params_cpu)
+    for k, r in zip(("pts", "sc_d", "rot_d"), o_ref):
+        np.testing.assert_allclose(a[k].cpu().numpy(), r.numpy(), rtol=2e-5, atol=3e-5)
+    np.testing.assert_allclose(a["sc"].cpu().numpy(), torch.exp(o_ref[1]).numpy(), rtol=3e-5, atol=1e-6)
+    np.testing.assert_allclose(a["rot"].cpu().numpy(), torch.nn.functional.normalize(o_ref[2]).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(a["op"].cpu().numpy(), torch.sigmoid(opac).numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_fused_forward_without_saved_tensors_and_refusals():
+    """feat_save / a0_save are optional (no-grad render()); unsupported shapes are reported, not mis-rendered."""
+    f = _field((64, 64, 64, 25)).cuda()
+    P = 777
+    params_cpu, mk = _mlp(3)
+    params = [p.cuda() for p in params_cpu]
+    xyz, scal, rot, flow, opac = (t_.cuda() for t_ in (_points(P), mk(P, 3), mk(P, 4), mk(P, 3), mk(P, 1)))
+    lib, s = N.lib(), N.current_stream()
+    hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in f.grids], f.aabb, None, aabb_host=f.aabb_host())
+    md = ops.DeformMLPFunction._desc(params)
+    ref = _run_forward(f, params, P, xyz, scal, rot, flow, opac, 0.5, None, fused=True)
+    pts, sc_d, rot_d = (torch.empty(P, k, device="cuda") for k in (3, 3, 4))
+    scratch = ops.field_scratch(hp, xyz.device)
+    N.check(lib.mom_deform_field_forward(C.byref(hp), C.byref(md), P, xyz.data_ptr(), 0.5, None, scal.data_ptr(), rot.data_ptr(),
+                                         flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), None, None, None,
+                                         None, None, None, scratch.data_ptr(), s), "fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(pts, ref["pts"]) and torch.equal(sc_d, ref["sc_d"]) and torch.equal(rot_d, ref["rot_d"])
+    assert lib.mom_deform_field_forward(C.byref(hp), C.byref(md), P, xyz.data_ptr(), 0.5, None, scal.data_ptr(), rot.data_ptr(),
+                                        flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), None, None, None,
+                                        None, None, None, None, s) == N.MOM_EINVAL          # no scratch
+    three = HexPlaneField(1.6, {'grid_dimensions': 2, 'input_coordinate_dim': 4, 'output_coordinate_dim': 32,
+                                'resolution': [8, 8, 8, 5]}, [1, 2, 4]).cuda()
+    hp3, keep3 = ops._hexplane_desc([[p.detach() for p in lv] for lv in three.grids], three.aabb, None, aabb_host=three.aabb_host())
+    assert lib.mom_deform_field_supported(C.byref(hp3)) == 0 and lib.mom_deform_field_supported(C.byref(hp)) == 1
