@@ -26,9 +26,30 @@ namespace {
 constexpr int kTileStride = 68;                      // B-operand tile rows: [32 gaussians][64 features + 4]: 16-byte aligned, conflict-free
 constexpr int kTileFloats = 32 * kTileStride;
 constexpr int kRecDw = 8;                            // dwords of one (point, level) record
-constexpr int kWaveFloats = kTileFloats + 64 * kRecDw;
-constexpr int kFieldWaves = 8;                       // waves per workgroup: two per SIMD (one gathers while the other multiplies)
-constexpr int kLFieldTotal = kLFwdTotal + kFieldWaves * kWaveFloats;
+constexpr int kBufFloats = kTileFloats + 64 * kRecDw;   // one gather wave's buffer: the tile + its records
+#ifndef MOM_FIELD_PRIO
+#define MOM_FIELD_PRIO 2
+#endif
+#ifndef MOM_FIELD_PIPE
+#define MOM_FIELD_PIPE 0
+#endif
+#ifndef MOM_FIELD_NG
+#define MOM_FIELD_NG 2
+#endif
+#ifndef MOM_FIELD_DEPTH
+#define MOM_FIELD_DEPTH 1
+#endif
+#ifndef MOM_FIELD_NM
+#define MOM_FIELD_NM 1
+#endif
+constexpr int kNG = MOM_FIELD_NG;                    // gather waves per SIMD
+constexpr int kNM = MOM_FIELD_NM;                    // MFMA waves per SIMD: they take the SIMD's tiles in turn
+constexpr int kMfmaGroup = (kNM + kNG) >= 4 ? 8 : 16;   // A-fragment prefetch depth (registers)
+constexpr int kNB = kNG > kNM ? kNG : kNM;           // tile buffers per SIMD
+constexpr int kFieldWaves = 4 * (kNM + kNG);
+constexpr int kLFlags = kLFwdTotal;                  // [4 SIMDs][kNG][2] ints: tiles published / tiles consumed
+constexpr int kLBufs = kLFlags + 32;
+constexpr int kLFieldTotal = kLBufs + 4 * kNB * kBufFloats;
 
 struct LineTab {
     unsigned off[4][3];                              // float offset of line (level, axis) inside the table
@@ -62,43 +83,41 @@ struct WeightRegs {
 };
 // load_weights of deform_mlp_dev.h in two halves, so that the gather of a wave's first tile runs while the 70 KB of weights
 // are in flight (256 CUs pull the same lines out of L2 at once: 16 k cycles when waited for on the spot)
-__device__ __forceinline__ void weights_issue(const MlpDev& m, WeightRegs& w)
+__device__ __forceinline__ void weights_issue(const MlpDev& m, WeightRegs& w, int tid, int nth)
 {
-    const int nth = (int)blockDim.x;
     const float* Ws[4] = {m.W0, m.W1[0], m.W1[1], m.W1[2]};
     const float* bs[4] = {m.b0, m.b1[0], m.b1[1], m.b1[2]};
     constexpr int kQuads = 4 * kHid * kHid / 4;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const int q = threadIdx.x + j * nth;
+        const int q = tid + j * nth;
         if (q < kQuads) w.v[j] = reinterpret_cast<const float4*>(Ws[q >> 10])[q & 1023];
     }
     w.bias = 0.f;
-    if (threadIdx.x < 4 * kHid) w.bias = bs[threadIdx.x >> 6][threadIdx.x & 63];
+    if (tid < 4 * kHid) w.bias = bs[tid >> 6][tid & 63];
 }
-__device__ __forceinline__ void weights_commit(const MlpDev& m, const WeightRegs& w, float* __restrict__ lds)
+__device__ __forceinline__ void weights_commit(const MlpDev& m, const WeightRegs& w, float* __restrict__ lds, int tid, int nth)
 {
-    const int nth = (int)blockDim.x;
     constexpr int kQuads = 4 * kHid * kHid / 4;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const int q = threadIdx.x + j * nth;
+        const int q = tid + j * nth;
         if (q < kQuads) {
             const int L = q >> 10, i = 4 * (q & 1023), o = i >> 6, k = i & 63;
             float* d = lds + kLW + L * kWFloats + k * kWStride + o;
             d[0] = w.v[j].x; d[kWStride] = w.v[j].y; d[2 * kWStride] = w.v[j].z; d[3 * kWStride] = w.v[j].w;
         }
     }
-    if (threadIdx.x < 4 * kHid) lds[kLB + threadIdx.x] = w.bias;
-    for (int i = threadIdx.x; i < 3 * 4 * kHid; i += nth) {
+    if (tid < 4 * kHid) lds[kLB + tid] = w.bias;
+    for (int i = tid; i < 3 * 4 * kHid; i += nth) {
         const int head = i >> 8, n = (i >> 6) & 3, f = i & 63;
         const int nout = head == 2 ? 4 : 3;
         lds[kLW2 + i] = n < nout ? m.W2[head][n * kHid + f] : 0.f;
     }
-    if (threadIdx.x < 12) {
-        const int head = threadIdx.x >> 2, n = threadIdx.x & 3;
+    if (tid < 12) {
+        const int head = tid >> 2, n = tid & 3;
         const int nout = head == 2 ? 4 : 3;
-        lds[kLB2 + threadIdx.x] = n < nout ? m.b2[head][n] : 0.f;
+        lds[kLB2 + tid] = n < nout ? m.b2[head][n] : 0.f;
     }
 }
 
@@ -140,25 +159,17 @@ __device__ __forceinline__ void make_record(const HexArgs& a, const float* __res
     R1 = make_float4(b[0], b[1], b[2], 0.f);
 }
 
-// one space plane: four corner rows of 16 bytes per lane, ATen's accumulation order nw, ne, sw, se
-__device__ __forceinline__ float4 sample_space(const float* __restrict__ pl, unsigned o, unsigned sx, unsigned sy, float ax, float bx,
-                                               float ay, float by)
-{
-    const float4 t00 = ld4(pl, o), t01 = ld4(pl, o + sx), t10 = ld4(pl, o + sy), t11 = ld4(pl, o + sx + sy);
-    float4 v = mul4(t00, ax * ay);
-    v = fma4(t01, bx * ay, v);
-    v = fma4(t10, ax * by, v);
-    v = fma4(t11, bx * by, v);
-    return v;
-}
-__device__ __forceinline__ float4 sample_line(const float* __restrict__ ln, unsigned o, unsigned s, float a, float b)
-{
-    const float4 l0 = ld4(ln, o), l1 = ld4(ln, o + s);
-    return fma4(l1, b, mul4(l0, a));
-}
+// The 18 texel rows (16 bytes per lane each) of one (point, level) in flight, with what finishing them needs.
+struct UnitLoads {
+    float4 t[18];          // (x,y) nw ne sw se | (x,z) | (y,z) | line x: r0 r1 | line y | line z
+    float bx, by, bz;
+    int gl;
+};
 
 // Gather the 64 features of the tile's 32 Gaussians into `tile` ([gaussian][kTileStride]) and, optionally, into feat[P][64].
-// g_mine: the Gaussian of lane (lane & 31) (or -1 past the end).
+// g_mine: the Gaussian of lane (lane & 31) (or -1 past the end).  Eight lanes work on one (point, level); the eight units of a
+// pass are software pipelined two deep: the loads of unit u + 2 are issued as soon as unit u's registers are free, so two
+// memory round trips are always in flight (issued one unit at a time and waited for on the spot, a tile took 34-41 k cycles).
 __device__ __forceinline__ void gather_tile(const HexArgs& a, const LineTab& lt, const float* __restrict__ lines,
                                             const float* __restrict__ xyz, int g_mine, float* __restrict__ tile,
                                             uint4* __restrict__ rec, float* __restrict__ feat_save, int lane)
@@ -173,46 +184,77 @@ __device__ __forceinline__ void gather_tile(const HexArgs& a, const LineTab& lt,
         rec[2 * lane + 1] = make_uint4(__float_as_uint(R1.x), __float_as_uint(R1.y), __float_as_uint(R1.z), 0u);
     }
     __builtin_amdgcn_wave_barrier();
-    // phase B: eight lanes per unit; four iterations per level
+    // phase B: eight lanes per unit; pass u = 4 lvl + i covers the gaussians 8 i .. 8 i + 7 of the tile at level lvl
     const int g8 = lane >> 3, c = lane & 7;
     const unsigned cb = (unsigned)c * 16u;
-#pragma unroll 1
-    for (int lvl = 0; lvl < 2; lvl++) {
+    auto issue = [&](int u, UnitLoads& L) {
+        const int lvl = u >> 2, gl = 8 * (u & 3) + g8;
+        const uint4 R0 = rec[2 * (32 * lvl + gl)];
+        const uint4 R1u = rec[2 * (32 * lvl + gl) + 1];
+        L.bx = __uint_as_float(R1u.x); L.by = __uint_as_float(R1u.y); L.bz = __uint_as_float(R1u.z);
+        L.gl = gl;
         const unsigned rowx = (unsigned)a.res[lvl][0] * 128u, rowy = (unsigned)a.res[lvl][1] * 128u;
+        const unsigned sx = (R0.x & 1u) ? 128u : 0u, sy = (R0.x & 2u) ? 128u : 0u, sz = (R0.y & 2u) ? 128u : 0u;
+        const unsigned ry_x = (R0.x & 2u) ? rowx : 0u, rz_x = (R0.y & 2u) ? rowx : 0u, rz_y = (R0.y & 2u) ? rowy : 0u;
+        const unsigned x0 = R0.w & 1023u, y0 = (R0.w >> 10) & 1023u, z0 = R0.w >> 20;
         const float* __restrict__ pxy = a.planes[lvl][0];
         const float* __restrict__ pxz = a.planes[lvl][1];
         const float* __restrict__ pyz = a.planes[lvl][3];
+        const unsigned oxy = (R0.x & ~127u) + cb, oxz = (R0.y & ~127u) + cb, oyz = (R0.z & ~127u) + cb;
+        L.t[0] = ld4(pxy, oxy); L.t[1] = ld4(pxy, oxy + sx); L.t[2] = ld4(pxy, oxy + ry_x); L.t[3] = ld4(pxy, oxy + sx + ry_x);
+        L.t[4] = ld4(pxz, oxz); L.t[5] = ld4(pxz, oxz + sx); L.t[6] = ld4(pxz, oxz + rz_x); L.t[7] = ld4(pxz, oxz + sx + rz_x);
+        L.t[8] = ld4(pyz, oyz); L.t[9] = ld4(pyz, oyz + sy); L.t[10] = ld4(pyz, oyz + rz_y); L.t[11] = ld4(pyz, oyz + sy + rz_y);
         const float* __restrict__ lx = lines + lt.off[lvl][0];
         const float* __restrict__ ly = lines + lt.off[lvl][1];
         const float* __restrict__ lz = lines + lt.off[lvl][2];
-#pragma unroll 2
-        for (int i = 0; i < 4; i++) {
-            const int gl = 8 * i + g8;                           // gaussian of the tile this lane works on
-            const uint4 R0 = rec[2 * (32 * lvl + gl)];
-            const uint4 R1u = rec[2 * (32 * lvl + gl) + 1];
-            const float bx = __uint_as_float(R1u.x), by = __uint_as_float(R1u.y), bz = __uint_as_float(R1u.z);
-            const float ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
-            const unsigned sx = (R0.x & 1u) ? 128u : 0u, sy = (R0.x & 2u) ? 128u : 0u, sz = (R0.y & 2u) ? 128u : 0u;
-            const unsigned x0 = R0.w & 1023u, y0 = (R0.w >> 10) & 1023u, z0 = R0.w >> 20;
-            // reference order of the product: (x,y) (x,z) (x,t) (y,z) (y,t) (z,t)
-            const float4 vxy = sample_space(pxy, (R0.x & ~127u) + cb, sx, (R0.x & 2u) ? rowx : 0u, ax, bx, ay, by);
-            const float4 vxz = sample_space(pxz, (R0.y & ~127u) + cb, sx, (R0.y & 2u) ? rowx : 0u, ax, bx, az, bz);
-            const float4 vxt = sample_line(lx, x0 * 128u + cb, sx, ax, bx);
-            const float4 vyz = sample_space(pyz, (R0.z & ~127u) + cb, sy, (R0.y & 2u) ? rowy : 0u, ay, by, az, bz);
-            const float4 vyt = sample_line(ly, y0 * 128u + cb, sy, ay, by);
-            const float4 vzt = sample_line(lz, z0 * 128u + cb, sz, az, bz);
-            float4 f = mul44(vxy, vxz);                          // 1 * v0 * v1 ... in the reference's order
-            f = mul44(f, vxt);
-            f = mul44(f, vyz);
-            f = mul44(f, vyt);
-            f = mul44(f, vzt);
-            *reinterpret_cast<float4*>(tile + gl * kTileStride + 32 * lvl + 4 * c) = f;
-            if (feat_save) {
-                const int g = __shfl(g_mine, gl);
-                if (g >= 0) *reinterpret_cast<float4*>(feat_save + (size_t)g * kHid + 32 * lvl + 4 * c) = f;
-            }
+        L.t[12] = ld4(lx, x0 * 128u + cb); L.t[13] = ld4(lx, x0 * 128u + cb + sx);
+        L.t[14] = ld4(ly, y0 * 128u + cb); L.t[15] = ld4(ly, y0 * 128u + cb + sy);
+        L.t[16] = ld4(lz, z0 * 128u + cb); L.t[17] = ld4(lz, z0 * 128u + cb + sz);
+    };
+    auto space = [&](const float4* t, float a0, float b0, float a1, float b1) {      // ATen's order nw, ne, sw, se
+        float4 v = mul4(t[0], a0 * a1);
+        v = fma4(t[1], b0 * a1, v);
+        v = fma4(t[2], a0 * b1, v);
+        v = fma4(t[3], b0 * b1, v);
+        return v;
+    };
+    auto finish = [&](int u, const UnitLoads& L) {
+        const int lvl = u >> 2;
+        const float bx = L.bx, by = L.by, bz = L.bz, ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
+        // reference order of the product: (x,y) (x,z) (x,t) (y,z) (y,t) (z,t)
+        float4 f = mul44(space(L.t, ax, bx, ay, by), space(L.t + 4, ax, bx, az, bz));
+        f = mul44(f, fma4(L.t[13], bx, mul4(L.t[12], ax)));
+        f = mul44(f, space(L.t + 8, ay, by, az, bz));
+        f = mul44(f, fma4(L.t[15], by, mul4(L.t[14], ay)));
+        f = mul44(f, fma4(L.t[17], bz, mul4(L.t[16], az)));
+        if (tile) *reinterpret_cast<float4*>(tile + L.gl * kTileStride + 32 * lvl + 4 * c) = f;
+        if (feat_save) {
+            const int g = __shfl(g_mine, L.gl);
+            if (g >= 0) *reinterpret_cast<float4*>(feat_save + (size_t)g * kHid + 32 * lvl + 4 * c) = f;
         }
+    };
+#ifdef MOM_FIELD_NOGATHER
+    if (lane >= 0) { __builtin_amdgcn_wave_barrier(); return; }   // probe build: the MLP alone (tiles hold the records' leftovers)
+#endif
+#if MOM_FIELD_DEPTH == 2
+    UnitLoads LA, LB;
+    issue(0, LA);
+    issue(1, LB);
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+        finish(u, LA);
+        if (u + 2 < 8) issue(u + 2, LA);
+        finish(u + 1, LB);
+        if (u + 3 < 8) issue(u + 3, LB);
     }
+#else
+#pragma unroll 1
+    for (int u = 0; u < 8; u++) {        // one pass in flight per wave (128 registers: two gather waves per SIMD make up for it)
+        UnitLoads LA;
+        issue(u, LA);
+        finish(u, LA);
+    }
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -231,6 +273,24 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ tile, int co
         }
 }
 
+#ifdef MOM_FIELD_STAMPS
+__device__ unsigned long long g_field_dbg[256 * 32 * 4];
+#define STAMP() __builtin_amdgcn_s_memtime()
+#else
+#define STAMP() 0ull
+#endif
+__device__ __forceinline__ void flag_wait(const int* f, int need)
+{
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+}
+__device__ __forceinline__ void flag_set(int* f, int v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Waves specialise.  Waves 0..3 (one per SIMD) run the MLP of their SIMD's tiles on the matrix pipe and never wait for memory;
+// waves 4.. (kNG per SIMD) gather: each owns one tile buffer in LDS, fills it for its next tile while the MFMA wave works through
+// the previous one, and hands it over through two counters in LDS (tiles published / tiles consumed).  The MFMA wave frees a
+// buffer as soon as the tile sits in its registers, so the gather has a whole tile's MFMA time (16 k cycles) for the next one.
+// Run as ONE program per wave (gather a tile, then multiply it) the two waves of a SIMD moved in lockstep -- all gathering, then
+// all queueing for the matrix pipe -- and the kernel took the sum of the two phases (120 us); so did the two separate kernels.
 __global__ void __launch_bounds__(64 * kFieldWaves)
 deform_field_fwd_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float* __restrict__ lines, const float* __restrict__ xyz,
                         const float* __restrict__ scaling, const float* __restrict__ rotation, const float* __restrict__ flow,
@@ -239,77 +299,184 @@ deform_field_fwd_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float*
 {
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    float* tile = lds + kLFieldTotal - (wv + 1) * kWaveFloats;
-    uint4* rec = reinterpret_cast<uint4*>(tile + kTileFloats);
     const int P = a.P;
     const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
-    const int t_first = t_begin + wv, t_step = kFieldWaves;
+    int* flags = reinterpret_cast<int*>(lds + kLFlags);
+    if (threadIdx.x < 32) flags[threadIdx.x] = 0;
     auto gaussian_of = [&](int t) {
         const int gi = t * 32 + col;
         return gi < P ? (a.order ? (int)a.order[gi] : gi) : -1;
     };
+    const bool mfma_wave = wv < 4 * kNM;
+    const int simd = wv & 3, gj = mfma_wave ? wv >> 2 : (wv - 4 * kNM) >> 2;      // waves w, w + 4, w + 8 share a SIMD (speed only)
     WeightRegs wr;
-    weights_issue(m, wr);
-    int g = -1;
-    if (t_first < t_end) {
-        g = gaussian_of(t_first);
-        gather_tile(a, lt, lines, xyz, g, tile, rec, feat_save, lane);
+    if (mfma_wave) weights_issue(m, wr, (int)threadIdx.x, 256 * kNM);
+    __syncthreads();                                                   // the flags are zero
+    if (!mfma_wave) {
+        // the SIMD's k-th tile (tile t_begin + simd + 4 k) goes through buffer k % kNB; gather wave gj fills k = gj, gj + kNG, ...
+        unsigned long long tw = 0, tg = 0, t00 = STAMP();
+        int n_done = 0;
+        for (int k = gj; t_begin + simd + 4 * k < t_end; k += kNG, n_done++) {
+            const int t = t_begin + simd + 4 * k, j = k % kNB, n = k / kNB;
+            float* tile = lds + kLBufs + (simd * kNB + j) * kBufFloats;
+            uint4* rec = reinterpret_cast<uint4*>(tile + kTileFloats);
+            int* f_ready = flags + (simd * kNB + j) * 2, *f_free = f_ready + 1;
+            const int g = gaussian_of(t);
+            const unsigned long long s0 = STAMP();
+            flag_wait(f_free, n);                                      // the buffer's previous tile sits in an MFMA wave's registers
+            const unsigned long long s1 = STAMP();
+            gather_tile(a, lt, lines, xyz, g, tile, rec, feat_save, lane);
+            flag_set(f_ready, n + 1);
+            const unsigned long long s2 = STAMP();
+            tw += s1 - s0; tg += s2 - s1;
+        }
+#ifdef MOM_FIELD_STAMPS
+        if (lane == 0) {
+            unsigned long long* d = g_field_dbg + ((size_t)blockIdx.x * 32 + wv) * 4;
+            d[0] = tw; d[1] = tg; d[2] = STAMP() - t00; d[3] = n_done;
+        }
+#endif
+        return;
     }
-    weights_commit(m, wr, lds);
-    __syncthreads();
-    for (int t = t_first; t < t_end; t += t_step) {
+    __builtin_amdgcn_s_setprio(MOM_FIELD_PRIO);     // the matrix wave's few vector / LDS instructions go ahead of the gather waves' many
+    weights_commit(m, wr, lds, (int)threadIdx.x, 256 * kNM);
+    // only the four MFMA waves read the weights: a barrier among them (the gather waves never come here)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add(flags + 31, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    flag_wait(flags + 31, 4 * kNM);
+    int k = 0;
+    unsigned long long tw = 0, t00 = STAMP(), tpro = 0, tl = 0, tm = 0, to = 0;
+    // MFMA wave gj of the SIMD takes the SIMD's tiles k = gj, gj + kNM, ...: while one wave is between its MFMA phases (bias,
+    // ReLU, output layers, stores) the other's MFMAs keep the pipe busy
+    for (k = gj; t_begin + simd + 4 * k < t_end; k += kNM) {
+        const int t = t_begin + simd + 4 * k;
+        const int j = k % kNB, n = k / kNB;
+        const float* tile = lds + kLBufs + (simd * kNB + j) * kBufFloats;
+        int* f_ready = flags + (simd * kNB + j) * 2, *f_free = f_ready + 1;
+        const int g = gaussian_of(t);
         const bool ok = g >= 0;
+        // this Gaussian's inputs of the residual adds: requested now, used after the heads (a load issued where it is used costs
+        // this wave -- alone on its SIMD -- the whole memory latency, three times per tile)
+        float in_xyz[3] = {0.f, 0.f, 0.f}, in_flow[3] = {0.f, 0.f, 0.f}, in_scal[3] = {0.f, 0.f, 0.f}, in_opac = 0.f;
+        float4 in_rot = make_float4(0.f, 0.f, 0.f, 0.f);
+        constexpr bool kPrefetchIn = kNM == 1;     // with a second MFMA wave on the SIMD the loads are issued where they are used
+        if (kPrefetchIn && h == 0 && ok) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                in_xyz[q] = xyz[3 * g + q];
+                in_flow[q] = flow[3 * g + q];
+                in_scal[q] = scaling[3 * g + q];
+            }
+            in_rot = *reinterpret_cast<const float4*>(rotation + 4 * g);
+            if (act.opacity) in_opac = act.opacity_raw[g];
+        }
         f32x16 a0[2];
         {
             f32x16 x[2];
+            const unsigned long long s0 = STAMP();
+            flag_wait(f_ready, n + 1);
+            tw += STAMP() - s0;
+            if (k == gj) tpro = STAMP() - t00;
             load_tile(tile, col, h, x);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the tile is in registers: its buffer is free again
+            flag_set(f_free, n + 1);
+#ifdef MOM_FIELD_NOMLP
+            if (x[0][0] != 12345.678f) continue;     // probe build: the gather alone
+#endif
             init_bias(lds + kLB, a0, h);
-            layer64<false>(lds + kLW, x, a0, col, h);
+            const unsigned long long s1 = STAMP();
+            layer64p<false, kMfmaGroup>(lds + kLW, x, a0, col, h);
+            tl += STAMP() - s1;
         }
         relu_tile(a0);
         if (a0_save) store_feat(a0_save, g, ok, h, a0);
+        // Heads.  MOM_FIELD_PIPE: software pipelined -- the thin output layer of head k rides between the MFMAs of head k + 1's hidden
+        // layer (for a wave that is ALONE on its SIMD; it needs two hidden tiles in registers).  With two MFMA waves per SIMD the
+        // other wave's MFMAs fill those gaps and the plain order is used.
+        f32x16 hcur[2];
+#if MOM_FIELD_PIPE
+        init_bias(lds + kLB + kHid, hcur, h);
+        const unsigned long long s2 = STAMP();
+        layer64p<false>(lds + kLW + kWFloats, a0, hcur, col, h);
+        relu_tile(hcur);
+        tm += STAMP() - s2;
+#endif
+#if MOM_FIELD_PIPE
+#pragma unroll
+#else
 #pragma nounroll
+#endif
         for (int head = 0; head < 3; head++) {
-            f32x16 h1[2];
-            init_bias(lds + kLB + (1 + head) * kHid, h1, h);
-            layer64<false>(lds + kLW + (1 + head) * kWFloats, a0, h1, col, h);
-            relu_tile(h1);
             float o[4];
-            out_layer(lds + kLW2 + head * 4 * kHid, lds + kLB2 + head * 4, h1, h, o);
+            const unsigned long long s3 = STAMP();
+#if MOM_FIELD_PIPE
+            if (head < 2) {
+                f32x16 hn[2];
+                float p[4] = {0.f, 0.f, 0.f, 0.f};
+                init_bias(lds + kLB + (2 + head) * kHid, hn, h);
+                layer64p_fill<false>(lds + kLW + (2 + head) * kWFloats, a0, hn, col, h, lds + kLW2 + head * 4 * kHid, hcur, p);
+                out_finish(lds + kLB2 + head * 4, p, o);
+                relu_tile(hn);
+                hcur[0] = hn[0];
+                hcur[1] = hn[1];
+            } else {
+                out_layer(lds + kLW2 + head * 4 * kHid, lds + kLB2 + head * 4, hcur, h, o);
+            }
+#else
+            init_bias(lds + kLB + (1 + head) * kHid, hcur, h);
+            layer64p<false, kMfmaGroup>(lds + kLW + (1 + head) * kWFloats, a0, hcur, col, h);
+            tm += STAMP() - s3;
+            relu_tile(hcur);
+            out_layer(lds + kLW2 + head * 4 * kHid, lds + kLB2 + head * 4, hcur, h, o);
+#endif
+            to += STAMP() - s3;
             if (h == 0 && ok) {
+                if (!kPrefetchIn) {
+                    if (head == 0) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) { in_xyz[q] = xyz[3 * g + q]; in_flow[q] = flow[3 * g + q]; }
+                    } else if (head == 1) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) in_scal[q] = scaling[3 * g + q];
+                    } else {
+                        in_rot = *reinterpret_cast<const float4*>(rotation + 4 * g);
+                        if (act.opacity) in_opac = act.opacity_raw[g];
+                    }
+                }
                 if (head == 0) {
 #pragma unroll
-                    for (int k = 0; k < 3; k++) pts[3 * g + k] = xyz[3 * g + k] + (o[k] + flow_coef * flow[3 * g + k]);
+                    for (int q = 0; q < 3; q++) pts[3 * g + q] = in_xyz[q] + (o[q] + flow_coef * in_flow[q]);
                 } else if (head == 1) {
-                    float s3[3];
+                    float s3v[3];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        s3[k] = scaling[3 * g + k] + o[k];
-                        scales[3 * g + k] = s3[k];
+                    for (int q = 0; q < 3; q++) {
+                        s3v[q] = in_scal[q] + o[q];
+                        scales[3 * g + q] = s3v[q];
                     }
                     if (act.scales) {
 #pragma unroll
-                        for (int k = 0; k < 3; k++) act.scales[3 * g + k] = expf(s3[k]);
+                        for (int q = 0; q < 3; q++) act.scales[3 * g + q] = expf(s3v[q]);
                     }
                 } else {
-                    float4 q = *reinterpret_cast<const float4*>(rotation + 4 * g);
-                    q = make_float4(q.x + o[0], q.y + o[1], q.z + o[2], q.w + o[3]);
-                    *reinterpret_cast<float4*>(rots + 4 * g) = q;
+                    const float4 q4 = make_float4(in_rot.x + o[0], in_rot.y + o[1], in_rot.z + o[2], in_rot.w + o[3]);
+                    *reinterpret_cast<float4*>(rots + 4 * g) = q4;
                     if (act.rots) {
-                        const float n = mom_quat_norm(q.x, q.y, q.z, q.w);
-                        *reinterpret_cast<float4*>(act.rots + 4 * g) = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+                        const float nq = mom_quat_norm(q4.x, q4.y, q4.z, q4.w);
+                        *reinterpret_cast<float4*>(act.rots + 4 * g) = make_float4(q4.x / nq, q4.y / nq, q4.z / nq, q4.w / nq);
                     }
-                    if (act.opacity) act.opacity[g] = mom_sigmoid(act.opacity_raw[g]);
+                    if (act.opacity) act.opacity[g] = mom_sigmoid(in_opac);
                 }
             }
         }
-        // next tile's features (the other wave of this SIMD is somewhere in its MFMAs meanwhile)
-        const int tn = t + t_step;
-        if (tn < t_end) {
-            g = gaussian_of(tn);
-            gather_tile(a, lt, lines, xyz, g, tile, rec, feat_save, lane);
-        }
     }
+#ifdef MOM_FIELD_STAMPS
+    if (lane == 0) {
+        unsigned long long* d = g_field_dbg + ((size_t)blockIdx.x * 32 + wv) * 4;
+        d[0] = tw; d[1] = tpro; d[2] = STAMP() - t00; d[3] = k;
+        unsigned long long* e = g_field_dbg + ((size_t)blockIdx.x * 32 + 16 + wv) * 4;
+        e[0] = tl; e[1] = tm; e[2] = to; e[3] = 0;
+    }
+#endif
 }
 
 }  // namespace
@@ -372,8 +539,9 @@ extern "C" int mom_deform_field_forward(const MomHexPlane* hp, const MomDeformML
     MomProfScope ps(MOM_P_HEX_FWD, s);
     hipLaunchKernelGGL(hexplane_lines_kernel, dim3((nline + 255) / 256), dim3(256), 0, s, a, lt, lines, nline);
     const int tiles = (P + 31) / 32;
-    // one workgroup per CU (the weights and eight B-operand tiles fill its LDS); a small problem is spread over the CUs
-    const int blocks = tiles < 256 * kFieldWaves ? (tiles + kFieldWaves - 1) / kFieldWaves : 256;
+    const ActOut act = {scales_act, rots_act, opacity_act, opacity_raw};
+    // one workgroup per CU (MFMA waves fed by gather waves); a small problem is spread over the CUs
+    const int blocks = tiles < 256 * 4 ? (tiles + 3) / 4 : 256;
     static bool attr_set = false;
     const size_t lds_bytes = sizeof(float) * kLFieldTotal;
     if (!attr_set) {
@@ -382,8 +550,15 @@ extern "C" int mom_deform_field_forward(const MomHexPlane* hp, const MomDeformML
             return MOM_ELAUNCH;
         attr_set = true;
     }
-    const ActOut act = {scales_act, rots_act, opacity_act, opacity_raw};
     hipLaunchKernelGGL(deform_field_fwd_kernel, dim3(blocks), dim3(64 * kFieldWaves), lds_bytes, s, a, lt, d, tiles, lines, xyz, scaling,
                        rotation, scene_flow, flow_coef, pts, scales, rots, feat_save, a0_save, act);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
+
+#ifdef MOM_FIELD_STAMPS
+// diagnostic build only: per-wave cycle stamps of the last forward launch ([256 workgroups][16 waves][4])
+extern "C" int mom_debug_field_stamps(unsigned long long* host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_field_dbg), sizeof(unsigned long long) * 256 * 32 * 4) == hipSuccess ? 0 : -2;
+}
+#endif

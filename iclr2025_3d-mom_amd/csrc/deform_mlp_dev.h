@@ -86,6 +86,95 @@ __device__ __forceinline__ void layer64(const float* __restrict__ Wl, const f32x
             }
 }
 
+// The same layer with the A fragments (weights, from LDS) of the NEXT group of 16 MFMAs requested before the current group is
+// issued.  layer64 leaves the order to the compiler, which reads two weights, waits for them and issues two MFMAs: a wave that
+// is alone on its SIMD then pays an LDS round trip per pair of MFMAs (29.7 k cycles per tile of 256 MFMAs, where the matrix pipe
+// needs 16.4 k: in-kernel stamps of deform_field_fwd_kernel).  With other waves of the same program on the SIMD that wait is
+// hidden by their MFMAs, which is why the multi-wave kernels of deform_mlp.hip do not need this form.
+template <bool TRANS, int G = 16>
+__device__ __forceinline__ void layer64p(const float* __restrict__ Wl, const f32x16 (&in)[2], f32x16 (&out)[2], int col, int h)
+{
+    // groups of G = 16 or 8 MFMAs, two fragment buffers of G registers
+    float a[2][G];
+    constexpr int kGroups = 64 / G, kPer = 16 / G;    // groups in all; groups per 16 k-steps of one (mt, kt) block
+    auto fetch = [&](int grp, float (&dst)[G]) {
+        const int blk = grp / kPer, mt = blk >> 1, kt = blk & 1, r0 = G * (grp % kPer);
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            const int k = 32 * kt + fmap(r0 + r, h), mrow = 32 * mt + col;
+            dst[r] = TRANS ? Wl[mrow * kWStride + k] : Wl[k * kWStride + mrow];
+        }
+    };
+    fetch(0, a[0]);
+#pragma unroll
+    for (int grp = 0; grp < kGroups; grp++) {
+        const int blk = grp / kPer, mt = blk >> 1, kt = blk & 1, r0 = G * (grp % kPer);
+        if (grp + 1 < kGroups) fetch(grp + 1, a[(grp + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);            // the next group's reads stay above this group's MFMAs
+#pragma unroll
+        for (int r = 0; r < G; r++) out[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][r], in[kt][r0 + r], out[mt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// layer64p with the PREVIOUS head's thin output layer (p[n] += sum_f W2[n][f] hp[f], 32 pieces of one 16-byte LDS read + 4 FMAs)
+// spread between the MFMAs: a wave that is alone on its SIMD has nothing else to put into the 64 cycles an MFMA occupies the
+// pipe, and run after the layer the output layer costs 1.6 k cycles per head (stamps).  The caller adds the cross-half exchange
+// and the bias (out_finish).
+template <bool TRANS>
+__device__ __forceinline__ void layer64p_fill(const float* __restrict__ Wl, const f32x16 (&in)[2], f32x16 (&out)[2], int col, int h,
+                                              const float* __restrict__ W2l, const f32x16 (&hp)[2], float (&p)[4])
+{
+    // A fragments in groups of EIGHT here (two buffers of 8 registers): the two hidden tiles of the pipelined heads leave no room
+    // for two buffers of 16 under the 168 registers of a 768-thread workgroup
+    float a[2][8];
+    auto fetch = [&](int grp, float (&dst)[8]) {      // grp 0..7: (mt, kt, half of the 16 k-steps)
+        const int mt = grp >> 2, kt = (grp >> 1) & 1, r0 = 8 * (grp & 1);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int k = 32 * kt + fmap(r0 + r, h), mrow = 32 * mt + col;
+            dst[r] = TRANS ? Wl[mrow * kWStride + k] : Wl[k * kWStride + mrow];
+        }
+    };
+    auto piece_w = [&](int s) {      // piece s: output s >> 3, features 32 ((s >> 2) & 1) + 8 (s & 3) + 4 h .. + 3
+        return *reinterpret_cast<const float4*>(W2l + (s >> 3) * kHid + 32 * ((s >> 2) & 1) + 8 * (s & 3) + 4 * h);
+    };
+    fetch(0, a[0]);
+    float4 w[2];
+    w[0] = piece_w(0);
+#pragma unroll
+    for (int grp = 0; grp < 8; grp++) {
+        const int mt = grp >> 2, kt = (grp >> 1) & 1, r0 = 8 * (grp & 1);
+        if (grp + 1 < 8) fetch(grp + 1, a[(grp + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            out[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[grp & 1][r], in[kt][r0 + r], out[mt], 0, 0, 0);
+            if ((r & 1) == 0) {
+                const int s = grp * 4 + (r >> 1), pm = (s >> 2) & 1, pq = s & 3;
+                if (s + 1 < 32) w[(s + 1) & 1] = piece_w(s + 1);
+                const float4 ww = w[s & 1];
+                p[s >> 3] += ww.x * hp[pm][4 * pq] + ww.y * hp[pm][4 * pq + 1] + ww.z * hp[pm][4 * pq + 2] + ww.w * hp[pm][4 * pq + 3];
+            }
+        }
+        // order inside the group: MFMA, one LDS read, four vector instructions, MFMA, MFMA, ...
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if ((r & 1) == 0) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+__device__ __forceinline__ void out_finish(const float* __restrict__ b2l, const float (&p)[4], float (&o)[4])
+{
+#pragma unroll
+    for (int n = 0; n < 4; n++) o[n] = p[n] + __shfl_xor(p[n], 32) + b2l[n];
+}
+
 __device__ __forceinline__ void init_bias(const float* __restrict__ b, f32x16 (&t)[2], int h)
 {
 #pragma unroll
