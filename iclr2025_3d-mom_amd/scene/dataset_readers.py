@@ -55,11 +55,14 @@ class SceneInfo(NamedTuple):
 
 
 def getNerfppNorm(cam_info):
-    """Centre and 1.1 x radius of the camera positions (dataset_readers.py:62-83)."""
+    """Centre and 1.1 x radius of the camera positions (dataset_readers.py:62-83).  The reference's dtypes are kept -- the
+    world-to-view matrices are float32, so the centres, their mean, the distances and `diagonal * 1.1` are float32 arithmetic
+    (under NumPy 2's promotion rules the product stays float32): the radius becomes spatial_lr_scale, and fixture g12 pins it
+    to the last bit."""
     centres = np.hstack([np.linalg.inv(getWorld2View2(c.R, c.T))[:3, 3:4] for c in cam_info])
-    centre = centres.mean(axis=1, keepdims=True)
-    radius = float(np.linalg.norm(centres - centre, axis=0).max()) * 1.1
-    return {"translate": -centre.flatten(), "radius": radius}
+    centre = np.mean(centres, axis=1, keepdims=True)
+    diagonal = np.max(np.linalg.norm(centres - centre, axis=0, keepdims=True))
+    return {"translate": -centre.flatten(), "radius": diagonal * 1.1}
 
 
 def frame_timeline(num_frames):

@@ -279,3 +279,77 @@ def test_g9_side_render_trajectory():
         np.testing.assert_allclose(cams[i].T, d["t"][i], atol=1e-8)
         np.testing.assert_array_equal(cams[i].R, d["R"][i])
         assert cams[i].frame_num == i and abs(cams[i].time - i / 59) < 1e-12
+
+
+def _rebuild_stage1_dir(d, root):
+    """The stage-1 directory the fixture g12 was generated on, from the arrays the fixture holds."""
+    from PIL import Image
+    mom = os.path.join(root, "MOM")
+    os.makedirs(os.path.join(mom, "video"))
+    data = {"camera_angle_x": float(d["camera_angle_x"]), "camera_angle_y": float(d["camera_angle_y"]), "W": int(d["W"]),
+            "H": int(d["H"]), "pcd_points": d["pcd_points"], "pcd_colors": d["pcd_colors"], "pcd_masks": d["pcd_masks"], "frames": []}
+    for i in range(int(d["n_frames"])):
+        img = d[f"frame{i}_image"]
+        data["frames"].append({"image": Image.fromarray(img, "RGBA" if img.shape[2] == 4 else "RGB"),
+                               "transform_matrix": d[f"frame{i}_c2w"].tolist()})
+    for i, n in enumerate(d["video_names"]):
+        Image.fromarray(d[f"video{i}"]).save(os.path.join(mom, "video", str(n)))
+    path = os.path.join(mom, "train_data.pth")
+    torch.save(data, path)
+    torch.save(torch.from_numpy(d["scene_flow"]), os.path.join(mom, "scene_flow.pth"))
+    return path
+
+
+@pytest.mark.parametrize("ev", [False, True])
+def test_g12_stage1_reader_matches_the_references_own_reader(tmp_path, ev):
+    """f4: scene/dataset_readers.readNerfSyntheticInfo and Scene.__init__'s call of it against what the REFERENCE's reader
+    (scene/dataset_readers.py:1160-1202, called as scene/__init__.py:52 calls it) made of the same stage-1 directory -- cameras of
+    every list (pose, field of view, time, frame number, size, uid), images (incl. the RGBA frame, whose compositing background is
+    args.eval through the reference's shifted positional arguments: SURVEY section 5, known defect 1), point cloud, time line,
+    maxtime and the normalisation radius that becomes spatial_lr_scale."""
+    d = np.load(os.path.join(G, "g12_stage1_reader.npz"))
+    path = _rebuild_stage1_dir(d, str(tmp_path))
+    scene_pkg = importlib.import_module("iclr2025_3d-mom_amd.scene")
+    dr = importlib.import_module("iclr2025_3d-mom_amd.scene.dataset_readers")
+    stage1 = importlib.import_module("iclr2025_3d-mom_amd.scene.stage1")
+    assert stage1.check_stage1_dir(str(tmp_path)) == (d["pcd_points"].shape[1], int(d["n_frames"]), len(d["video_names"]))
+    # exactly the reference's call: six positional arguments (source_path, white_background, eval, viewcrafter, extension)
+    info, time_line = dr.sceneLoadTypeCallbacks["Blender"](path, "unused_source_path", False, ev, False, ".png")
+    tag = "eval1" if ev else "eval0"
+    np.testing.assert_array_equal(np.asarray(time_line), d[f"{tag}_time_line"])
+    assert float(info.maxtime) == float(d[f"{tag}_maxtime"])
+    np.testing.assert_allclose(info.nerf_normalization["radius"], float(d[f"{tag}_radius"]), rtol=1e-12)
+    np.testing.assert_allclose(info.nerf_normalization["translate"], d[f"{tag}_translate"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_array_equal(np.asarray(info.point_cloud.points), d[f"{tag}_points"])
+    np.testing.assert_array_equal(np.asarray(info.point_cloud.colors), d[f"{tag}_colors"])
+    for lname in ("train_cameras", "train_cameras_2", "test_cameras", "video_cameras_up", "video_cameras_side", "video_cameras_zoom",
+                  "video_cameras_circle"):
+        cams = getattr(info, lname)
+        assert len(cams) == int(d[f"{tag}_{lname}_n"]), lname
+        np.testing.assert_allclose(np.stack([np.asarray(c.R, np.float64) for c in cams]), d[f"{tag}_{lname}_R"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.stack([np.asarray(c.T, np.float64) for c in cams]), d[f"{tag}_{lname}_T"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.array([[c.FovX, c.FovY] for c in cams]), d[f"{tag}_{lname}_fov"], rtol=1e-14)
+        np.testing.assert_array_equal(np.array([float(c.time) for c in cams]), d[f"{tag}_{lname}_time"])
+        np.testing.assert_array_equal(np.array([int(c.frame_num) for c in cams]), d[f"{tag}_{lname}_frame_num"])
+        np.testing.assert_array_equal(np.array([int(c.uid) for c in cams]), d[f"{tag}_{lname}_uid"])
+        np.testing.assert_array_equal(np.array([[int(c.width), int(c.height)] for c in cams]), d[f"{tag}_{lname}_wh"])
+        for k, i in enumerate(d[f"{tag}_{lname}_img_idx"]):
+            np.testing.assert_array_equal(np.asarray(cams[int(i)].image, np.float32), d[f"{tag}_{lname}_img"][k], err_msg=f"{lname}[{i}]")
+    # the RGBA frame really depends on the flag the defect routes into white_background
+    a, b = d["eval0_train_cameras_img"][1], d["eval1_train_cameras_img"][1]
+    assert np.abs(a - b).max() > 0.1
+    # Scene.__init__ passes its arguments in the reference's (shifted) order
+    args = argparse.Namespace(source_path="unused", white_background=not ev, eval=ev, extension=".png", add_points=False)
+    seen = {}
+    orig = scene_pkg.sceneLoadTypeCallbacks["Blender"]
+
+    def spy(*a, **k):
+        seen["args"] = a
+        raise StopIteration
+    scene_pkg.sceneLoadTypeCallbacks["Blender"] = spy
+    try:
+        with pytest.raises(StopIteration):
+            scene_pkg.Scene(path, "unused_model", args, gaussians=None)
+    finally:
+        scene_pkg.sceneLoadTypeCallbacks["Blender"] = orig
+    assert seen["args"] == (path, "unused", (not ev), ev, False, ".png")
