@@ -179,6 +179,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MomError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+        # torch first: it brings its own copy of the HIP runtime (torch/lib/libamdhip64.so), and libmom4d must bind to THAT copy --
+        # loaded before torch, libmom4d pulls in /opt/rocm's runtime, the process then holds two, and every launch on one of
+        # torch's streams fails (seen as "HIP launch/runtime failure" in smoke() when build() had loaded the library first)
+        import torch  # noqa: F401
         _lib = _sig(C.CDLL(LIB_PATH))
     return _lib
 

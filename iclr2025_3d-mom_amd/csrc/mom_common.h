@@ -167,7 +167,12 @@ __device__ __forceinline__ float mom_edge_max(float fixed, float lo, float hi, f
     // Contraction off: the tile histogram and the tile scatter must take the same decision for the same (splat, tile).
 #pragma clang fp contract(off)
     const float t = fminf(fmaxf(-b * fixed * inv_q_free, lo), hi);
-    return -0.5f * (q_fixed * fixed * fixed + q_free * t * t) - b * fixed * t;
+    // The three terms can be large and cancel (a long thin splat hundreds of pixels away: each ~1e5, sum ~ -5): the fp32 error
+    // of the sum scales with their magnitude, not with the result, so the returned maximum is raised by a bound on that error
+    // (a few ulp of the summed magnitudes) on top of the caller's absolute margin -- the cull stays on the safe side for any
+    // anisotropy.
+    const float p = q_fixed * fixed * fixed, q = q_free * t * t, r = b * fixed * t;
+    return (-0.5f * (p + q) - r) + 1e-6f * (0.5f * (p + q) + fabsf(r));
 }
 // centre (cx, cy), conic (a, b, c), bound = mom_power_bound(opacity), inv_a = 1/a, inv_c = 1/c (hardware reciprocals are
 // enough); pixel centres xa..xb by ya..yb.  The caller has checked a > 0 and c > 0.

@@ -4,9 +4,13 @@ same three functions, same argument order, same return tuples -- backed by libmo
 
 Differences a caller can observe, all documented in INTEGRATION.md:
 * the byte buffers' internal layout is private to libmom4d;
-* `num_rendered` is the instance CAPACITY of the binning buffer; it equals the true
-  instance count in the default "exact" mode (one host sync per forward, like the
-  reference's cudaMemcpy at rasterizer_impl.cu:282) and is an upper bound in "async" mode.
+* `num_rendered` (the first return value of rasterize_gaussians, rasterize_points.cu:35-117): in the default "exact" mode
+  -- one host sync per forward, like the reference's cudaMemcpy at rasterizer_impl.cu:282 -- it is the TRUE number of
+  instances this forward binned: the reference's count bit for bit under set_keep_all_tiles(True), and that count less the
+  (splat, tile) pairs that cannot reach alpha >= 1/255 under the default tile cull (images and gradients are identical
+  either way).  Only in the opt-in "async" mode (set_sync_mode) is it the CAPACITY the binning buffer was sized for, an
+  upper bound of the count; the backward takes whichever of the two the forward returned.  This is the one place where the
+  boundary's integer contract deviates, and only on request.
 """
 from __future__ import annotations
 
@@ -18,8 +22,19 @@ from .. import _native as N
 
 from collections import deque
 
-_state = {"mode": "exact", "cap_hint": 0, "last_R": None, "flag": None, "pending": deque(), "keep_all_tiles": False}
+_state = {"mode": "exact", "cap_hint": 0, "last_R": None, "flag": None, "pending": deque(), "keep_all_tiles": False,
+          "serial": 0, "verified": 0}
 _FLAG_LAG = 4
+
+
+class BinningOverflow(RuntimeError):
+    """An async-mode forward did not fit its binning buffer.  `serial`: the number of that forward (async forwards are counted from
+    1 in _state["serial"]); every forward before it is known to be complete, it and every later one were truncated and -- where
+    FusedAdam.skip_flag / the statistics kernel were given overflow_flag() -- left the model untouched."""
+
+    def __init__(self, msg, serial):
+        super().__init__(msg)
+        self.serial = serial
 
 
 _PIN_RING = 256
@@ -50,16 +65,20 @@ def overflow_flag(device):
 def _check_overflow(lag):
     q = _state["pending"]
     while len(q) > lag:
-        ev, host, count = q.popleft()
+        ev, host, count, serial = q.popleft()
         ev.synchronize()
-        if int(host[0]) & 1:
+        if not (int(host[0]) & 1):
+            _state["verified"] = serial
+            continue
+        if True:
             q.clear()
+            torch.cuda.current_stream().synchronize()      # nothing that still tests the word is in flight when it is cleared
             _state["flag"].zero_()
             _state["cap_hint"] = max(_state["cap_hint"], int(count[0]) * 2)
-            raise RuntimeError("libmom4d: an async-mode forward overflowed its binning capacity (instance count "
+            raise BinningOverflow("libmom4d: an async-mode forward overflowed its binning capacity (instance count "
                                f"{int(count[0])}); its image and every image since were truncated.  Optimizer steps were skipped "
                                "on the device from that forward on if FusedAdam.skip_flag is overflow_flag(); the capacity "
-                               "hint has been doubled -- repeat those iterations, or use set_sync_mode('exact')")
+                               "hint has been doubled -- repeat those iterations, or use set_sync_mode('exact')", serial)
 
 
 def set_sync_mode(mode: str, capacity_hint: int = 0) -> None:
@@ -148,9 +167,13 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     nr_host = pinned_word()
     N.check(lib.mom_raster_forward_geometry(C.byref(a), geom.data_ptr(), img.data_ptr(), radii.data_ptr(),
                                             nr_dev.data_ptr(), nr_host.data_ptr(), stream), "mom_raster_forward_geometry")
-    if _state["mode"] == "exact":
+    # async with nothing to size from (no hint, no earlier frame): this one forward waits for its count, like exact mode
+    blind = _state["mode"] == "async" and _state["cap_hint"] == 0 and _state["last_R"] is None
+    if _state["mode"] == "exact" or blind:
         torch.cuda.current_stream().synchronize()
         cap = int(nr_host[0])
+        if blind:
+            _state["cap_hint"] = int(cap * 1.5) + 4096
     else:
         flag = overflow_flag(dev)
         _check_overflow(_FLAG_LAG)
@@ -162,14 +185,15 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, cap),), dtype=torch.uint8, device=dev)
     N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
                                           out_color.data_ptr(), out_depth.data_ptr(),
-                                          flag.data_ptr() if _state["mode"] == "async" else None, stream),
+                                          flag.data_ptr() if (_state["mode"] == "async" and not blind) else None, stream),
             "mom_raster_forward_render")
-    if _state["mode"] == "async":
+    if _state["mode"] == "async" and not blind:
         status_host = pinned_word()
         status_host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        _state["pending"].append((ev, status_host, nr_host))
+        _state["serial"] += 1
+        _state["pending"].append((ev, status_host, nr_host, _state["serial"]))
     del keep
     return cap, out_color, out_depth, radii, geom, binning, img
 

@@ -23,7 +23,22 @@ from . import ops
 from .diff_gaussian_rasterization import _C as RC
 
 
-DIRECT_GRADS = True      # False: return the parameter gradients through the autograd graph (hooks on the parameters then fire)
+DIRECT_GRADS = True      # False: always return the parameter gradients through the autograd graph
+
+
+class grads_through_graph:
+    """Context manager: render() and the regulariser return their parameter gradients to the autograd engine instead of writing
+    p.grad themselves.  Needed around torch.autograd.grad() (which must not touch .grad and expects the gradients back); hooks,
+    frozen parameters and backward(inputs=...) are detected and need nothing (ops.direct_grads_ok)."""
+
+    def __enter__(self):
+        global DIRECT_GRADS
+        self._old = (DIRECT_GRADS, ops.PlaneRegFunction.DIRECT_GRADS)
+        DIRECT_GRADS = ops.PlaneRegFunction.DIRECT_GRADS = False
+
+    def __exit__(self, *a):
+        global DIRECT_GRADS
+        DIRECT_GRADS, ops.PlaneRegFunction.DIRECT_GRADS = self._old
 
 
 class _State:
@@ -112,6 +127,7 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
     a.scale_modifier = float(scaling_modifier)
     a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
     a.prefiltered, a.debug = 0, int(bool(debug))
+    a.keep_all_tiles = int(RC._state["keep_all_tiles"])       # set_keep_all_tiles(): the reference's lists and num_rendered
     st.keep = (bg, view, proj, campos, keep)
     nr_dev = torch.empty(1, dtype=torch.int32, device=dev)
     nr_host = RC.pinned_word()
@@ -119,9 +135,13 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
                                             nr_host.data_ptr(), s), "raster_geometry")
     # binning capacity exactly as diff_gaussian_rasterization._C.rasterize_gaussians sizes it
     state = RC._state
-    if state["mode"] == "exact":
+    # async with nothing to size from (no hint, no earlier frame): this one forward waits for its count, like exact mode
+    blind = state["mode"] == "async" and state["cap_hint"] == 0 and state["last_R"] is None
+    if state["mode"] == "exact" or blind:
         torch.cuda.current_stream().synchronize()
         cap, flag = int(nr_host[0]), None
+        if blind:
+            state["cap_hint"] = int(cap * 1.5) + 4096
     else:
         flag = RC.overflow_flag(dev)
         RC._check_overflow(RC._FLAG_LAG)
@@ -140,11 +160,12 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
         status_host.copy_(flag, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        state["pending"].append((ev, status_host, nr_host))
+        state["serial"] += 1
+        state["pending"].append((ev, status_host, nr_host, state["serial"]))
     return st
 
 
-def _field_grads(st, f):
+def _field_grads(st, f, direct=True):
     """Gradient storage of the deformation field -- the planes in their channel-last storage order, then the MLP tensors, one
     flat zeroed buffer -- with the backward descriptors that point into it.  One set is cached on the field and reused from
     iteration to iteration (the reference's loop drops the gradients with zero_grad(set_to_none=True), so the parameters let go
@@ -154,13 +175,15 @@ def _field_grads(st, f):
     place: the kernels add with atomics anyway, and twelve elementwise additions and their launches are saved.
     Returns (plane targets, MLP targets, hp, md, in_place) -- in_place[i]: plane i's target is its own .grad."""
     field = st.field
-    held = [p.grad for p in st.planes]
+    # through-the-graph mode (direct False): never touch a .grad, never hand out the cached buffer
+    held = [p.grad if direct else None for p in st.planes]
     in_place = [g is not None and ops._same_layout(g, p) and ops._dense(g) for g, p in zip(held, st.planes)]
     key = (tuple(p.data_ptr() for p in st.planes), tuple(p.data_ptr() for p in st.mlp), tuple(field.aabb_host()),
            tuple(g.data_ptr() if ip else 0 for g, ip in zip(held, in_place)))
     c = getattr(field, "_fa_grads", None)
-    own_busy = c is not None and ((st.mlp[0].grad is not None and st.mlp[0].grad.data_ptr() == c[3][0].data_ptr())
-                                  or any(g is not None and g.data_ptr() == v.data_ptr() for g, v in zip(held, c[2])))
+    own_busy = c is not None and (not direct or (st.mlp[0].grad is not None and st.mlp[0].grad.data_ptr() == c[3][0].data_ptr())
+                                  or any(g is not None and g.data_ptr() == v.data_ptr() for g, v in zip(held, c[2]))
+                                  or not ops._buffers_free(c[3]) or not ops._buffers_free(c[2], 2))   # a caller kept last iteration's gradient tensors (planes: also in `targets`)
     if c is not None and c[0] == key and not own_busy:
         c[1].zero_()
         return c[4], c[3], c[5], c[7], in_place
@@ -186,7 +209,7 @@ def _field_grads(st, f):
     return targets, gmlp, hp, md, in_place
 
 
-def _backward(st, dcolor, ddepth):
+def _backward(st, dcolor, ddepth, direct=True):
     lib, s = N.lib(), N.current_stream()
     P, dev = st.P, st.color.device
     f = dict(dtype=torch.float32, device=dev)
@@ -207,7 +230,7 @@ def _backward(st, dcolor, ddepth):
     N.check(lib.mom_activations_backward(P, st.sc.data_ptr(), st.rot_d.data_ptr(), st.op.data_ptr(), gsc_act.data_ptr(),
                                          grot_act.data_ptr(), gop_act.data_ptr(), gsc.data_ptr(), grot.data_ptr(), gop.data_ptr(), s),
             "act_bwd")
-    gplanes, gmlp, hp, md, in_place = _field_grads(st, f)
+    gplanes, gmlp, hp, md, in_place = _field_grads(st, f, direct)
     dfeat = e(P, 64)
     scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
     # pts = xyz + dx(...): d xyz starts as d pts (already in gxyz); scale / rotation residuals likewise
@@ -244,22 +267,24 @@ class FusedRenderFunction(torch.autograd.Function):
             raise RuntimeError("render(): a second backward through the same call -- its buffers were released after the first "
                                "(render again, or set pipe.per_op_autograd = True for retain_graph use)")
         ctx.st = None                                  # the call's buffers go back to the allocator after this backward
-        g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp, in_place = _backward(st, dcolor, ddepth)
-        if DIRECT_GRADS:
+        pc = ctx.pc
+        params = (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity, *st.planes, *st.mlp)
+        needs = ctx.needs_input_grad[7:]
+        direct = DIRECT_GRADS and ops.direct_grads_ok(params, needs)
+        g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp, in_place = _backward(st, dcolor, ddepth, direct)
+        if direct:
             # The 32 parameter gradients are handed to the parameters here (set, or added to what an earlier camera of the
             # batch left) instead of being returned: 32 AccumulateGrad nodes cost the autograd engine more host time than the
             # whole forward.  Only the 2-D gradient holder, a non-leaf, goes back through the graph.
-            pc = ctx.pc
-            for p, g in zip((pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity, *st.planes, *st.mlp),
-                            (gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp)):
+            for p, g in zip(params, (gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp)):
                 if p.grad is None:
                     p.grad = g
                 elif p.grad is not g:                   # (a plane accumulated into in place IS its own gradient)
                     p.grad.add_(g)
             return (None, None, None, None, None, None, g2d) + (None,) * (6 + len(gplanes) + len(gmlp))
-        # through the graph: planes that were accumulated into in place contribute nothing more
-        gplanes = [None if ip else gp for gp, ip in zip(gplanes, in_place)]
-        return (None, None, None, None, None, None, g2d, gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp)
+        # through the graph (fresh buffers: nothing is accumulated in place on this path); inputs that were not asked for get None
+        out = [g if n else None for g, n in zip((gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp), needs)]
+        return (None, None, None, None, None, None, g2d, *out)
 
 
 def render(cam, pc, pipe, bg, delta_scale, scaling_modifier, screenspace_points):

@@ -98,6 +98,7 @@ class FusedRender:
         a.scale_modifier = float(scaling_modifier)
         a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         a.prefiltered, a.debug = 0, int(bool(debug))
+        a.keep_all_tiles = int(RC._state["keep_all_tiles"])
         a.forward_only = 1               # no backward follows: cov3D / clamped / final_T / n_contrib are not written
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)

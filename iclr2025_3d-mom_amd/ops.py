@@ -392,6 +392,27 @@ def ssim(img1, img2):
 
 
 # --------------------------------------------------------------------------- plane regularisers
+def direct_grads_ok(params, needs):
+    """May a backward hand these parameters their gradients itself (p.grad = ...) instead of returning them to the engine?  Only
+    if the engine would do exactly that with a returned gradient: every one of them is asked for (needs_input_grad), is a leaf
+    that requires grad, and carries no tensor hook or post-accumulate hook -- those only fire on the engine's own path.
+    (torch.autograd.grad() cannot be told apart from backward() inside a node: callers that use it switch the direct path off,
+    fused_autograd.grads_through_graph().)"""
+    for p, n in zip(params, needs):
+        if not n or not p.requires_grad or not p.is_leaf:
+            return False
+        if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
+def _buffers_free(views, held_by_cache=1):
+    """True if nobody but the cache (held_by_cache references per view) and this call still refers to the cached gradient views: a
+    caller that kept a parameter's .grad tensor from the last iteration must not see it zeroed and rewritten."""
+    import sys
+    return all(sys.getrefcount(v) <= held_by_cache + 2 for v in views)      # + the loop variable and getrefcount's argument
+
+
 class PlaneRegFunction(torch.autograd.Function):
     """value = sum_p  w_smooth[p] * smooth2(plane_p) + w_l1[p] * mean|1 - plane_p|."""
 
@@ -421,12 +442,14 @@ class PlaneRegFunction(torch.autograd.Function):
         # (DIRECT_GRADS = False returns them through the graph).  The buffer and the descriptor are cached between iterations
         # while the planes have let go of last iteration's gradients (zero_grad(set_to_none=True)); the upstream weight stays on
         # the device (float(g) was a host synchronisation in every iteration).
-        held = [p.grad if PlaneRegFunction.DIRECT_GRADS else None for p in planes]
+        direct = PlaneRegFunction.DIRECT_GRADS and direct_grads_ok(planes, ctx.needs_input_grad[2:])
+        held = [p.grad if direct else None for p in planes]
         in_place = [h is not None and _same_layout(h, p) and _dense(h) for h, p in zip(held, planes)]
         key = (tuple(p.data_ptr() for p in planes), tuple(w_smooth), tuple(w_l1),
                tuple(h.data_ptr() if ip else 0 for h, ip in zip(held, in_place)))
         c = PlaneRegFunction._cache
-        busy = c is not None and any(h is not None and h.data_ptr() == v.data_ptr() for h, v in zip(held, c[2]))
+        busy = c is not None and (any(h is not None and h.data_ptr() == v.data_ptr() for h, v in zip(held, c[2]))
+                                  or not _buffers_free(c[2]))
         if c is None or c[0] != key or busy:
             flat = torch.zeros(sum(p.numel() for p in planes), dtype=torch.float32, device=planes[0].device)
             off, grads = 0, []
@@ -450,7 +473,7 @@ class PlaneRegFunction(torch.autograd.Function):
         up = g.detach().reshape(1).float()
         N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), N.current_stream()),
                 "mom_plane_regulation")
-        if PlaneRegFunction.DIRECT_GRADS:
+        if direct:
             for p, gp, ip in zip(planes, grads, in_place):
                 if not ip:
                     if p.grad is None:
@@ -458,7 +481,7 @@ class PlaneRegFunction(torch.autograd.Function):
                     else:
                         p.grad.add_(gp)
             return (None, None) + (None,) * len(planes)
-        return (None, None, *grads)
+        return (None, None, *[gp if n else None for gp, n in zip(grads, ctx.needs_input_grad[2:])])
 
     _cache = None
     DIRECT_GRADS = True

@@ -7,6 +7,7 @@ from random import randint
 
 import torch
 
+from .diff_gaussian_rasterization import _C as RC
 from .gaussian_renderer import render
 from .utils.image_utils import psnr
 from .utils.loss_utils import l1_loss, psnr_from_last_l1, ssim
@@ -35,6 +36,7 @@ class Trainer:
         # (serial of the last step they cover, ring slot, event)
         self._log = deque()
         self._checks = deque()
+        self._alog = deque()     # async autograd path: (first forward, last forward, iteration, cameras) of the unverified iterations
         self._serial = 0
         self.replayed = 0    # iterations replayed after a binning overflow (diagnostics)
         if gc_freeze:
@@ -84,6 +86,15 @@ class Trainer:
         if self.fused is not None:
             self._post_check()
             self._poll(0)
+        elif RC._state["mode"] == "async" and self._alog:
+            self.drain_autograd()
+
+    def save(self, iteration, stage=None):
+        """scene.save() behind drain(): a fused (or async) run may hold a few iterations the device skipped after a binning
+        overflow until the host replays them -- anything that reads the model between steps (checkpoints, evaluation renders)
+        drains first.  Trainer.step() does so itself at every iteration that restructures the model."""
+        self.drain()
+        self.scene.save(iteration, stage or self.stage)
 
     def _recover(self, tag):
         torch.cuda.synchronize()
@@ -121,12 +132,61 @@ class Trainer:
                 if len(self._log) and len(self._log) % self.CHECK_EVERY == 0:
                     self._post_check()
                 self._poll(self.FLAG_LAG)
+        elif RC._state["mode"] == "async" and self._boundary(iteration):
+            self.drain_autograd()      # async autograd path: the same rule
         g.update_learning_rate(iteration)
         if iteration % 1000 == 0:
             g.oneupSHdegree()
         cams = cams or self._draw()
         if self.fused is not None and len(cams) == 1:
             return self._step_fused(iteration, cams[0])
+        if RC._state["mode"] == "async":
+            # the rasterizer sizes its binning buffer from earlier frames and reports an overflow a few forwards later (render()
+            # raises BinningOverflow): replay what the overflow skipped (_recover_autograd), then take this iteration again
+            first = RC._state["serial"] + 1
+            try:
+                loss = self._step_autograd(iteration, cams)
+            except RC.BinningOverflow as e:
+                self._recover_autograd(e.serial)
+                g.update_learning_rate(iteration)
+                g.optimizer.zero_grad(set_to_none=True)
+                first = RC._state["serial"] + 1
+                loss = self._step_autograd(iteration, cams)       # the capacity hint has been doubled
+            self._alog.append((first, RC._state["serial"], iteration, list(cams)))
+            while self._alog and self._alog[0][1] <= RC._state["verified"]:
+                self._alog.popleft()
+            return loss
+        return self._step_autograd(iteration, cams)
+
+    def _recover_autograd(self, serial):
+        """Async forward number `serial` overflowed: the optimizer steps and statistics updates of its iteration and of every
+        later one were no-ops on the device (FusedAdam.skip_flag / the statistics kernel test RC.overflow_flag()).  Replay those
+        iterations with exactly sized buffers, as _recover does for the fused step."""
+        redo = [e for e in self._alog if e[1] >= serial]
+        self._alog.clear()
+        self.g.optimizer.rewind(len(redo))          # the host counted steps the device skipped
+        RC._state["mode"] = "exact"
+        try:
+            for _, _, it, cams in redo:
+                self.g.update_learning_rate(it)
+                self._step_autograd(it, cams)
+                self.replayed += 1
+        finally:
+            RC._state["mode"] = "async"
+
+    def drain_autograd(self):
+        """Async autograd path: every iteration enqueued so far has been applied (or replayed)."""
+        try:
+            RC._check_overflow(0)
+        except RC.BinningOverflow as e:
+            self._recover_autograd(e.serial)
+        self._alog.clear()
+
+    def _step_autograd(self, iteration, cams):
+        g, opt, hyper = self.g, self.opt, self.hyper
+        self._skip = None
+        if RC._state["mode"] == "async":
+            self._skip = g.optimizer.skip_flag = RC.overflow_flag(g._xyz.device)
         images, gts, radii_l, vis_l, vsp_l = [], [], [], [], []
         for cam in cams:
             pkg = render(cam, g, self.pipe, self.background, stage=self.stage, cam_type=self.scene.dataset_type,
@@ -171,7 +231,9 @@ class Trainer:
                 ps = psnr_from_last_l1() if image.shape[0] == 1 else psnr(image.detach(), gt).mean()
                 self.ema_psnr = 0.4 * float(ps) + 0.6 * self.ema_psnr
             self.last = {"loss": loss.detach(), "l1": Ll1.detach(), "points": g._xyz.shape[0]}
-        return self._after_backward(iteration, loss.detach(), radii, visibility, vsp_grad)
+        loss = self._after_backward(iteration, loss.detach(), radii, visibility, vsp_grad)
+        self._skip = None
+        return loss
 
     def _step_fused(self, iteration, cam, replay=False):
         with torch.no_grad():

@@ -112,3 +112,87 @@ def test_async_mode_overflow_is_reported_and_gates_adam():
     finally:
         DGR.set_sync_mode("exact")
         g.optimizer.skip_flag = None
+
+
+def test_trainer_autograd_path_in_async_mode_replays_an_overflow():
+    """Trainer.step's autograd branch under set_sync_mode("async") points the optimizer and the statistics kernel at
+    the rasterizer's overflow word, catches the overflow the rasterizer reports a few forwards later, and replays the skipped
+    iterations in exact mode -- the model ends where a run that never overflowed ends (same check as the fused step's)."""
+    import bench
+    DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
+    RC = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization._C")
+
+    def run(force):
+        torch.manual_seed(0)
+        scene, g, trainer, op = bench.build_state(CFG, torch.device("cuda"), fused=False, lambda_dssim=0.0)
+        trainer.sync_every_step = False
+        RC._state.update(cap_hint=0, last_R=None, flag=None, serial=0, verified=0)
+        RC._state["pending"].clear()
+        DGR.set_sync_mode("async")
+        try:
+            for i in range(12):
+                if force and i == 5:
+                    RC._state["cap_hint"], RC._state["last_R"] = 4096, None      # this forward and the next ones cannot fit
+                trainer.step(5001 + i, cams=[trainer.cams[i % 4]])
+            trainer.drain()
+        finally:
+            DGR.set_sync_mode("exact")
+        torch.cuda.synchronize()
+        steps = {float(st["step"]) for st in g.optimizer.state.values() if "step" in st}
+        return g._xyz.detach().clone(), g._opacity.detach().clone(), g.denom.detach().clone(), steps, trainer.replayed
+
+    x0, o0, d0, s0, r0 = run(False)
+    x1, o1, d1, s1, r1 = run(True)
+    assert r0 == 0 and r1 >= 1
+    assert s0 == s1 == {12.0}
+    assert torch.equal(d0, d1)
+    # parameters: the replayed iterations sum their float atomics in another order, and Adam's m / sqrt(v) turns a last-bit
+    # difference of a near-zero gradient into a visible fraction of the learning rate -- for a few elements (the fused step's
+    # overflow test applies the same bound)
+    for a, b, lr in ((x0, x1, 1.6e-4 * 5), (o0, o1, 0.05)):
+        frac = float(((a - b).abs() > 0.02 * lr * 12).float().mean())
+        assert frac <= 2e-3, frac
+
+
+def test_direct_gradients_respect_frozen_parameters_hooks_kept_references_and_autograd_grad():
+    """the one-node render() hands gradients to the parameters itself only where the engine would do the same:
+    a frozen parameter gets none, a hooked parameter goes through the engine (the hook fires), a gradient tensor the caller kept
+    is not overwritten by the next iteration, and under grads_through_graph() torch.autograd.grad() gets its gradients back
+    without .grad being touched."""
+    import bench
+    FA = importlib.import_module("iclr2025_3d-mom_amd.fused_autograd")
+    render = importlib.import_module("iclr2025_3d-mom_amd.gaussian_renderer").render
+    scene, g, trainer, op = bench.build_state(CFG, torch.device("cuda"), fused=False, lambda_dssim=0.0)
+
+    def go(cam=0):
+        pk = render(trainer.cams[cam], g, trainer.pipe, trainer.background, stage="fine", cam_type=scene.dataset_type,
+                    delta_scale=trainer.delta_scale)
+        return pk["render"].sum()
+    params = [g._xyz, g._features_dc, g._scaling, g._opacity]
+    go().backward()
+    ref = [p.grad.clone() for p in params]
+    kept = g._xyz.grad                               # the caller keeps last iteration's gradient tensor ...
+    kept_copy = kept.clone()
+    g.optimizer.zero_grad(set_to_none=True)
+    go(1).backward()                                 # ... and the next iteration must not write into it
+    assert torch.equal(kept, kept_copy)
+    g.optimizer.zero_grad(set_to_none=True)
+    # frozen parameter: no gradient, the others as before
+    g._opacity.requires_grad_(False)
+    go().backward()
+    assert g._opacity.grad is None and _close(g._xyz.grad, ref[0], tol=1e-5)
+    g._opacity.requires_grad_(True)
+    g.optimizer.zero_grad(set_to_none=True)
+    # a tensor hook fires and its result is what lands in .grad
+    fired = []
+    h = g._scaling.register_hook(lambda gr: fired.append(1) or gr * 2.0)
+    go().backward()
+    h.remove()
+    assert fired and _close(g._scaling.grad, 2.0 * ref[2], tol=1e-5) and _close(g._xyz.grad, ref[0], tol=1e-5)
+    g.optimizer.zero_grad(set_to_none=True)
+    # torch.autograd.grad: gradients come back, .grad stays untouched
+    with FA.grads_through_graph():
+        got = torch.autograd.grad(go(), params)
+    assert all(p.grad is None for p in params)
+    for a, b in zip(got, ref):
+        assert _close(a, b, tol=1e-5)

@@ -11,10 +11,58 @@ from scenes import camera, random_gaussians
 
 pytestmark = pytest.mark.gpu
 
-IMG_L1_TOL = 1e-4      # mean per-pixel L1 (north_star)
-IMG_MAX_TOL = 2e-2     # a 1-ulp exp difference may flip one of the hard thresholds (1/255, T<1e-4) on a few pixels
-GRAD_REL_TOL = 2e-3
-ROW_TOL, ROW_FRAC, ROW_MAX = 1e-4, 0.999, 5e-3
+# Regression gates, set from what the kernels achieve (tools/parity_stats.py on an MI355X: image mean L1 2.9e-8 .. 4.3e-8, max
+# 1.2e-6, no pixel above 1e-5, n_contrib and last contributors identical, gradient norms within 4.6e-6, worst gradient row
+# 1.3e-5 of its tensor's scale) -- the north star's 1e-4 is the ceiling, not the gate.  A (pixel, splat) pair whose alpha sits
+# within rounding of one of the hard thresholds (1/255, 0.99, T < 1e-4) may legitimately take the other branch under v_exp_f32
+# than under expf; such pixels / rows are allowed as COUNTED exceptions and every outlier pixel must be shown to hold such a pair.
+NORTH_STAR_L1 = 1e-4
+IMG_L1_TOL = 1e-6      # mean per-pixel L1
+IMG_PIX_TOL = 1e-5     # per pixel; above it: a counted threshold exception, bounded by IMG_MAX_TOL
+IMG_MAX_TOL = 2e-2
+MAX_EXC_FRAC = 1e-4    # at most this fraction of the pixels / Gaussian rows (and never fewer than 2 allowed) may be exceptions
+GRAD_REL_TOL = 5e-5
+ROW_TOL, ROW_MAX = 2e-5, 5e-3
+
+
+def _allowed(n):
+    return max(2, int(MAX_EXC_FRAC * n))
+
+
+def _near_threshold(st, px, py, W, rel=2e-5):
+    """Does pixel (px, py) of the oracle state hold a (pixel, splat) pair whose alpha is within `rel` of 1/255 or 0.99, or whose
+    transmittance test T (1 - alpha) < 1e-4 is that close?  (forward.cu:331-345, recomputed from the oracle's own lists.)"""
+    gx = (W + 15) // 16
+    t = (py // 16) * gx + px // 16
+    T = 1.0
+    for i in st.point_list[st.ranges[t, 0]:st.ranges[t, 1]]:
+        dx, dy = float(st.means2D[i, 0]) - px, float(st.means2D[i, 1]) - py
+        cx, cy, cz, op = (float(v) for v in st.conic_opacity[i])
+        power = -0.5 * (cx * dx * dx + cz * dy * dy) - cy * dx * dy
+        if power > 0:
+            continue
+        raw = op * np.exp(power)
+        alpha = min(0.99, raw)
+        if abs(raw - 1.0 / 255.0) <= rel / 255.0 or abs(raw - 0.99) <= rel:
+            return True
+        if alpha < 1.0 / 255.0:
+            continue
+        if abs(T * (1 - alpha) - 1e-4) <= rel * 1e-4:
+            return True
+        if T * (1 - alpha) < 1e-4:
+            break
+        T *= 1 - alpha
+    return False
+
+
+def _assert_image(fw_img, st_img, st, what):
+    d = np.abs(fw_img - st_img)
+    assert d.mean() <= IMG_L1_TOL <= NORTH_STAR_L1, (what, d.mean())
+    H, W = d.shape[1], d.shape[2]
+    ys, xs = np.nonzero(d.max(axis=0) > IMG_PIX_TOL)
+    assert len(ys) <= _allowed(W * H) and d.max() <= IMG_MAX_TOL, (what, len(ys), d.max())
+    for y, x in zip(ys, xs):
+        assert _near_threshold(st, int(x), int(y), W), (what, "pixel off by more than rounding without a threshold pair", x, y)
 
 
 def _oracle(s, **kw):
@@ -53,7 +101,10 @@ def _cmp_lists_culled(fw, st, W, H):
         np.testing.assert_array_equal(ref[np.isin(ref, mine)], mine)          # an order-preserving subsequence
     a = _last_contributor(fw["n_contrib"], fw["ranges"], fw["point_list"], W, H)
     b = _last_contributor(st.n_contrib, st.ranges, st.point_list, W, H)
-    assert (a == b).mean() >= 0.999
+    bad = np.nonzero(a != b)[0]
+    assert len(bad) <= _allowed(W * H), len(bad)
+    for p in bad:
+        assert _near_threshold(st, int(p % W), int(p // W), W), ("last contributor differs without a threshold pair", p)
 
 
 def _cmp_forward(fw, st, P, feat=None):
@@ -76,14 +127,16 @@ def _cmp_forward(fw, st, P, feat=None):
     # with precomputed colours the reference leaves geomState.rgb untouched and renders from the input
     ref_rgb = st.rgb if feat is None else feat
     np.testing.assert_allclose(fw["rgb"][vis], ref_rgb[vis], rtol=1e-6, atol=1e-7)
-    dc = np.abs(fw["color"] - st.out_color)
-    assert dc.mean() <= IMG_L1_TOL and dc.max() <= IMG_MAX_TOL, (dc.mean(), dc.max())
-    dd = np.abs(fw["depth"] - st.out_depth)
-    assert dd.mean() <= IMG_L1_TOL * max(1.0, float(st.depths.max())), dd.mean()
+    _assert_image(fw["color"], st.out_color, st, "color")
+    dscale = max(1.0, float(st.depths.max()))
+    _assert_image(fw["depth"] / dscale, st.out_depth / dscale, st, "depth")
     if not culled:
-        same = (fw["n_contrib"] == st.n_contrib).mean()
-        assert same >= 0.999, same
-    assert np.abs(fw["final_T"] - st.final_T).mean() <= 1e-5
+        W = fw["color"].shape[2]
+        bad = np.nonzero((fw["n_contrib"] != st.n_contrib).reshape(-1))[0]
+        assert len(bad) <= _allowed(fw["n_contrib"].size), len(bad)
+        for p in bad:
+            assert _near_threshold(st, int(p % W), int(p // W), W), ("n_contrib differs without a threshold pair", p)
+    assert np.abs(fw["final_T"] - st.final_T).mean() <= 1e-8
 
 
 def _relerr(a, b):
@@ -105,10 +158,12 @@ def test_wave_sum_selftest():
     (2, 700, 100, 50, dict(scale=(-3.0, -0.5))),   # ragged image, large splats (wave-cooperative enumeration)
     (3, 64, 33, 17, {}),
     (4, 20000, 320, 180, dict(scale=(-5.0, -3.0))),
+    (5, 100000, 480, 270, dict(scale=(-5.5, -3.5))),      # mid size: half of config 2's Gaussians at a quarter of its pixels
 ])
 @pytest.mark.parametrize("keep_all_tiles", [True, False])
 def test_forward_parity(seed, P, W, H, kw, keep_all_tiles):
     from hip_helpers import hip_forward
+    ro.set_threads(16 if P >= 100000 else 1)
     s = random_gaussians(P, seed=seed, W=W, H=H, **kw)
     _cmp_forward(hip_forward(s, keep_all_tiles=keep_all_tiles), _oracle(s), P)
 
@@ -188,13 +243,13 @@ def test_backward_parity(seed, P, W, H, kw):
         inv = st.radii == 0
         assert np.abs(a[inv]).max(initial=0.0) == 0.0, name
         # per GAUSSIAN, not only as a whole-tensor norm (a norm hides a few badly wrong rows): the worst element of a row,
-        # relative to the tensor's largest element, is within ROW_TOL on at least ROW_FRAC of the rows and within ROW_MAX on
-        # all of them.  Rows outside ROW_TOL are Gaussians with a (pixel, splat) pair whose alpha sits within an ulp of the
-        # 1/255 or 0.99 thresholds (v_exp_f32 vs expf), where the two implementations legitimately take different branches.
+        # relative to the tensor's largest element, is within ROW_TOL on all rows but a counted handful (_allowed) and within
+        # ROW_MAX on those -- Gaussians with a (pixel, splat) pair whose alpha sits within an ulp of the 1/255 or 0.99
+        # thresholds (v_exp_f32 vs expf), where the two implementations legitimately take different branches.
         scale = max(float(np.abs(b).max()), 1e-30)
         row_err = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1) / scale
-        frac_ok = float((row_err <= ROW_TOL).mean())
-        assert frac_ok >= ROW_FRAC and float(row_err.max()) <= ROW_MAX, (name, frac_ok, float(row_err.max()))
+        n_bad = int((row_err > ROW_TOL).sum())
+        assert n_bad <= _allowed(a.shape[0]) and float(row_err.max()) <= ROW_MAX, (name, n_bad, float(row_err.max()))
 
 
 def test_dropin_autograd_matches_oracle():
