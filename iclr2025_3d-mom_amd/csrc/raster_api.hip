@@ -37,7 +37,10 @@ static int check_grads(const MomRasterArgs* a, const MomRasterGrads* gr)
 
 extern "C" {
 
-const char* mom_version(void) { return "mom4d 0.1 (gfx950)"; }
+#ifndef MOM_SRC_HASH
+#define MOM_SRC_HASH "unknown"
+#endif
+const char* mom_version(void) { return "mom4d 0.3 (gfx950) src " MOM_SRC_HASH; }
 
 size_t mom_raster_geom_bytes(int P) { return geom_view(nullptr, P, nullptr) + MOM_ALIGN; }
 size_t mom_raster_image_bytes(int W, int H) { return image_view(nullptr, W, H, nullptr) + MOM_ALIGN; }

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
-from ._C import set_sync_mode, last_num_rendered  # noqa: F401  (extensions; not in the reference)
+from ._C import set_sync_mode, set_keep_all_tiles, last_num_rendered  # noqa: F401  (extensions; not in the reference)
 
 
 def cpu_deep_copy_tuple(input_tuple):

@@ -67,13 +67,4 @@ def roofline(kernel, P, R, Npix, traffic=None):
     out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
            "algorithmic_bytes_per_launch": b}
-    if kernel in VALU_FLOP_PER_PAIR:
-        # secondary ceiling: the compositing loops are bound by fp32 VALU issue, not by HBM.  Nominal work:
-        # every one of the 256 pixels of a tile evaluates every splat of the tile's list.
-        flop = 256.0 * R * VALU_FLOP_PER_PAIR[kernel]
-        tf = flop / avg_s / 1e12
-        out["valu"] = {"achieved": tf, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_VALU_PEAK_TFLOPS,
-                       "flop_per_pair": VALU_FLOP_PER_PAIR[kernel], "pairs_per_launch": 256 * R,
-                       "note": "nominal pair count; the kernels skip pairs that cannot contribute, so this can exceed what "
-                               "is executed"}
     return out

@@ -23,6 +23,7 @@ import collections
 import csv
 import json
 import re
+import os
 import sys
 
 # kernel symbol -> the name bench.py / profiling.py use
@@ -84,7 +85,13 @@ def main():
                     "write_bytes", "traffic_bytes_per_launch"])
         w.writerows(rows)
     doc = dict(WORKLOAD)
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    native = importlib.import_module("iclr2025_3d-mom_amd._native")
     doc.update({
+        # the library the counters were collected on (mom_version() carries a hash of the kernel sources): bench.py reports the
+        # figures of this file only while the running library is that build
+        "lib_version": native.lib().mom_version().decode(),
         "what": "HBM-side traffic per launch from rocprofv3 PMC counters, one MI355X, bench.py config c2",
         "method": "two separate --pmc passes, per-dispatch values averaged over the launches after the first %d" % SKIP,
         "corrections": {"unit": "counter values are KiB (x1024)", "FETCH_SIZE": "x2 on gfx950", "WRITE_SIZE": "exact"},
