@@ -1,10 +1,12 @@
 // extern "C" entry points of the rasterizer (see include/mom4d.h).
 #include "mom_common.h"
+#include <stdlib.h>
 
-int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, uint32_t* zero_words, int n_zero, hipStream_t s);
+int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, uint32_t* zero_words, int n_zero,
+                              uint32_t* hist_counts, bool* did_hist, hipStream_t s);
 int mom_launch_mark_visible(int P, const float* means3D, const float* view, uint8_t* present, hipStream_t s);
 int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const ImageView& im, uint32_t* num_rendered_dev,
-                             uint32_t* num_rendered_host, hipStream_t s);
+                             uint32_t* num_rendered_host, bool hist_done, hipStream_t s);
 int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
                             uint32_t* status_dev, hipStream_t s);
 int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
@@ -90,10 +92,13 @@ int mom_raster_forward_geometry(const MomRasterArgs* a, void* geom, void* image,
     image_view(mom_align_ptr(image), a->W, a->H, &im);
     // the header and the tile counters are adjacent in the image scratch (image_view): the projection kernel clears both
     const int tiles = ((a->W + MOM_TILE - 1) / MOM_TILE) * ((a->H + MOM_TILE - 1) / MOM_TILE);
-    rc = mom_launch_preprocess_fwd(a, g, radii, im.hdr, (int)((im.tile_counts + tiles) - im.hdr), s);
+    bool did_hist = false;
+    static int fold = -1;                 // MOM_FOLD_HIST=1: the tile histogram inside the projection kernel (measured: slower, see raster_preprocess.hip)
+    if (fold < 0) { const char* e = getenv("MOM_FOLD_HIST"); fold = (e && e[0] == '1') ? 1 : 0; }
+    rc = mom_launch_preprocess_fwd(a, g, radii, im.hdr, (int)((im.tile_counts + tiles) - im.hdr), fold ? im.tile_counts : nullptr, &did_hist, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
-    rc = mom_launch_binning_count(a, g, im, num_rendered_dev, num_rendered_host, s);
+    rc = mom_launch_binning_count(a, g, im, num_rendered_dev, num_rendered_host, did_hist, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
     return MOM_OK;

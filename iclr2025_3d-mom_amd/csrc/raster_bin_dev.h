@@ -1,0 +1,100 @@
+// Device helpers of the tile binning shared by raster_binning.hip and raster_preprocess.hip (the projection kernel also decides
+// which (splat, tile) instances are binned and counts them per tile: the per-(splat, tile) test sits in a kernel that waits for
+// memory most of the time, and the separate histogram launch with its second read of the records is gone).
+#pragma once
+#include "mom_common.h"
+
+namespace {
+
+constexpr int kSmallRect = 8;          // splats touching <= 8 tiles are enumerated by their own lane
+constexpr int kMaxLdsTiles = 16384;    // 64 KiB LDS histogram
+
+
+// What the tile cull needs of a splat (mom_rect_reach, mom_common.h).  cull == 0: every tile of the rectangle is kept, as
+// the reference does (MomRasterArgs.keep_all_tiles).
+struct Reach {
+    float cx, cy, a, b, c, bound, inv_a, inv_c;
+    int cull;
+};
+__device__ __forceinline__ bool tile_reached(const Reach& r, int tx, int ty)
+{
+    if (!r.cull) return true;
+    const float xa = (float)(tx * MOM_TILE), ya = (float)(ty * MOM_TILE);
+    return mom_rect_reach(r.cx, r.cy, r.a, r.b, r.c, r.bound, r.inv_a, r.inv_c, xa, xa + (float)(MOM_TILE - 1), ya,
+                          ya + (float)(MOM_TILE - 1));
+}
+__device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
+struct WaveSplat {       // one lane's splat, broadcast to the wave
+    int x0, y0, w, cnt;
+    uint32_t payload;
+    uint64_t mask;
+    Reach rc;
+};
+__device__ __forceinline__ WaveSplat bcast_splat(int x0, int y0, int w, int cnt, uint32_t payload, uint64_t mask, const Reach& rc, int src)
+{
+    WaveSplat o;
+    o.x0 = __builtin_amdgcn_readlane(x0, src);
+    o.y0 = __builtin_amdgcn_readlane(y0, src);
+    o.w = __builtin_amdgcn_readlane(w, src);
+    o.cnt = __builtin_amdgcn_readlane(cnt, src);
+    o.payload = (uint32_t)__builtin_amdgcn_readlane((int)payload, src);
+    o.mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mask >> 32), src) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, src);
+    o.rc.cx = bcast(rc.cx, src); o.rc.cy = bcast(rc.cy, src); o.rc.a = bcast(rc.a, src); o.rc.b = bcast(rc.b, src);
+    o.rc.c = bcast(rc.c, src); o.rc.bound = bcast(rc.bound, src); o.rc.inv_a = bcast(rc.inv_a, src);
+    o.rc.inv_c = bcast(rc.inv_c, src);
+    o.rc.cull = __builtin_amdgcn_readlane(rc.cull, src);
+    return o;
+}
+// i / w for 0 <= i, 1 <= w <= 64 * 64: (i + 0.5) / w is at least 0.5 / w away from an integer, far more than the error of
+// the hardware reciprocal and the product
+__device__ __forceinline__ int small_div(int i, float inv_w) { return (int)(((float)i + 0.5f) * inv_w); }
+
+// Pass 1 (tile_hist): decides, for every (Gaussian, tile) instance of this wave's 64 Gaussians, whether it is binned
+// (tile_reached), calls f(tile) for those that are, and returns the lane's own decisions as a mask: bit i = tile i of the
+// rectangle, row-major, for i < 64 (tile_scatter evaluates tiles beyond 64 again).  Lanes own small rectangles; large ones
+// are walked by the whole wave, one tile per lane, and the ballot IS the mask.
+template <class F>
+__device__ __forceinline__ uint64_t decide_instances(int x0, int y0, int x1, int y1, int gx, const Reach& rc, F f)
+{
+    const int lane = mom_lane();
+    const int w = x1 - x0;
+    const int cnt = w * (y1 - y0);
+    uint64_t mask = 0;
+    if (cnt <= kSmallRect) {
+        int tx = x0, ty = y0;
+        for (int i = 0; i < cnt; i++) {
+            if (tile_reached(rc, tx, ty)) {
+                mask |= 1ull << i;
+                f(ty * gx + tx);
+            }
+            if (++tx == x1) { tx = x0; ty++; }
+        }
+    }
+    unsigned long long big = __ballot(cnt > kSmallRect);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const WaveSplat b = bcast_splat(x0, y0, w, cnt, 0u, 0ull, rc, src);
+        const float inv_w = __builtin_amdgcn_rcpf((float)b.w);
+        for (int base = 0; base < b.cnt; base += MOM_WAVE) {
+            const int i = base + lane;
+            bool r = false;
+            if (i < b.cnt) {
+                const int q = small_div(i, inv_w);
+                const int tx = b.x0 + i - q * b.w, ty = b.y0 + q;
+                r = tile_reached(b.rc, tx, ty);
+                if (r) f(ty * gx + tx);
+            }
+            if (base == 0) {
+                const uint64_t bal = __ballot(r);
+                if (lane == src) mask = bal;
+            }
+        }
+    }
+    return mask;
+}
+
+
+}  // namespace

@@ -21,104 +21,17 @@
 //                     in LDS (bitonic network, all compare-exchanges ascending,
 //                     so no padding is ever materialised) and writes point_list.
 // Instances never travel through HBM more than: 8 B write, 8 B read, 4 B write.
-#include "mom_common.h"
+#include "raster_bin_dev.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int kSmallRect = 8;          // splats touching <= 8 tiles are enumerated by their own lane
 constexpr int kSortLdsCap = 8192;      // 64 KiB of 64-bit keys per workgroup: the largest tile sorted in LDS
 #ifndef MOM_SORT_SMALL
 #define MOM_SORT_SMALL 2048
 #endif
 constexpr int kSortSmallCap = MOM_SORT_SMALL;   // tiles up to this size go to the launch with the small LDS footprint
-constexpr int kMaxLdsTiles = 16384;    // 64 KiB LDS histogram
 constexpr int kOrderBins = 128;        // weight classes of the tile order (32 instances each; the last one open-ended)
-
-// What the tile cull needs of a splat (mom_rect_reach, mom_common.h).  cull == 0: every tile of the rectangle is kept, as
-// the reference does (MomRasterArgs.keep_all_tiles).
-struct Reach {
-    float cx, cy, a, b, c, bound, inv_a, inv_c;
-    int cull;
-};
-__device__ __forceinline__ bool tile_reached(const Reach& r, int tx, int ty)
-{
-    if (!r.cull) return true;
-    const float xa = (float)(tx * MOM_TILE), ya = (float)(ty * MOM_TILE);
-    return mom_rect_reach(r.cx, r.cy, r.a, r.b, r.c, r.bound, r.inv_a, r.inv_c, xa, xa + (float)(MOM_TILE - 1), ya,
-                          ya + (float)(MOM_TILE - 1));
-}
-__device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
-
-struct WaveSplat {       // one lane's splat, broadcast to the wave
-    int x0, y0, w, cnt;
-    uint32_t payload;
-    uint64_t mask;
-    Reach rc;
-};
-__device__ __forceinline__ WaveSplat bcast_splat(int x0, int y0, int w, int cnt, uint32_t payload, uint64_t mask, const Reach& rc, int src)
-{
-    WaveSplat o;
-    o.x0 = __builtin_amdgcn_readlane(x0, src);
-    o.y0 = __builtin_amdgcn_readlane(y0, src);
-    o.w = __builtin_amdgcn_readlane(w, src);
-    o.cnt = __builtin_amdgcn_readlane(cnt, src);
-    o.payload = (uint32_t)__builtin_amdgcn_readlane((int)payload, src);
-    o.mask = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mask >> 32), src) << 32) |
-             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mask, src);
-    o.rc.cx = bcast(rc.cx, src); o.rc.cy = bcast(rc.cy, src); o.rc.a = bcast(rc.a, src); o.rc.b = bcast(rc.b, src);
-    o.rc.c = bcast(rc.c, src); o.rc.bound = bcast(rc.bound, src); o.rc.inv_a = bcast(rc.inv_a, src);
-    o.rc.inv_c = bcast(rc.inv_c, src);
-    o.rc.cull = __builtin_amdgcn_readlane(rc.cull, src);
-    return o;
-}
-// i / w for 0 <= i, 1 <= w <= 64 * 64: (i + 0.5) / w is at least 0.5 / w away from an integer, far more than the error of
-// the hardware reciprocal and the product
-__device__ __forceinline__ int small_div(int i, float inv_w) { return (int)(((float)i + 0.5f) * inv_w); }
-
-// Pass 1 (tile_hist): decides, for every (Gaussian, tile) instance of this wave's 64 Gaussians, whether it is binned
-// (tile_reached), calls f(tile) for those that are, and returns the lane's own decisions as a mask: bit i = tile i of the
-// rectangle, row-major, for i < 64 (tile_scatter evaluates tiles beyond 64 again).  Lanes own small rectangles; large ones
-// are walked by the whole wave, one tile per lane, and the ballot IS the mask.
-template <class F>
-__device__ __forceinline__ uint64_t decide_instances(int x0, int y0, int x1, int y1, int gx, const Reach& rc, F f)
-{
-    const int lane = mom_lane();
-    const int w = x1 - x0;
-    const int cnt = w * (y1 - y0);
-    uint64_t mask = 0;
-    if (cnt <= kSmallRect) {
-        int tx = x0, ty = y0;
-        for (int i = 0; i < cnt; i++) {
-            if (tile_reached(rc, tx, ty)) {
-                mask |= 1ull << i;
-                f(ty * gx + tx);
-            }
-            if (++tx == x1) { tx = x0; ty++; }
-        }
-    }
-    unsigned long long big = __ballot(cnt > kSmallRect);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const WaveSplat b = bcast_splat(x0, y0, w, cnt, 0u, 0ull, rc, src);
-        const float inv_w = __builtin_amdgcn_rcpf((float)b.w);
-        for (int base = 0; base < b.cnt; base += MOM_WAVE) {
-            const int i = base + lane;
-            bool r = false;
-            if (i < b.cnt) {
-                const int q = small_div(i, inv_w);
-                const int tx = b.x0 + i - q * b.w, ty = b.y0 + q;
-                r = tile_reached(b.rc, tx, ty);
-                if (r) f(ty * gx + tx);
-            }
-            if (base == 0) {
-                const uint64_t bal = __ballot(r);
-                if (lane == src) mask = bal;
-            }
-        }
-    }
-    return mask;
-}
 
 // Pass 2 (tile_scatter): calls f(tile, src_lane, src_payload) for the instances pass 1 kept.  A lane walks the set bits of
 // its own mask when they are few; otherwise the wave takes one tile per lane.
@@ -416,7 +329,7 @@ __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict_
 }  // namespace
 
 int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const ImageView& im, uint32_t* num_rendered_dev,
-                             uint32_t* num_rendered_host, hipStream_t s)
+                             uint32_t* num_rendered_host, bool hist_done, hipStream_t s)
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const int tiles = gx * gy;
@@ -428,9 +341,16 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
     // device-scope fence the ticket needs, 782 workgroups each wrote the L2 back, 27 -> 72 us.)
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
     if (chunks < 1) chunks = 1;
+    {
+        static int forced = -1;           // MOM_BIN_CHUNKS: 256-Gaussian chunks per workgroup (measurement)
+        if (forced < 0) { const char* e = getenv("MOM_BIN_CHUNKS"); forced = e ? atoi(e) : 0; }
+        if (forced > 0) chunks = forced;
+    }
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
     mom_prof_begin(MOM_P_HIST, s);
-    if (tiles <= kMaxLdsTiles)
+    if (hist_done) {
+        // the projection kernel counted the instances (raster_preprocess.hip, HIST)
+    } else if (tiles <= kMaxLdsTiles)
         hipLaunchKernelGGL(tile_hist_kernel<true>, dim3(blocks), dim3(256), (size_t)tiles * 4, s, a->P, chunks, gx, gy, ry0, ry1, cull,
                            g.rec, im.tile_counts, g.reach);
     else
@@ -454,6 +374,11 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     const int cull = a->keep_all_tiles ? 0 : 1;
     int chunks = (a->P + 256 * 2048 - 1) / (256 * 2048);
     if (chunks < 1) chunks = 1;
+    {
+        static int forced = -1;           // MOM_BIN_CHUNKS: 256-Gaussian chunks per workgroup (measurement)
+        if (forced < 0) { const char* e = getenv("MOM_BIN_CHUNKS"); forced = e ? atoi(e) : 0; }
+        if (forced > 0) chunks = forced;
+    }
     const int blocks = (a->P + 256 * chunks - 1) / (256 * chunks);
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
     const uint32_t tag = a->overflow_tag ? a->overflow_tag : 1u;

@@ -5,7 +5,7 @@
 // -ffp-contract=off: radii, tile rectangles and the depth sort keys must be
 // bit-identical to an IEEE evaluation of the reference's expressions in source
 // order (fp64 ndc2Pix, truncating casts, un-normalised quaternion), and they are.
-#include "mom_common.h"
+#include "raster_bin_dev.h"
 
 namespace {
 
@@ -47,21 +47,35 @@ struct PreArgs {
     const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *view, *proj, *cam;  // device pointers, [16] [16] [3]
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
+    // HIST: the tile histogram of the binning rides in this kernel (rows [ry0, ry1) of tiles, cull as MomRasterArgs.keep_all_tiles)
+    int ry0, ry1, cull;
+    uint32_t* tile_counts;
+    unsigned long long* reach;
 };
 
 // STAGED: the higher-order SH coefficients of the workgroup's 256 Gaussians -- (M-1)*3 floats each, contiguous in memory --
 // are copied to LDS with coalesced 16-byte loads and each thread then reads its own row from there (row stride odd: no
 // bank conflicts).  Read in place, a thread's 180-byte row makes every load instruction touch 64 different cache lines.
-template <bool STAGED>
+// HIST: after the projection every wave decides which (splat, tile) instances of its 64 Gaussians are binned (decide_instances,
+// raster_bin_dev.h: the reach test of the tile cull), counts them per tile in an LDS histogram behind the SH rows, leaves the
+// decisions as a 64-bit mask per Gaussian and the workgroup flushes its histogram with one global atomic per non-empty tile --
+// what tile_hist_kernel did in a launch of its own (27 us at 200 k Gaussians, most of it waiting for the records this kernel
+// still holds in registers).  The caller clears the header and the counters with a fill command in front of this kernel.
+template <bool STAGED, bool HIST>
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __restrict__ radii, float4* __restrict__ rec,
                                                             float* __restrict__ cov3Ds, uchar4* __restrict__ clamped,
-                                                            uint32_t* __restrict__ zero_words, int n_zero)
+                                                            uint32_t* __restrict__ zero_words, int n_zero, int sh_floats)
 {
     extern __shared__ float s_sh[];
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_sh + sh_floats);
     const int idx = blockIdx.x * 256 + threadIdx.x;
     // the image scratch's header and tile counters, which the binning kernels behind this one accumulate into, are cleared
-    // here instead of by a fill launch of their own
-    for (int i = idx; i < n_zero; i += gridDim.x * 256) zero_words[i] = 0u;
+    // here instead of by a fill launch of their own (not with HIST: this kernel then accumulates into them itself)
+    if (!HIST)
+        for (int i = idx; i < n_zero; i += gridDim.x * 256) zero_words[i] = 0u;
+    const int n_tiles = a.gx * a.gy;
+    if (HIST)
+        for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0u;
     const int sh_stride = (a.M - 1) * 3;
     if (STAGED) {
         const int block0 = blockIdx.x * 256;
@@ -71,8 +85,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
         for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(s_sh)[i] = reinterpret_cast<const float4*>(src)[i];
         for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) s_sh[i] = src[i];
         __syncthreads();
+    } else if (HIST) {
+        __syncthreads();
     }
-    if (idx >= a.P) return;
+    if (!HIST && idx >= a.P) return;
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
     const float* __restrict__ cam = a.cam;
@@ -81,14 +97,17 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
     uint32_t tiles = 0;
     float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
     uchar4 cl = {0, 0, 0, 0};
+    int hx0 = 0, hy0 = 0, hx1 = 0, hy1 = 0;        // the rectangle of tiles (HIST)
+    const bool live = idx < a.P;
+    const int gi = live ? idx : 0;                 // lanes past the end (HIST keeps them for the ballots) read Gaussian 0 and discard
 
-    const float px = a.means3D[3 * idx], py = a.means3D[3 * idx + 1], pz = a.means3D[3 * idx + 2];
+    const float px = a.means3D[3 * gi], py = a.means3D[3 * gi + 1], pz = a.means3D[3 * gi + 2];
     // near cull: keep iff p_view.z > 0.2
     const float vx = view[0] * px + view[4] * py + view[8] * pz + view[12];
     const float vy = view[1] * px + view[5] * py + view[9] * pz + view[13];
     const float vz = view[2] * px + view[6] * py + view[10] * pz + view[14];
     do {
-        if (vz <= 0.2f) break;
+        if (!live || vz <= 0.2f) break;
         const float hx = proj[0] * px + proj[4] * py + proj[8] * pz + proj[12];
         const float hy = proj[1] * px + proj[5] * py + proj[9] * pz + proj[13];
         const float hw = proj[3] * px + proj[7] * py + proj[11] * pz + proj[15];
@@ -98,15 +117,15 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
         float c3[6];
         if (a.cov3D_precomp != nullptr) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * idx + i];
+            for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * gi + i];
         } else {
             const float mod = a.scale_modifier;
             M3 S = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
-            S.m[0][0] = mod * a.scales[3 * idx];
-            S.m[1][1] = mod * a.scales[3 * idx + 1];
-            S.m[2][2] = mod * a.scales[3 * idx + 2];
-            const float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
-                        z = a.rotations[4 * idx + 3];
+            S.m[0][0] = mod * a.scales[3 * gi];
+            S.m[1][1] = mod * a.scales[3 * gi + 1];
+            S.m[2][2] = mod * a.scales[3 * gi + 2];
+            const float r = a.rotations[4 * gi], x = a.rotations[4 * gi + 1], y = a.rotations[4 * gi + 2],
+                        z = a.rotations[4 * gi + 3];
             M3 Rm = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                       {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
                       {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
@@ -116,7 +135,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             c3[3] = Sg.m[1][1]; c3[4] = Sg.m[1][2]; c3[5] = Sg.m[2][2];
             if (cov3Ds) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) cov3Ds[6 * idx + i] = c3[i];
+                for (int i = 0; i < 6; i++) cov3Ds[6 * gi + i] = c3[i];
             }
         }
 
@@ -157,9 +176,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             dx = dx / len; dy = dy / len; dz = dz / len;
             // coefficient i of this Gaussian: one [P,M,3] tensor, or DC and rest stored apart
-            const float* sh0 = a.shs + (size_t)idx * (a.shs_rest ? 1 : a.M) * 3;
+            const float* sh0 = a.shs + (size_t)gi * (a.shs_rest ? 1 : a.M) * 3;
             const float* sh = STAGED ? s_sh + threadIdx.x * sh_stride - 3
-                                     : (a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0);   // sh[3*i+c] valid for i >= 1
+                                     : (a.shs_rest ? a.shs_rest + (size_t)gi * (a.M - 1) * 3 - 3 : sh0);   // sh[3*i+c] valid for i >= 1
             float res[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -187,20 +206,40 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             cl.x = res[0] < 0; cl.y = res[1] < 0; cl.z = res[2] < 0;
             cr = fmaxf(res[0], 0.0f); cg = fmaxf(res[1], 0.0f); cb = fmaxf(res[2], 0.0f);
         } else {
-            cr = a.colors_precomp[3 * idx]; cg = a.colors_precomp[3 * idx + 1]; cb = a.colors_precomp[3 * idx + 2];
+            cr = a.colors_precomp[3 * gi]; cg = a.colors_precomp[3 * gi + 1]; cb = a.colors_precomp[3 * gi + 2];
         }
         radius = (int)my_radius;
         tiles = cnt;
+        hx0 = x0; hy0 = y0; hx1 = x1; hy1 = y1;
         r0 = make_float4(pix, piy, vz, __uint_as_float(tiles));
-        r1 = make_float4(conx, cony, conz, a.opacities[idx]);
+        r1 = make_float4(conx, cony, conz, a.opacities[gi]);
         r2 = make_float4(cr, cg, cb, __int_as_float(radius));
     } while (0);
 
-    radii[idx] = radius;
-    rec[3 * (size_t)idx + 0] = r0;
-    rec[3 * (size_t)idx + 1] = r1;
-    rec[3 * (size_t)idx + 2] = r2;
-    if (clamped) clamped[idx] = cl;
+    if (live) {
+        radii[idx] = radius;
+        rec[3 * (size_t)idx + 0] = r0;
+        rec[3 * (size_t)idx + 1] = r1;
+        rec[3 * (size_t)idx + 2] = r2;
+        if (clamped) clamped[idx] = cl;
+    }
+    if (HIST) {
+        // exactly what load_rect + tile_hist_kernel made of the stored record (raster_binning.hip): the rectangle cut to this
+        // launch's tile rows, the reach parameters from the conic and the opacity
+        hy0 = max(hy0, a.ry0);
+        hy1 = min(hy1, a.ry1);
+        if (hy1 <= hy0 || radius <= 0) hx0 = hy0 = hx1 = hy1 = 0;
+        Reach rc = Reach{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+        if (a.cull && radius > 0 && r1.x > 0.f && r1.z > 0.f)
+            rc = Reach{r0.x, r0.y, r1.x, r1.y, r1.z, mom_power_bound(r1.w), __builtin_amdgcn_rcpf(r1.x), __builtin_amdgcn_rcpf(r1.z), 1};
+        const uint64_t mask = decide_instances(hx0, hy0, hx1, hy1, a.gx, rc, [&](int tile) { atomicAdd(&s_cnt[tile], 1u); });
+        if (live) a.reach[idx] = mask;
+        __syncthreads();
+        for (int t = threadIdx.x; t < n_tiles; t += 256) {
+            const uint32_t n = s_cnt[t];
+            if (n) atomicAdd(&a.tile_counts[t], n);
+        }
+    }
 }
 
 __global__ void mark_visible_kernel(int P, const float* __restrict__ means, const float* __restrict__ view,
@@ -214,8 +253,10 @@ __global__ void mark_visible_kernel(int P, const float* __restrict__ means, cons
 
 }  // namespace
 
-// host launcher (called from raster_api.hip)
-int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, uint32_t* zero_words, int n_zero, hipStream_t s)
+// host launcher (called from raster_api.hip).  hist_counts / hist_reach non-null: the tile histogram rides in the projection kernel
+// (the caller has cleared the counters); *did_hist tells the binning whether it still has to run tile_hist_kernel.
+int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* radii, uint32_t* zero_words, int n_zero,
+                              uint32_t* hist_counts, bool* did_hist, hipStream_t s)
 {
     PreArgs p;
     p.P = a->P; p.D = a->D; p.M = a->M; p.W = a->W; p.H = a->H;
@@ -228,18 +269,45 @@ int mom_launch_preprocess_fwd(const MomRasterArgs* a, const GeomView& g, int* ra
     p.focal_y = a->H / (2.0f * a->tan_fovy);
     p.focal_x = a->W / (2.0f * a->tan_fovx);
     p.view = a->viewmatrix; p.proj = a->projmatrix; p.cam = a->campos;
+    mom_tile_rows(a, p.gy, &p.ry0, &p.ry1);
+    p.cull = a->keep_all_tiles ? 0 : 1;
+    p.tile_counts = hist_counts;
+    p.reach = g.reach;
     const int blocks = (a->P + 255) / 256;
-    MomProfScope ps(MOM_P_PRE_FWD, s);
     // staged SH rows: DC and rest stored apart, colours from SH above degree 0, an odd row length, 16-byte aligned rows
     const int sh_stride = (a->M - 1) * 3;
     const bool staged = a->shs_rest && !a->colors_precomp && a->D > 0 && (sh_stride & 1) && sh_stride <= 45 &&
                         ((uintptr_t)a->shs_rest & 15) == 0;
-    if (staged)
-        hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3(blocks), dim3(256), (size_t)256 * sh_stride * 4, s, p, radii, g.rec,
-                           a->forward_only ? nullptr : g.cov3D, a->forward_only ? nullptr : g.clamped, zero_words, n_zero);
-    else
-        hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3(blocks), dim3(256), 0, s, p, radii, g.rec,
-                           a->forward_only ? nullptr : g.cov3D, a->forward_only ? nullptr : g.clamped, zero_words, n_zero);
+    const int tiles = p.gx * p.gy;
+    const int sh_floats = staged ? 256 * sh_stride : 0;
+    // the histogram needs its counters in LDS beside the SH rows (45 KB): images up to 16 k tiles (e.g. 2048 x 2048)
+    const bool hist = hist_counts != nullptr && tiles <= kMaxLdsTiles && (size_t)(sh_floats + tiles) * 4 <= 64 * 1024 + 46 * 1024;
+    if (did_hist) *did_hist = hist;
+    const size_t lds = (size_t)(sh_floats + (hist ? tiles : 0)) * 4;
+    MomProfScope ps(MOM_P_PRE_FWD, s);
+    float* cov = a->forward_only ? nullptr : g.cov3D;
+    uchar4* cl = a->forward_only ? nullptr : g.clamped;
+    if (hist) {
+        // the header and the tile counters: one fill command in front (this kernel adds into the counters itself)
+        if (hipMemsetAsync(zero_words, 0, (size_t)n_zero * 4, s) != hipSuccess) return MOM_ELAUNCH;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_fwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    112 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_fwd_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    112 * 1024) != hipSuccess)
+                return MOM_ELAUNCH;
+            attr_set = true;
+        }
+        if (staged)
+            hipLaunchKernelGGL((preprocess_fwd_kernel<true, true>), dim3(blocks), dim3(256), lds, s, p, radii, g.rec, cov, cl, zero_words, n_zero, sh_floats);
+        else
+            hipLaunchKernelGGL((preprocess_fwd_kernel<false, true>), dim3(blocks), dim3(256), lds, s, p, radii, g.rec, cov, cl, zero_words, n_zero, sh_floats);
+    } else if (staged) {
+        hipLaunchKernelGGL((preprocess_fwd_kernel<true, false>), dim3(blocks), dim3(256), lds, s, p, radii, g.rec, cov, cl, zero_words, n_zero, sh_floats);
+    } else {
+        hipLaunchKernelGGL((preprocess_fwd_kernel<false, false>), dim3(blocks), dim3(256), 0, s, p, radii, g.rec, cov, cl, zero_words, n_zero, sh_floats);
+    }
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

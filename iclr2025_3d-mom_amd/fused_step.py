@@ -32,15 +32,22 @@ class FusedStep:
         self.dist = None      # parallel.DistContext (camera-batch shard): set by parallel.attach()
 
     # ------------------------------------------------------------------ buffers (re-made when P changes)
+    def _rows(self, P):
+        """Rows of the per-Gaussian buffers a tile-row shard gathers: world x S (DistContext.slice_rows), else P."""
+        dc = self.dist
+        return dc.world * dc.slice_rows(P) if (dc is not None and dc.mode == "tile-row") else P
+
     def _ensure(self, P, W, H, dev):
-        if P == self.P and getattr(self, "_wh", None) == (W, H):
+        if P == self.P and getattr(self, "_wh", None) == (W, H) and getattr(self, "_pad", None) == self._rows(P):
             return
         self.P, self._wh = P, (W, H)
+        Pp = self._pad = self._rows(P)
         f = dict(dtype=torch.float32, device=dev)
         e = lambda *s: torch.empty(*s, **f)
         self.feat, self.a0, self.dfeat = e(P, 64), e(P, 64), e(P, 64)
-        self.pts, self.sc_d, self.rot_d = e(P, 3), e(P, 3), e(P, 4)
-        self.sc, self.rot, self.op = e(P, 3), e(P, 4), e(P, 1)
+        # (the gathered buffers of a tile-row shard carry world x S >= P rows; every kernel reads the first P)
+        self.pts, self.sc_d, self.rot_d = e(Pp, 3), e(P, 3), e(Pp, 4)
+        self.sc, self.rot, self.op = e(Pp, 3), e(Pp, 4), e(Pp, 1)
         self.color, self.depth = e(3, H, W), e(1, H, W)
         self.radii = torch.empty(P, dtype=torch.int32, device=dev)
         self.geom = torch.empty(self.lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
@@ -108,11 +115,12 @@ class FusedStep:
         dn = self.g._deformation.deformation_net
         planes = [p for lv in dn.grid.grids for p in lv]
         mlp = dn._fused_params()
-        key = tuple(p.data_ptr() for p in planes + mlp) + (self.P,)
+        key = tuple(p.data_ptr() for p in planes + mlp) + (self.P, self._pad)
         if getattr(self, "_dg_key", None) != key:
-            n = sum(p.numel() for p in planes + mlp)
-            self._dg_flat = torch.zeros(n + 3 * self.P, dtype=torch.float32, device=planes[0].device)   # the `late` bucket
-            self.gxyz = self._dg_flat[n:].view(self.P, 3)
+            n = self._dg_n = sum(p.numel() for p in planes + mlp)
+            self._dg_flat = torch.zeros(n + 3 * self._pad, dtype=torch.float32, device=planes[0].device)   # the `late` bucket
+            self.gxyz_rows = self._dg_flat[n:].view(self._pad, 3)
+            self.gxyz = self.gxyz_rows[:self.P]
             off, self._dg_planes, self._dg_mlp = 0, [], []
             for p in planes:       # same channel-last strides as the parameter
                 st = ops.plane_storage(p)
@@ -164,8 +172,26 @@ class FusedStep:
         hp, keep, md = self._desc
         coef = float(delta_scale * cam.frame_num)
         # HexPlane lookup + MLP + the activations (exp / normalize / sigmoid) in one kernel (csrc/deform_field.hip)
-        ops.field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, self.pts, self.sc_d, self.rot_d, self.feat, self.a0,
-                          opac, self.sc, self.rot, self.op, s)
+        dc = self.dist
+        sl = None
+        if dc is not None and dc.mode == "tile-row":
+            # the deformation field is half of a step and does not care which rank computes which Gaussian: every rank takes a
+            # contiguous slice [g0, g1) of them, forward and backward, and the ranks all-gather the deformed state (what the
+            # replicated projection needs of ALL Gaussians: 15 floats each) while nothing else is in flight
+            S = dc.slice_rows(P)
+            g0 = min(P, dc.rank * S)
+            g1 = min(P, g0 + S)
+            sl = (S, g0, g1)
+            if g1 > g0:
+                v = lambda t: t[g0:g1]
+                so = field._slice_order(xyz, g0, g1)
+                ops.field_forward(hp, md, g1 - g0, v(xyz), time, so, v(scal), v(rot), v(flow), coef, v(self.pts), v(self.sc_d),
+                                  v(self.rot_d), v(self.feat), v(self.a0), v(opac), v(self.sc), v(self.rot), v(self.op), s)
+            dc.start_gather([self.pts, self.sc, self.rot, self.op, self.rot_d], S)
+            dc.finish()
+        else:
+            ops.field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, self.pts, self.sc_d, self.rot_d, self.feat, self.a0,
+                              opac, self.sc, self.rot, self.op, s)
         # ---- rasterizer forward (async: capacity from the previous iterations, checked below)
         a = N.MomRasterArgs()
         a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H
@@ -182,7 +208,6 @@ class FusedStep:
         if fuse_l1:      # L1 (its gradient image and its sums) in the compositing kernel's epilogue; a row shard forms it per slab below
             a.l1_target, a.l1_grad, a.l1_sums = gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr()
         a.overflow_tag = self.next_tag          # what this step leaves in the sticky word if its binning overflows (Trainer numbers the steps)
-        dc = self.dist
         rows = fwd_rows = None
         if dc is not None and dc.mode == "tile-row":
             # every rank renders this same camera, restricted to its rows of 16-pixel tiles.  With the SSIM term the forward
@@ -217,6 +242,9 @@ class FusedStep:
         # camera-batch shard: the batch loss is the mean over the ranks' cameras (train_4DGS.py:189-229), so every
         # gradient carries 1/world and the all-reduces below are plain sums (1/2, 1/4, 1/8 are exact in fp32)
         inv_world = 1.0 / dc.world if (dc is not None and dc.mode == "camera") else 1.0
+        # tile-row shard: the ranks' deformation gradients are SUMMED (each holds its slice's share); the regulariser's gradient,
+        # which every rank computes in full, must enter that sum once
+        reg_scale = 1.0 / dc.world if dc is not None else 1.0
         lam = float(self.opt.lambda_dssim)
         if lam != 0:
             # loss += lambda_dssim * (1 - ssim(image, gt))  (train_4DGS.py:222-223): its gradient is added into dimg
@@ -303,21 +331,43 @@ class FusedStep:
         if self.side is None:
             self.side = torch.cuda.Stream(device=dev)
         side = self.side.cuda_stream if self.OVERLAP_DW else s
-        N.check(lib.mom_deform_backward_split(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
-                                              d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
-                                              self.dh_scratch.data_ptr(), s, side), "deform_bwd")
-        if porders is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (P, hp.levels)):
-            self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
-            self._hex_scratch_key = (P, hp.levels)
-        N.check(lib.mom_hexplane_backward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.dfeat.data_ptr(),
-                                          self.gxyz.data_ptr(), None if porders is None else porders[0].data_ptr(),
-                                          None if porders is None else porders[1].data_ptr(),
-                                          None if porders is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
+        if sl is None:
+            N.check(lib.mom_deform_backward_split(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
+                                                  d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
+                                                  self.dh_scratch.data_ptr(), s, side), "deform_bwd")
+            if porders is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (P, hp.levels)):
+                self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
+                self._hex_scratch_key = (P, hp.levels)
+            N.check(lib.mom_hexplane_backward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.dfeat.data_ptr(),
+                                              self.gxyz.data_ptr(), None if porders is None else porders[0].data_ptr(),
+                                              None if porders is None else porders[1].data_ptr(),
+                                              None if porders is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
+        else:
+            # tile-row shard: the deformation backward of this rank's slice only.  Its weight / plane gradients are partial sums
+            # (summed over the ranks below); its position gradients complete gxyz for the slice's rows, which the ranks then
+            # all-gather -- the other rows hold d pts only, replicated by the projection backward.
+            S, g0, g1 = sl
+            ns = g1 - g0
+            if ns > 0:
+                v = lambda t: t[g0:g1]
+                N.check(lib.mom_deform_backward_split(C.byref(md), ns, v(self.feat).data_ptr(), v(self.a0).data_ptr(),
+                                                      v(self.gxyz).data_ptr(), v(d_sc).data_ptr(), v(d_rot).data_ptr(),
+                                                      v(self.dfeat).data_ptr(), self.dh_scratch.data_ptr(), s, side), "deform_bwd")
+                so = field._slice_order(xyz, g0, g1)
+                spo = field._slice_plane_orders(xyz, g0, g1)
+                if spo is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (ns, hp.levels)):
+                    self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), ns), dtype=torch.uint8, device=dev)
+                    self._hex_scratch_key = (ns, hp.levels)
+                N.check(lib.mom_hexplane_backward(C.byref(hp), ns, v(xyz).data_ptr(), None, time, None if so is None else so.data_ptr(),
+                                                  v(self.dfeat).data_ptr(), v(self.gxyz).data_ptr(),
+                                                  None if spo is None else spo[0].data_ptr(), None if spo is None else spo[1].data_ptr(),
+                                                  None if spo is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
+            dc.start_gather([self.gxyz_rows], S)
         # ---- plane regularisers (value + gradient added into the plane gradients)
         hy = self.hyper
         reg = None
         if hy.time_smoothness_weight != 0:
-            rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, inv_world)
+            rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, reg_scale)
             if self._reg_arr is None or self._reg_arr[0] != rkey:
                 arr = (N.MomRegPlane * len(planes))()
                 for i, p in enumerate(planes):
@@ -327,7 +377,7 @@ class FusedStep:
                     tplane = (i % 6) in (2, 4, 5)
                     arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
                     arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
-                    arr[i].grad_scale = inv_world      # identical on every rank: the sum over ranks restores it
+                    arr[i].grad_scale = reg_scale      # identical on every rank: the sum over ranks restores it
                 self._reg_arr = (rkey, arr)
             arr = self._reg_arr[1]
             N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
@@ -336,6 +386,9 @@ class FusedStep:
             torch.cuda.current_stream().wait_stream(self.side)
         if dc is not None and dc.mode == "camera":
             dc.start(self._dg_flat, "sum")     # xyz + deformation field; the caller waits (DistContext.finish) before Adam
+        elif sl is not None:
+            dc.start(self._dg_flat[:self._dg_n], "sum")     # the deformation field's gradients: the slices' shares (and the regulariser's, once)
+            dc.finish()
         # ---- hand the gradients to the parameters
         for p, gbuf in ((g._xyz, self.gxyz), (g._features_dc, self.gdc), (g._features_rest, self.grest), (g._scaling, self.gsc),
                         (g._rotation, self.grot), (g._opacity, self.gop)):

@@ -61,8 +61,11 @@ def split_rows(n_rows, world, weights=None):
 
 class DistContext:
     """mode "camera": every rank renders its own camera of the step (the reference's batch axis).
-    mode "tile-row": every rank renders the SAME camera, restricted to its tile rows; the per-Gaussian record of the
-    compositing backward is summed across ranks and everything after it is replicated (fused step only)."""
+    mode "tile-row": every rank renders the SAME camera, restricted to its tile rows, and runs the deformation field (HexPlane +
+    MLP, forward and backward: half of a step) on its own SLICE of the Gaussians.  Exchanges per step: all-gather of the
+    deformed state (15 floats per Gaussian), sum of the compositing backward's per-Gaussian record (12 floats), all-gather of
+    the position gradients (3 floats), sum of the deformation field's gradients (2.9 M floats); projection, its backward, the
+    activations and Adam run replicated on identical inputs and stay bit-identical (fused step only)."""
 
     def __init__(self, rank, world, seed=6666, mode="camera"):
         if mode not in ("camera", "tile-row"):
@@ -96,6 +99,24 @@ class DistContext:
         self.row_weights = [float(x) + 1.0 for x in total.tolist()]     # +1: an empty row still costs a launch slot
         self.steps_since_rebalance = 0
         return self.rows(n_rows) != before
+
+    def slice_rows(self, P):
+        """Rows per rank of the Gaussian-sharded part of a tile-row step: ceil(P / world) rounded up to a whole tile of 32
+        (the deformation kernels work on tiles of 32 Gaussians).  Rank r owns rows [r S, min((r + 1) S, P)); the per-Gaussian
+        buffers that are gathered hold world x S rows."""
+        return ((P + self.world - 1) // self.world + 31) // 32 * 32
+
+    def start_gather(self, tensors, S):
+        """Begin the in-place all-gather of every tensor in `tensors` ([world * S, k] rows, contiguous): this rank's rows
+        [rank S, (rank + 1) S) are valid going in, all rows coming out of finish()."""
+        for t in tensors:
+            if not t.is_contiguous() or t.shape[0] != self.world * S:
+                raise ValueError("start_gather(): needs contiguous [world * S, k] buffers")
+            own = t[self.rank * S:(self.rank + 1) * S]
+            if dist.get_backend() == "nccl":
+                self._pending.append(dist.all_gather_into_tensor(t, own, async_op=True))
+            else:                                   # gloo (tests): list form, no aliasing of input and output
+                self._pending.append(dist.all_gather([t[r * S:(r + 1) * S] for r in range(self.world)], own.clone(), async_op=True))
 
     _OPS = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}
 

@@ -118,5 +118,29 @@ class HexPlaneField(nn.Module):
             self._porders_key = tuple(self.aabb_host())
         return self._porders
 
+    def _slice_order(self, pts, g0, g1):
+        """Morton order of the points [g0, g1) (positions relative to g0): what a rank of a tile-row shard, which runs the
+        field on its slice of the Gaussians only, hands to the kernels.  Cached like the whole-cloud order."""
+        if not hasattr(ops.BACKEND, "morton_order") or g1 <= g0:
+            return None
+        c = getattr(self, "_sl_order", None)
+        key = (g0, g1, pts.device)
+        if c is None or c[0] != key or c[2] >= self.REORDER_EVERY:
+            c = self._sl_order = [key, ops.BACKEND.morton_order(pts[g0:g1]), 0]
+            self._sl_porders = None
+        c[2] += 1
+        return c[1]
+
+    def _slice_plane_orders(self, pts, g0, g1):
+        """Per-space-plane orders of the slice [g0, g1) for the two-pass backward; rebuilt with _slice_order (call it first)."""
+        if not hasattr(ops.BACKEND, "hexplane_orders") or g1 <= g0 or not pts.is_cuda:
+            return None
+        key = (g0, g1, tuple(self.aabb_host()))
+        po = getattr(self, "_sl_porders", None)
+        if po is None or po[0] != key:
+            po = self._sl_porders = (key, ops.BACKEND.hexplane_orders(pts[g0:g1], [list(g) for g in self.grids], self.aabb,
+                                                                     aabb_host=self.aabb_host()))
+        return po[1]
+
     def forward(self, pts: torch.Tensor, timestamps=None):
         return self.get_density(pts, timestamps)

@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 @pytest.mark.parametrize("lambda_dssim", [0.0, 0.2])
 def test_config4_tile_row_x8_at_200k_960x540(lambda_dssim):
     import bench
-    from test_fused_step_gpu import _RowRank
+    from virtual_ranks import VirtualWorld
     par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
     cfg = bench.CONFIGS["c2"]
     scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=True, lambda_dssim=lambda_dssim)
@@ -36,19 +36,20 @@ def test_config4_tile_row_x8_at_200k_960x540(lambda_dssim):
 
     def run(dist):
         fs.dist = dist
+        fs.exact_next()
         loss, radii, g2d = fs.forward_backward(cam, 1)
         torch.cuda.synchronize()
         assert int(fs.flags[0]) == 0
         return {"loss": float(loss), "radii": radii.clone(), "g2d": g2d.clone(), "early": fs.early.clone(),
-                "late": fs._dg_flat.clone(), "mse": float(fs.last["mse_sum"]), "R": int(fs.nr_host[0])}
+                "late": fs._dg_flat[:fs._dg_n + 3 * cfg["P"]].clone(), "mse": float(fs.last["mse_sum"]), "R": int(fs.nr_host[0])}
 
     want = run(None)
-    first = [_RowRank(r, world) for r in range(world)]
-    local_R = []
-    for d in first:
-        fs.exact_next()
-        local_R.append(run(d)["R"])
-        assert len(d.captured) == 2
+    full_rec = fs._gacc_view(cfg["P"], cfg["W"], cfg["H"]).clone()
+    vw = VirtualWorld(world)
+    results, ranks = vw.run(run)
+    # the ranks' Gaussian slices: 25 000 each (a multiple of 32: 25 024 rows per rank, the last one shorter)
+    assert ranks[0].slice_rows(cfg["P"]) == 25024
+    local_R = [r["R"] for r in results]
     # property: the ranks' instance counts partition the unsharded count (a splat's tile rectangle is cut by rows); with the
     # SSIM term every forward also bins its halo rows, so the counts overlap there
     if lambda_dssim == 0:
@@ -56,17 +57,11 @@ def test_config4_tile_row_x8_at_200k_960x540(lambda_dssim):
     else:
         assert want["R"] < sum(local_R) < 2 * want["R"], (local_R, want["R"])
     # property: the per-Gaussian records of the ranks sum to the unsharded record (linearity of the exchange)
-    fs.dist = None
-    fs.exact_next()
-    run(None)
-    full_rec = fs._gacc_view(cfg["P"], cfg["W"], cfg["H"]).clone()
-    rec_sum = sum(d.captured[0] for d in first)
+    kind, rec_sum = vw.resolved[1][0], vw.resolved[1][1][0]
+    assert kind == ("reduce", "sum")
     sc = float(full_rec.abs().max())
     assert float((rec_sum - full_rec).abs().max()) <= 3e-5 * sc
-    feed = [rec_sum, sum(d.captured[1] for d in first)]
-    for r in range(world):
-        fs.exact_next()
-        got = run(_RowRank(r, world, feed))
+    for r, got in enumerate(results):
         assert abs(got["loss"] - want["loss"]) <= 2e-6 * max(1.0, abs(want["loss"])), (r, got["loss"], want["loss"])
         assert abs(got["mse"] - want["mse"]) <= 2e-5 * abs(want["mse"])
         torch.testing.assert_close(got["radii"], want["radii"], rtol=0, atol=0)
@@ -74,6 +69,7 @@ def test_config4_tile_row_x8_at_200k_960x540(lambda_dssim):
             scale = float(want[k].abs().max())
             err = float((got[k] - want[k]).abs().max())
             assert torch.isfinite(got[k]).all() and err <= 5e-5 * scale + 1e-9, (r, k, err, scale)
+            assert torch.equal(got[k], results[0][k]), (r, k)          # replicas: the same bits on every rank
     fs.dist = None
 
 

@@ -128,51 +128,21 @@ def test_camera_batch_buckets_of_two_virtual_ranks_sum_to_the_batch_mean():
         assert float((got - want).abs().max()) <= 2e-5 * scale + 1e-9, (k, float((got - want).abs().max()), scale)
 
 
-class _RowRank:
-    """Stand-in for parallel.DistContext(mode="tile-row") on one GPU.  Pass 1 (feed=None) captures what the rank hands to
-    start(); pass 2 writes the sum over the ranks back into the buffer, which is what the all-reduce leaves there."""
-    mode = "tile-row"
+from virtual_ranks import VirtualWorld  # noqa: E402
 
-    def __init__(self, rank, world, feed=None, split=None, resplit=None):
-        self.rank, self.world, self.feed, self.captured, self.split = rank, world, feed, [], split
-        self.resplit = resplit          # a split to adopt at the first rebalance (the fused step's own rebalance branch)
-        self.row_counts = None
-
-    def rows(self, n_rows):
-        if self.split is not None:                           # an uneven split, as a rebalance would produce
-            return self.split[self.rank]
-        split = importlib.import_module("iclr2025_3d-mom_amd.parallel").split_rows
-        return split(n_rows, self.world)[self.rank]
-
-    def rebalance_due(self):
-        return self.resplit is not None
-
-    def rebalance_rows(self, own_row_counts):
-        self.row_counts = own_row_counts.clone()
-        before = self.rows(own_row_counts.shape[0])
-        self.split, self.resplit = self.resplit, None
-        return self.rows(own_row_counts.shape[0]) != before
-
-    def start(self, tensor, op="sum"):
-        if tensor.dtype == torch.int32 and tensor.numel() == 1:      # the sticky overflow word
-            assert op == "max"
-            return
-        assert op == "sum" and tensor.is_contiguous()
-        self.captured.append(tensor.clone())
-        if self.feed is not None:
-            tensor.copy_(self.feed[len(self.captured) - 1])
-
-    def finish(self):
-        pass
+# the collectives of one tile-row step, in order: deformed state (gather), compositing record (sum), position gradients (gather),
+# deformation gradients (sum), loss sums (sum)
+N_COLLECTIVES = 5
 
 
 @pytest.mark.parametrize("world,lambda_dssim,split", [(2, 0.0, None), (3, 0.0, None), (2, 0.2, None), (3, 0.2, None), (6, 0.2, None),
                                                       (3, 0.2, [(0, 1), (1, 5), (5, 6)]), (3, 0.0, [(0, 4), (4, 6), (6, 6)])])
 def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world, lambda_dssim, split):
-    """BASELINE config 4 on one GPU: `world` virtual ranks render the same camera, each its own tile rows, exchange the
-    per-Gaussian record of the compositing backward (and the loss sums), and must all end with the unsharded step's
-    gradients, statistics and loss.  With the SSIM term every rank also renders a one-tile-row halo and evaluates SSIM on
-    that slab (no pixels are exchanged); world 6 gives every rank a single tile row, so every boundary has a halo.  The
+    """BASELINE config 4 on one GPU: `world` virtual ranks take the same step -- each runs the deformation field on its slice of
+    the Gaussians and renders its own tile rows of the same camera; they exchange the deformed state, the per-Gaussian record of
+    the compositing backward, the position gradients, the deformation gradients and the loss sums -- and must all end with the
+    unsharded step's gradients, statistics and loss.  With the SSIM term every rank also renders a one-tile-row halo and evaluates
+    SSIM on that slab (no pixels are exchanged); world 6 gives every rank a single tile row, so every boundary has a halo.  The
     uneven splits are what a rebalance produces, one of them leaving the last rank without rows."""
     import bench
     cfg = dict(P=6000, F=4, W=160, H=96, time_res=10, name="tiny")            # 6 tile rows
@@ -184,18 +154,15 @@ def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world, l
         loss, radii, g2d = fs.forward_backward(cam, 1)
         torch.cuda.synchronize()
         return {"loss": float(loss), "radii": radii.clone(), "g2d": g2d.clone(), "early": fs.early.clone(),
-                "late": fs._dg_flat.clone(), "mse": float(fs.last["mse_sum"])}
+                "late": fs._dg_flat[:fs._dg_n + 3 * cfg["P"]].clone(), "mse": float(fs.last["mse_sum"]), "rows": None if dist is None else dist.rows(6)}
 
     want = run(None)
-    first = [_RowRank(r, world, split=split) for r in range(world)]
-    for d in first:
-        run(d)
-        assert len(d.captured) == 2                                   # the record, then the L1 slab sums
-    feed = [sum(d.captured[i] for d in first) for i in range(2)]
-    rows = [d.rows(6) for d in first]
+    vw = VirtualWorld(world, split=split)
+    results, ranks = vw.run(run)
+    assert len(vw.resolved) == N_COLLECTIVES and [k[0][0] for k in vw.resolved] == ["gather", "reduce", "gather", "reduce", "reduce"]
+    rows = [r["rows"] for r in results]
     assert rows[0][0] == 0 and rows[-1][1] == 6 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
-    for r in range(world):
-        got = run(_RowRank(r, world, feed, split=split))
+    for r, got in enumerate(results):
         assert abs(got["loss"] - want["loss"]) <= 1e-6 * max(1.0, abs(want["loss"])), (got["loss"], want["loss"])
         assert abs(got["mse"] - want["mse"]) <= 1e-5 * abs(want["mse"])
         torch.testing.assert_close(got["radii"], want["radii"], rtol=0, atol=0)
@@ -203,6 +170,10 @@ def test_tile_row_shard_of_the_fused_step_reproduces_the_unsharded_step(world, l
             scale = float(want[k].abs().max())
             err = float((got[k] - want[k]).abs().max())
             assert torch.isfinite(got[k]).all() and err <= 3e-5 * scale + 1e-9, (r, k, err, scale)
+    # every rank ends with the SAME bits where the step promises replicas: what Adam consumes
+    for got in results[1:]:
+        for k in ("g2d", "early", "late"):
+            assert torch.equal(got[k], results[0][k]), k
     fs.dist = None
 
 
@@ -216,31 +187,30 @@ def test_tile_row_rebalance_inside_the_step_keeps_the_gradients():
     fs, cam = trainer.fused, trainer.cams[2]
     world, old, new = 3, [(0, 2), (2, 4), (4, 6)], [(0, 1), (1, 5), (5, 6)]
 
-    def run(dist):
-        fs.dist = dist
-        loss, radii, g2d = fs.forward_backward(cam, 1)
-        torch.cuda.synchronize()
-        return {"loss": float(loss), "g2d": g2d.clone(), "early": fs.early.clone(), "late": fs._dg_flat.clone()}
-
-    want = run(None)
-    for splits, resplit in ((old, new), (new, None)):       # the rebalance iteration, then the one after it (new rows)
-        first = [_RowRank(r, world, split=list(splits), resplit=resplit) for r in range(world)]
-        for d in first:
+    want = None
+    for splits, resplit in ((None, None), (old, new), (new, None)):       # unsharded; the rebalance iteration; the one after it (new rows)
+        def run(dist):
+            fs.dist = dist
             fs._resize_next = resplit is None                 # the iteration after a re-split sizes its buffer exactly
-            run(d)
-            assert len(d.captured) == 2
+            loss, radii, g2d = fs.forward_backward(cam, 1)
+            torch.cuda.synchronize()
+            out = {"loss": float(loss), "g2d": g2d.clone(), "early": fs.early.clone(), "late": fs._dg_flat[:fs._dg_n + 3 * cfg["P"]].clone(),
+                   "resize_next": fs._resize_next}
+            return out
+        if splits is None:
+            want = run(None)
+            continue
+        results, ranks = VirtualWorld(world, split=list(splits), resplit=resplit).run(run)
+        for d, got in zip(ranks, results):
             if resplit is not None:
-                assert d.split == new and fs._resize_next    # adopted, and the NEXT step will re-size
+                assert d.split == new and got["resize_next"]    # adopted, and the NEXT step will re-size
                 own = d.row_counts
                 assert float(own.sum()) > 0 and float(own[:splits[d.rank][0]].sum()) == 0 and float(own[splits[d.rank][1]:].sum()) == 0
-        feed = [sum(d.captured[i] for d in first) for i in range(2)]
-        for r in range(world):
-            got = run(_RowRank(r, world, feed, split=list(splits), resplit=resplit))
             assert abs(got["loss"] - want["loss"]) <= 1e-6 * max(1.0, abs(want["loss"]))
             for k in ("g2d", "early", "late"):
                 scale = float(want[k].abs().max())
                 err = float((got[k] - want[k]).abs().max())
-                assert torch.isfinite(got[k]).all() and err <= 3e-5 * scale + 1e-9, (resplit is not None, r, k, err, scale)
+                assert torch.isfinite(got[k]).all() and err <= 3e-5 * scale + 1e-9, (resplit is not None, d.rank, k, err, scale)
     fs.dist = None
 
 

@@ -113,6 +113,51 @@ def test_async_bucket_all_reduce_world2(tmp_path):
     np.testing.assert_array_equal(a["radii"], b["radii"])
 
 
+def _run_gather(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    dc = par.DistContext(rank, world, mode="tile-row")
+    P = 1000                                            # 3 ranks: 352 rows each (a multiple of 32), the last rank owns 296
+    S = dc.slice_rows(P)
+    a = torch.full((world * S, 3), -1.0)
+    b = torch.full((world * S, 4), -1.0)
+    g0 = rank * S
+    a[g0:g0 + S] = torch.arange(S * 3, dtype=torch.float32).view(S, 3) + 10000 * rank
+    b[g0:g0 + S] = float(rank + 1)
+    red = torch.full((7,), float(rank + 1))
+    dc.start_gather([a, b], S)
+    dc.start(red, "sum")                                # a reduction in flight beside the gathers
+    dc.finish()
+    np.savez(out, S=S, a=a.numpy(), b=b.numpy(), red=red.numpy())
+    dist.destroy_process_group()
+
+
+def test_slice_gather_world3(tmp_path):
+    """DistContext.start_gather(): the in-place all-gather of row slices a tile-row shard uses for the deformed state and the
+    position gradients -- world 3, uneven last slice, beside an all-reduce, every rank ends with every rank's rows."""
+    port = 33500 + os.getpid() % 2000
+    outs = [str(tmp_path / f"g{r}.npz") for r in range(3)]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run_gather, args=(r, 3, port, outs[r])) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=250)
+        assert p.exitcode == 0
+    res = [np.load(o) for o in outs]
+    S = int(res[0]["S"])
+    assert S == 352
+    for r in res[1:]:
+        np.testing.assert_array_equal(r["a"], res[0]["a"])
+        np.testing.assert_array_equal(r["b"], res[0]["b"])
+    for k in range(3):
+        np.testing.assert_array_equal(res[0]["a"][k * S:(k + 1) * S], np.arange(S * 3, dtype=np.float32).reshape(S, 3) + 10000 * k)
+        assert (res[0]["b"][k * S:(k + 1) * S] == k + 1).all()
+        np.testing.assert_array_equal(res[k]["red"], np.full(7, 6.0, np.float32))
+
+
 def test_split_rows_partitions():
     """parallel.split_rows: contiguous, ordered, complete; balanced by weight; never (0, 0) for an empty range."""
     split = importlib.import_module("iclr2025_3d-mom_amd.parallel").split_rows

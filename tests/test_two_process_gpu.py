@@ -1,0 +1,54 @@
+"""parallel.DistContext across a REAL process boundary: two fresh processes share GPU 0, rendezvous
+over gloo on device tensors and run three fused training steps in both shard modes.  Checked: the two replicas end bit-identical
+(what "everything downstream is replicated" promises), and they end where a single process ends -- the unsharded step for the
+tile-row shard, a batch of the same two cameras per iteration for the camera-batch shard (the reference's batch_size semantics,
+train_4DGS.py:172-229).  RCCL itself is not involved (it refuses two ranks on one device); what this exercises is the step's
+ordering of start() / finish() around in-place asynchronous reductions of device buffers owned by another process's peer."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+launch = importlib.import_module("iclr2025_3d-mom_amd.launch")
+
+
+def _close_enough(a, b, name):
+    """Same model up to the order of float atomics, amplified by Adam's m / sqrt(v) on near-zero gradients for a few elements
+    (the bound of test_fused_step_gpu's overflow test)."""
+    scale = max(1e-12, float(b.abs().max()))
+    frac = float(((a - b).abs() > 1e-3 * scale + 1e-6).float().mean())
+    assert frac <= 2e-3, (name, frac)
+
+
+@pytest.mark.parametrize("mode", ["tile-row", "camera"])
+def test_two_processes_on_one_gpu_end_with_identical_replicas_and_the_single_process_model(mode, tmp_path):
+    import bench
+    import two_process_rank as R
+    prefix = str(tmp_path / f"snap_{mode}")
+    rc, out = launch.spawn_ranks(2, [sys.executable, os.path.join(ROOT, "tests", "two_process_rank.py"), mode, prefix], timeout=600)
+    assert rc == 0, out
+    a, b = torch.load(prefix + "_0.pt"), torch.load(prefix + "_1.pt")
+    diff = {k: float((a[k].float() - b[k].float()).abs().max()) for k in a if not torch.equal(a[k], b[k])}
+    assert not diff, f"replicas differ: {diff}"
+    # the same three iterations in ONE process
+    if mode == "tile-row":
+        scene, g, trainer, op = bench.build_state(R.CFG, torch.device("cuda"), fused=True, lambda_dssim=0.2)
+        for i in range(3):
+            trainer.step(5001 + i, cams=[trainer.cams[i % len(trainer.cams)]])
+        trainer.drain()
+    else:
+        scene, g, trainer, op = bench.build_state(R.CFG, torch.device("cuda"), fused=False, lambda_dssim=0.2)
+        op.batch_size = 2
+        for i in range(3):
+            trainer.step(5001 + i, cams=[trainer.cams[(2 * i) % len(trainer.cams)], trainer.cams[(2 * i + 1) % len(trainer.cams)]])
+    torch.cuda.synchronize()
+    want = {k: v.detach().cpu() for k, v in R.snapshot(g).items()}
+    assert torch.equal(a["denom"], want["denom"])
+    assert torch.equal(a["maxr"], want["maxr"])
+    for k in ("xyz", "opacity", "f_dc", "scaling", "plane_xy", "plane_xt", "w0", "accum"):
+        _close_enough(a[k], want[k], k)

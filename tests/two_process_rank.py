@@ -1,0 +1,49 @@
+"""One rank of tests/test_two_process_gpu.py: TWO real processes share GPU 0, rendezvous over gloo (which moves device tensors in
+this torch build; RCCL refuses two ranks on one device) and run three fused training steps through parallel.DistContext --
+start() / finish() with in-place asynchronous all-reduces of device buffers across a process boundary.
+usage: two_process_rank.py <camera|tile-row> <out prefix>"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import bench  # noqa: E402
+
+CFG = dict(P=20000, F=6, W=320, H=192, time_res=12, name="small")
+
+
+def snapshot(g):
+    dn = g._deformation.deformation_net
+    planes = [p for lv in dn.grid.grids for p in lv]
+    return {"xyz": g._xyz, "opacity": g._opacity, "f_dc": g._features_dc, "scaling": g._scaling, "plane_xy": planes[0],
+            "plane_xt": planes[2], "w0": dn._fused_params()[0], "accum": g.xyz_gradient_accum, "denom": g.denom,
+            "maxr": g.max_radii2D}
+
+
+def main():
+    mode, prefix = sys.argv[1], sys.argv[2]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    scene, g, trainer, op = bench.build_state(CFG, torch.device("cuda"), fused=True, lambda_dssim=0.2)
+    par.attach(trainer, rank, world, mode=mode)
+    cams = trainer.cams
+    for i in range(3):
+        cam = cams[(i * world + rank) % len(cams)] if mode == "camera" else cams[i % len(cams)]
+        trainer.step(5001 + i, cams=[cam])
+    trainer.drain()
+    torch.cuda.synchronize()
+    torch.save({k: v.detach().cpu() for k, v in snapshot(g).items()}, f"{prefix}_{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print("done", flush=True)
+
+
+if __name__ == "__main__":
+    main()
