@@ -121,7 +121,7 @@ def _sig(lib):
     lib.mom_deform_backward_split.argtypes = [C.POINTER(MomDeformMLP), i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_deform_field_supported.argtypes = [C.POINTER(MomHexPlane)]
     lib.mom_deform_field_scratch_bytes.restype = sz
-    lib.mom_deform_field_scratch_bytes.argtypes = [C.POINTER(MomHexPlane)]
+    lib.mom_deform_field_scratch_bytes.argtypes = [C.POINTER(MomHexPlane), i32]
     lib.mom_deform_field_forward.argtypes = [C.POINTER(MomHexPlane), C.POINTER(MomDeformMLP), i32, vp, C.c_float, vp, vp, vp, vp,
                                              C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_densify_stats.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp]

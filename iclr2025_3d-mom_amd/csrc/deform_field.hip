@@ -249,7 +249,7 @@ __device__ __forceinline__ void gather_tile(const HexArgs& a, const LineTab& lt,
     }
 #else
 #pragma unroll 1
-    for (int u = 0; u < 8; u++) {        // one pass in flight per wave (128 registers: two gather waves per SIMD make up for it)
+    for (int u = 0; u < 8; u++) {        // one pass in flight per wave
         UnitLoads LA;
         issue(u, LA);
         finish(u, LA);
@@ -479,6 +479,243 @@ deform_field_fwd_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float*
 #endif
 }
 
+// ---- the MLP on the bf16 matrix cores, fp32-exact operands --------------------------------------------------------------
+// v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and occupies the SIMD's vector ALU while it does (tools/probe/
+// mfma_valu_coissue.hip: MFMA-only and FMA-only waves on one SIMD take the SUM of their times), so an f32 MLP can neither beat
+// 157 TFLOP/s nor hide the gather's vector work behind its matrix work.  The bf16 pipe is 16 times faster and does co-issue.
+// Every fp32 operand is split EXACTLY into three bf16 pieces (x = x1 + x2 + x3: the top 8, the next 8 and the last 8 significant
+// bits, by masking -- no rounding anywhere) and a product is formed from the six piece products whose weight is at least
+// 2^-16 of the full one (x1 y1, x1 y2, x2 y1, x1 y3, x3 y1, x2 y2; the three dropped ones are below 2^-23 |x||y|, the size of
+// fp32's own rounding of the product).  Accumulation is fp32 inside the MFMA.  Six bf16 MFMAs of K = 16 replace eight f32
+// MFMAs of K = 2: 0.375 of the matrix cycles, and the vector ALU is free meanwhile.
+//
+// Layout: D = A B with A = weights (32 outputs x 16 inputs per MFMA), B = activations (16 inputs x 32 Gaussians).  K-step s of a
+// layer covers input features 16 s .. 16 s + 15 in the order k(h, j) = 16 s + 4 h + (j & 3) + 8 (j >> 2) for lane half h and
+// j = 0..7: exactly the eight accumulator registers 8 (s & 1) .. + 7 of output tile s >> 1 of the previous layer, so a layer's
+// B operand is its predecessor's accumulator, split in place, with no shuffle.  The weight fragments are prepared once per
+// workgroup in that order: wfrag[layer][piece][mt][s][lane] = 16 bytes = a lane's A operand, 96 KB of LDS in all.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef MOM_B3_WAVES
+#define MOM_B3_WAVES 12
+#endif
+constexpr int kB3Waves = MOM_B3_WAVES;
+constexpr int kL3Frag = 0;                              // uint4 [4 layers][3 pieces][2 mt][4 s][64 lanes]
+constexpr int kL3FragU4 = 4 * 3 * 2 * 4 * 64;
+constexpr int kL3Small = kL3FragU4 * 4;                 // floats from here: biases [4][64], W2 [3][4][64], b2 [16]
+constexpr int kL3B = kL3Small, kL3W2 = kL3B + 4 * kHid, kL3B2 = kL3W2 + 3 * 4 * kHid;
+constexpr int kL3Recs = kL3B2 + 16;
+constexpr int kL3Total = kL3Recs + kB3Waves * 64 * kRecDw;
+
+__device__ __forceinline__ uint32_t hi16(float x) { return __float_as_uint(x) & 0xFFFF0000u; }
+// (a, b) -> three dwords, piece p = bf16(a_p) | bf16(b_p) << 16
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t (&p)[3])
+{
+    const uint32_t a1 = hi16(a), b1 = hi16(b);
+    const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+    const uint32_t a2 = hi16(ra), b2 = hi16(rb);
+    const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+    p[0] = (a1 >> 16) | b1;
+    p[1] = (a2 >> 16) | b2;
+    p[2] = (__float_as_uint(sa) >> 16) | hi16(sb);
+}
+struct Frag3 {
+    uint4 p[3];            // the three pieces of eight values: an MFMA operand each
+};
+__device__ __forceinline__ Frag3 split8(const float (&v)[8])
+{
+    Frag3 f;
+    uint32_t q[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) split_pair(v[2 * j], v[2 * j + 1], q[j]);
+#pragma unroll
+    for (int p = 0; p < 3; p++) f.p[p] = make_uint4(q[0][p], q[1][p], q[2][p], q[3][p]);
+    return f;
+}
+// the B operand of the next layer: accumulator tile -> four K-steps of three pieces (RELU: through the ReLU first)
+template <bool RELU>
+__device__ __forceinline__ void split_tile(const f32x16 (&t)[2], Frag3 (&B)[4])
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float x = t[s >> 1][8 * (s & 1) + j];
+            v[j] = RELU ? fmaxf(x, 0.f) : x;
+        }
+        B[s] = split8(v);
+    }
+}
+__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc[mt] += W_layer x: 48 MFMAs, the smallest products first
+__device__ __forceinline__ void layer_b3(const uint4* __restrict__ wf /* [3][2][4][64] of this layer */, const Frag3 (&B)[4], f32x16 (&acc)[2], int lane)
+{
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint4 a1 = wf[((0 * 2 + mt) * 4 + s) * 64 + lane], a2 = wf[((1 * 2 + mt) * 4 + s) * 64 + lane],
+                        a3 = wf[((2 * 2 + mt) * 4 + s) * 64 + lane];
+            f32x16 c = acc[mt];
+            c = mfma16(a3, B[s].p[0], c);
+            c = mfma16(a1, B[s].p[2], c);
+            c = mfma16(a2, B[s].p[1], c);
+            c = mfma16(a2, B[s].p[0], c);
+            c = mfma16(a1, B[s].p[1], c);
+            c = mfma16(a1, B[s].p[0], c);
+            acc[mt] = c;
+        }
+}
+
+__global__ void __launch_bounds__(64 * kB3Waves)
+deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float* __restrict__ lines, const float* __restrict__ xyz,
+                           const float* __restrict__ scaling, const float* __restrict__ rotation, const float* __restrict__ flow,
+                           float flow_coef, float* __restrict__ pts, float* __restrict__ scales, float* __restrict__ rots,
+                           float* __restrict__ feat, float* __restrict__ a0_save, ActOut act)
+{
+    extern __shared__ float lds[];
+    uint4* wfrag = reinterpret_cast<uint4*>(lds + kL3Frag);
+    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    uint4* rec = reinterpret_cast<uint4*>(lds + kL3Recs + wv * 64 * kRecDw);
+    const int P = a.P;
+    const unsigned long long t_start = STAMP();
+    // ---- prologue: weight fragments (exact three-way split), biases, output layers
+    {
+        const float* Ws[4] = {m.W0, m.W1[0], m.W1[1], m.W1[2]};
+        const float* bs[4] = {m.b0, m.b1[0], m.b1[1], m.b1[2]};
+        for (int slot = threadIdx.x; slot < 4 * 2 * 4 * 64; slot += blockDim.x) {
+            const int L = slot >> 9, mt = (slot >> 8) & 1, s = (slot >> 6) & 3, ln = slot & 63;
+            const int row = 32 * mt + (ln & 31), k0 = 16 * s + 4 * (ln >> 5);
+            const float4 lo = *reinterpret_cast<const float4*>(Ws[L] + row * kHid + k0);
+            const float4 hi = *reinterpret_cast<const float4*>(Ws[L] + row * kHid + k0 + 8);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+            const Frag3 f = split8(v);
+#pragma unroll
+            for (int p = 0; p < 3; p++) wfrag[(((L * 3 + p) * 2 + mt) * 4 + s) * 64 + ln] = f.p[p];
+        }
+        for (int i = threadIdx.x; i < 4 * kHid; i += blockDim.x) lds[kL3B + i] = bs[i >> 6][i & 63];
+        for (int i = threadIdx.x; i < 3 * 4 * kHid; i += blockDim.x) {
+            const int head = i >> 8, n = (i >> 6) & 3, f = i & 63;
+            const int nout = head == 2 ? 4 : 3;
+            lds[kL3W2 + i] = n < nout ? m.W2[head][n * kHid + f] : 0.f;
+        }
+        if (threadIdx.x < 12) {
+            const int head = threadIdx.x >> 2, n = threadIdx.x & 3;
+            const int nout = head == 2 ? 4 : 3;
+            lds[kL3B2 + threadIdx.x] = n < nout ? m.b2[head][n] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
+    unsigned long long tg = 0, tb = 0, tl = 0, to = 0;
+    int n_t = 0;
+    const unsigned long long t_pro = STAMP();
+    for (int t = t_begin + wv; t < t_end; t += kB3Waves, n_t++) {
+        const int gi = t * 32 + col;
+        const int g = gi < P ? (a.order ? (int)a.order[gi] : gi) : -1;
+        const bool ok = g >= 0;
+        const unsigned long long s0 = STAMP();
+        // this Gaussian's inputs of the residual adds, requested now and used after the heads: loaded where they are used, each
+        // head paid a memory round trip (stamps: 4.4 k cycles per head for 150 vector instructions)
+        float in_xyz[3] = {0.f, 0.f, 0.f}, in_flow[3] = {0.f, 0.f, 0.f}, in_scal[3] = {0.f, 0.f, 0.f}, in_opac = 0.f;
+        float4 in_rot = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (h == 0 && ok) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                in_xyz[q] = xyz[3 * g + q];
+                in_flow[q] = flow[3 * g + q];
+                in_scal[q] = scaling[3 * g + q];
+            }
+            in_rot = *reinterpret_cast<const float4*>(rotation + 4 * g);
+            if (act.opacity) in_opac = act.opacity_raw[g];
+        }
+        // features: gathered eight lanes per (point, level), bounced through this wave's own rows of feat[P,64] (kept for the
+        // backward anyway) into the MFMA layout; the rows were written by this wave: visible to it after the wait
+        gather_tile(a, lt, lines, xyz, g, nullptr, rec, feat, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long s1 = STAMP();
+        Frag3 B[4];
+        {
+            f32x16 x[2];
+            load_feat(feat, g, ok, h, x);
+            split_tile<false>(x, B);
+        }
+#ifdef MOM_FIELD_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(B[0].p[0].x), "v"(B[3].p[2].w) : "memory");
+#endif
+        const unsigned long long s2 = STAMP();
+        f32x16 acc[2];
+        init_bias(lds + kL3B, acc, h);
+#ifndef MOM_B3_NOMFMA
+        layer_b3(wfrag, B, acc, lane);
+#else
+        acc[0][0] += __uint_as_float(B[0].p[0].x + B[3].p[2].w);
+#endif
+        relu_tile(acc);
+        if (a0_save) store_feat(a0_save, g, ok, h, acc);
+        Frag3 A0[4];
+        split_tile<false>(acc, A0);                       // already through the ReLU
+        tg += s1 - s0; tb += s2 - s1;
+#pragma nounroll
+        for (int head = 0; head < 3; head++) {
+            const unsigned long long s3 = STAMP();
+            f32x16 h1[2];
+            init_bias(lds + kL3B + (1 + head) * kHid, h1, h);
+#ifndef MOM_B3_NOMFMA
+            layer_b3(wfrag + (1 + head) * (3 * 2 * 4 * 64), A0, h1, lane);
+#else
+            h1[0][0] += __uint_as_float(A0[0].p[0].x + A0[3].p[2].w);
+#endif
+            relu_tile(h1);
+#ifdef MOM_FIELD_STAMPS
+            asm volatile("" :: "v"(h1[0][0]), "v"(h1[1][15]));
+#endif
+            const unsigned long long s4 = STAMP();
+            tl += s4 - s3;
+            float o[4];
+            out_layer(lds + kL3W2 + head * 4 * kHid, lds + kL3B2 + head * 4, h1, h, o);
+            if (h == 0 && ok) {
+                if (head == 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) pts[3 * g + q] = in_xyz[q] + (o[q] + flow_coef * in_flow[q]);
+                } else if (head == 1) {
+                    float s3[3];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+                        s3[q] = in_scal[q] + o[q];
+                        scales[3 * g + q] = s3[q];
+                    }
+                    if (act.scales) {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) act.scales[3 * g + q] = expf(s3[q]);
+                    }
+                } else {
+                    const float4 q4 = make_float4(in_rot.x + o[0], in_rot.y + o[1], in_rot.z + o[2], in_rot.w + o[3]);
+                    *reinterpret_cast<float4*>(rots + 4 * g) = q4;
+                    if (act.rots) {
+                        const float nq = mom_quat_norm(q4.x, q4.y, q4.z, q4.w);
+                        *reinterpret_cast<float4*>(act.rots + 4 * g) = make_float4(q4.x / nq, q4.y / nq, q4.z / nq, q4.w / nq);
+                    }
+                    if (act.opacity) act.opacity[g] = mom_sigmoid(in_opac);
+                }
+            }
+            to += STAMP() - s4;
+        }
+    }
+#ifdef MOM_FIELD_STAMPS
+    if (lane == 0) {
+        unsigned long long* d = g_field_dbg + ((size_t)blockIdx.x * 32 + wv) * 4;
+        d[0] = tg; d[1] = tb; d[2] = STAMP() - t_start; d[3] = n_t;
+        unsigned long long* e = g_field_dbg + ((size_t)blockIdx.x * 32 + 16 + wv) * 4;
+        e[0] = tl; e[1] = to; e[2] = t_pro - t_start; e[3] = 0;
+    }
+#endif
+}
+
 }  // namespace
 
 static int line_table(const MomHexPlane* hp, LineTab* lt)
@@ -492,11 +729,12 @@ static int line_table(const MomHexPlane* hp, LineTab* lt)
     return (int)off;
 }
 
-extern "C" size_t mom_deform_field_scratch_bytes(const MomHexPlane* hp)
+extern "C" size_t mom_deform_field_scratch_bytes(const MomHexPlane* hp, int P)
 {
     if (!hp) return MOM_ALIGN;
     LineTab lt;
-    return (size_t)line_table(hp, &lt) * sizeof(float) + MOM_ALIGN;
+    // the table of time lines, then a [P,64] feature buffer for calls that keep no copy of the features (feat_save == null)
+    return mom_align_up((size_t)line_table(hp, &lt) * sizeof(float)) + (size_t)(P > 0 ? P : 0) * kHid * sizeof(float) + 2 * MOM_ALIGN;
 }
 
 extern "C" int mom_deform_field_supported(const MomHexPlane* hp)
@@ -540,6 +778,26 @@ extern "C" int mom_deform_field_forward(const MomHexPlane* hp, const MomDeformML
     hipLaunchKernelGGL(hexplane_lines_kernel, dim3((nline + 255) / 256), dim3(256), 0, s, a, lt, lines, nline);
     const int tiles = (P + 31) / 32;
     const ActOut act = {scales_act, rots_act, opacity_act, opacity_raw};
+    static int mode = -1;                 // MOM_FIELD_MODE=f32: the f32-MFMA kernel (gather waves feeding MFMA waves; measurement)
+    if (mode < 0) {
+        const char* e = getenv("MOM_FIELD_MODE");
+        mode = (e && e[0] == 'f') ? 1 : 0;
+    }
+    if (mode == 0) {
+        float* feat = feat_save ? feat_save : (float*)mom_align_ptr((char*)lines + mom_align_up((size_t)nline * sizeof(float)));
+        const int blocks = tiles < 256 * kB3Waves ? (tiles + kB3Waves - 1) / kB3Waves : 256;
+        static bool attr_b3 = false;
+        const size_t lds_b3 = sizeof(float) * kL3Total;
+        if (!attr_b3) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_field_fwd_b3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_b3) != hipSuccess)
+                return MOM_ELAUNCH;
+            attr_b3 = true;
+        }
+        hipLaunchKernelGGL(deform_field_fwd_b3_kernel, dim3(blocks), dim3(64 * kB3Waves), lds_b3, s, a, lt, d, tiles, lines, xyz, scaling,
+                           rotation, scene_flow, flow_coef, pts, scales, rots, feat, a0_save, act);
+        return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+    }
     // one workgroup per CU (MFMA waves fed by gather waves); a small problem is spread over the CUs
     const int blocks = tiles < 256 * 4 ? (tiles + 3) / 4 : 256;
     static bool attr_set = false;

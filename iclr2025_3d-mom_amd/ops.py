@@ -154,9 +154,10 @@ FIELD_ORDER = _os.environ.get("MOM_FIELD_ORDER", "1") != "0"   # the fused kerne
 _field_scratch = {}
 
 
-def field_scratch(hp, device):
-    """The per-frame table of time lines of the fused deformation kernels (73 KB at the shipped resolutions), one per device."""
-    n = N.lib().mom_deform_field_scratch_bytes(C.byref(hp))
+def field_scratch(hp, device, P=0):
+    """Scratch of the fused deformation kernels, one per device: the per-frame table of time lines (73 KB at the shipped
+    resolutions) and, for calls that keep no copy of the features (P > 0: no-grad render()), a [P,64] feature buffer."""
+    n = N.lib().mom_deform_field_scratch_bytes(C.byref(hp), int(P))
     t = _field_scratch.get(device)
     if t is None or t.numel() < n:
         t = _field_scratch[device] = torch.empty(n, dtype=torch.uint8, device=device)
@@ -175,7 +176,7 @@ def field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, pts, sc_d,
                                              q(order) if FIELD_ORDER else None, scal.data_ptr(),
                                              rot.data_ptr(), flow.data_ptr(), float(coef), pts.data_ptr(), sc_d.data_ptr(),
                                              rot_d.data_ptr(), q(feat), q(a0), q(opac), q(sc), q(rot_act), q(op),
-                                             field_scratch(hp, xyz.device).data_ptr(), s), "deform_field_fwd")
+                                             field_scratch(hp, xyz.device, 0 if feat is not None else P).data_ptr(), s), "deform_field_fwd")
         return
     f = feat if feat is not None else scratch_feat
     N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, float(time), q(order), f.data_ptr(), s), "hexplane_fwd")

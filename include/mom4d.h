@@ -385,7 +385,7 @@ int mom_deform_backward_split(const MomDeformMLP* w, int P, const float* feat, c
  * `order` (optional) is the processing order as in mom_hexplane_forward.  Needs levels == 2, channels == 32 and resolutions
  * <= 1024 (mom_deform_field_supported); other shapes take the two separate calls. */
 int mom_deform_field_supported(const MomHexPlane* hp);
-size_t mom_deform_field_scratch_bytes(const MomHexPlane* hp);
+size_t mom_deform_field_scratch_bytes(const MomHexPlane* hp, int P /* 0 if every call keeps a feature copy (feat_save) */);
 int mom_deform_field_forward(const MomHexPlane* hp, const MomDeformMLP* w, int P, const float* xyz, float time,
                              const uint32_t* order, const float* scaling, const float* rotation, const float* scene_flow,
                              float flow_coef, float* pts, float* scales, float* rots, float* feat_save, float* a0_save,

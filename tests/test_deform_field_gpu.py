@@ -110,7 +110,7 @@ def test_fused_forward_without_saved_tensors_and_refusals():
     md = ops.DeformMLPFunction._desc(params)
     ref = _run_forward(f, params, P, xyz, scal, rot, flow, opac, 0.5, None, fused=True)
     pts, sc_d, rot_d = (torch.empty(P, k, device="cuda") for k in (3, 3, 4))
-    scratch = ops.field_scratch(hp, xyz.device)
+    scratch = ops.field_scratch(hp, xyz.device, P)
     N.check(lib.mom_deform_field_forward(C.byref(hp), C.byref(md), P, xyz.data_ptr(), 0.5, None, scal.data_ptr(), rot.data_ptr(),
                                          flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), None, None, None,
                                          None, None, None, scratch.data_ptr(), s), "fwd")
