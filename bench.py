@@ -312,6 +312,8 @@ def parse_args(argv=None):
                     help="weight of the SSIM loss term in the headline value (0 = the reference's default)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the extra single-GPU legs (steady state, training with lambda_dssim 0.2, render FPS)")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip via_render_api and other_configs (profiling runs: their kernels would mix into the per-kernel averages)")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state leg (SURVEY 8d: >= 200)")
     ap.add_argument("--steady-warmup", type=int, default=50, help="warm-up of the steady-state leg (SURVEY 8d: 50)")
     ap.add_argument("--path", default="fused", choices=["fused", "autograd", "autograd-per-op"],
@@ -510,7 +512,7 @@ def main():
             # train_4DGS.py:189-297 drives the modules (render() is one autograd node, fused_autograd.py; async binning with the
             # overflow replay of Trainer.step) -- on the same workload; and the other single-GPU configurations of BASELINE.json
             # (parity-test sizes, not bench lines), so that BASELINE.md's table is filled from this record
-            if a.config == "c2":
+            if a.config == "c2" and not a.no_side_legs:
                 out["via_render_api"] = side_leg(cfg, dev, "autograd", 100, 20)
                 out["other_configs"] = {k: side_leg(CONFIGS[k], dev, "fused", 20, 5) for k in ("c1", "c3", "c5")}
         if world == 1 and not a.no_cpu_baseline:

@@ -10,7 +10,7 @@ root=$PWD
 out=$root/gpurun_out/$pre
 mkdir -p $out $root/profiles
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $root/bench.py --no-cpu-baseline > $out/bench_default.json 2> $out/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 $root/bench.py --no-cpu-baseline --no-side-legs > $out/bench_default.json 2> $out/stats.err
 cp $(find $out/stats -name "*kernel_stats.csv" | head -1) $out/${pre}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o run -- python3 $root/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra > $out/pmc_$c.json 2> $out/pmc_$c.err

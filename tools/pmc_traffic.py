@@ -33,7 +33,8 @@ NAMES = {
     "hexplane_fwd4_kernel": "hexplane_fwd", "adam_kernel": "adam", "l1_kernel": "l1_loss",
     "preprocess_fwd_kernel": "preprocess_fwd", "preprocess_bwd_kernel": "preprocess_bwd", "tile_sort_kernel": "tile_sort",
     "deform_fwd_kernel": "mlp_fwd", "deform_bwd_dx_kernel": "mlp_bwd_dx", "deform_bwd_dw_kernel": "mlp_bwd_dw",
-    "plane_reg_kernel": "plane_reg",
+    "plane_reg_kernel": "plane_reg", "deform_field_fwd_b3_kernel": "deform_field_fwd", "deform_field_fwd_kernel": "deform_field_fwd_f32",
+    "hexplane_lines_kernel": "hexplane_lines", "tile_hist_kernel": "tile_hist", "tile_scatter_kernel": "tile_scatter",
 }
 SKIP = 5  # warm-up launches left out of the average
 
