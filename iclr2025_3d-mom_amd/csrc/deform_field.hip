@@ -614,7 +614,8 @@ deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const flo
     unsigned long long tg = 0, tb = 0, tl = 0, to = 0;
     int n_t = 0;
     const unsigned long long t_pro = STAMP();
-    for (int t = t_begin + wv; t < t_end; t += kB3Waves, n_t++) {
+    const int n_waves = (int)(blockDim.x >> 6);
+    for (int t = t_begin + wv; t < t_end; t += n_waves, n_t++) {
         const int gi = t * 32 + col;
         const int g = gi < P ? (a.order ? (int)a.order[gi] : gi) : -1;
         const bool ok = g >= 0;
@@ -785,7 +786,16 @@ extern "C" int mom_deform_field_forward(const MomHexPlane* hp, const MomDeformML
     }
     if (mode == 0) {
         float* feat = feat_save ? feat_save : (float*)mom_align_ptr((char*)lines + mom_align_up((size_t)nline * sizeof(float)));
-        const int blocks = tiles < 256 * kB3Waves ? (tiles + kB3Waves - 1) / kB3Waves : 256;
+        // Waves per workgroup (MOM_B3_RUN_WAVES overrides): measured at 200 k Gaussians, 24.4 tiles per CU: 5 waves 116 us, 6: 109,
+        // 8: 98, 9: 92, 10: 91, 11: 86, 12: 87 -- the gather wants bytes in flight more than the tile rounds want an even split
+        // (12 waves take 3 rounds for 2.03 tiles each, 10 waves 3 rounds for 2.44)
+        int waves = kB3Waves;
+        {
+            static int forced = -1;
+            if (forced < 0) { const char* e = getenv("MOM_B3_RUN_WAVES"); forced = e ? atoi(e) : 0; }
+            if (forced >= 4 && forced <= kB3Waves) waves = forced;
+        }
+        const int blocks = tiles < 256 * waves ? (tiles + waves - 1) / waves : 256;
         static bool attr_b3 = false;
         const size_t lds_b3 = sizeof(float) * kL3Total;
         if (!attr_b3) {
@@ -794,7 +804,7 @@ extern "C" int mom_deform_field_forward(const MomHexPlane* hp, const MomDeformML
                 return MOM_ELAUNCH;
             attr_b3 = true;
         }
-        hipLaunchKernelGGL(deform_field_fwd_b3_kernel, dim3(blocks), dim3(64 * kB3Waves), lds_b3, s, a, lt, d, tiles, lines, xyz, scaling,
+        hipLaunchKernelGGL(deform_field_fwd_b3_kernel, dim3(blocks), dim3(64 * waves), lds_b3, s, a, lt, d, tiles, lines, xyz, scaling,
                            rotation, scene_flow, flow_coef, pts, scales, rots, feat, a0_save, act);
         return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
     }
