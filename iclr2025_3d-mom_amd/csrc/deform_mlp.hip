@@ -358,6 +358,273 @@ deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat,
     }
 }
 
+// (C) dx and dW in ONE kernel: the four dH matrices never leave the CU.
+//
+// The two-kernel backward writes dH [4][P][64] (205 MB at 200 k Gaussians) and reads it back with a0 three times and feat once
+// (378 MB): two thirds of the MLP's traffic for an operand that exists in registers when it is needed.  Here a wave keeps the
+// four 64x64 weight-gradient tiles in 256 accumulator registers for its whole share of the Gaussians (one wave per SIMD, up to
+// 512 registers) and, per tile of 32 Gaussians, adds dW_L += dH_L^T X_L right after dH_L is formed: dH_L and X_L (a0 for the
+// three head layers, feat for the trunk) are transposed through two LDS staging tiles -- the MFMA's K index is the Gaussian
+// here, so both operands want lane = feature -- and the bias gradients fall out of the A operands.  704 MFMAs per tile either
+// way; what is gone is 480 MB of traffic (only the trunk's dH still goes out, see kNR).  (v_mfma_f32_32x32x2_f32 occupies the
+// vector ALU, so a second wave per SIMD would not overlap its vector work with this wave's matrix work anyway:
+// tools/probe/mfma_valu_coissue.hip.)
+//
+// MEASURED (round 3, 200 k Gaussians): 333 us against 153 us for dx with the weight-gradient kernel hidden on the second
+// stream; the training step goes from 1213 to 1328 us.  One wave per SIMD has nobody to cover its LDS round trips (two operand
+// reads per MFMA in the recomputed head layer, the staging transposes, 30 scratch reloads per tile), and the saved traffic was
+// never on the critical path: the two-kernel form overlaps the weight gradients with the HexPlane backward.  The kernel is
+// correct (tests/test_ops_gpu.py compares it with the two-kernel form) and stays opt-in: MOM_MLP_BWD=fused.
+constexpr int kFusedStage = 2 * kHid * kStageStride + 4 * 32;          // sA | sX | dout[32][4]
+constexpr int kLFusedStage = kLFwdTotal;
+constexpr int kLFusedTotal = kLFusedStage + 4 * kFusedStage;
+#ifndef MOM_FUSED_NR
+#define MOM_FUSED_NR 3
+#endif
+constexpr int kNR = MOM_FUSED_NR;                       // layers whose weight gradient lives in registers (3, or 4 = trunk too)
+
+__device__ __forceinline__ void dw_accumulate(const float* __restrict__ sA, const float* __restrict__ sX, f32x16 (&dW)[2][2], float (&db)[2],
+                                              int col, int h)
+{
+    // K-step j: Gaussians 2 j + h of the tile; A = dH^T (row = out feature), B = X (column = in feature).  Operands are fetched
+    // four K-steps ahead of their MFMAs.
+    constexpr int kAhead = 4;
+    float a_lo[2][kAhead], a_hi[2][kAhead], x0[2][kAhead], x1[2][kAhead];
+    auto fetch = [&](int j0, int b) {
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+            const int j = j0 + u;
+            a_lo[b][u] = sA[col * kStageStride + 2 * j + h];
+            a_hi[b][u] = sA[(32 + col) * kStageStride + 2 * j + h];
+            x0[b][u] = sX[col * kStageStride + 2 * j + h];
+            x1[b][u] = sX[(32 + col) * kStageStride + 2 * j + h];
+        }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int c = 0; c < 16 / kAhead; c++) {
+        const int b = c & 1;
+        if (c + 1 < 16 / kAhead) fetch((c + 1) * kAhead, b ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {
+            db[0] += a_lo[b][u];
+            db[1] += a_hi[b][u];
+            dW[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo[b][u], x0[b][u], dW[0][0], 0, 0, 0);
+            dW[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lo[b][u], x1[b][u], dW[0][1], 0, 0, 0);
+            dW[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi[b][u], x0[b][u], dW[1][0], 0, 0, 0);
+            dW[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_hi[b][u], x1[b][u], dW[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// h1 = W a0 + b with the B operand (a0, staged as [feature][gaussian]) read from LDS: a0 then needs no registers of its own
+__device__ __forceinline__ void layer64_ldsB(const float* __restrict__ Wl, const float* __restrict__ sB, f32x16 (&out)[2], int col, int h)
+{
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k = 32 * kt + fmap(r, h), mrow = 32 * mt + col;
+                out[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wl[k * kWStride + mrow], sB[k * kStageStride + col], out[mt], 0, 0, 0);
+                if (r == 15) __builtin_amdgcn_sched_barrier(0);
+            }
+}
+
+__global__ void __launch_bounds__(256, 1)
+deform_bwd_fused_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ a0g,
+                        const float* __restrict__ dpts, const float* __restrict__ dscales, const float* __restrict__ drots,
+                        float* __restrict__ dfeat, float* __restrict__ dH0)
+{
+    extern __shared__ float lds[];
+    load_weights(m, lds);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    // The staging area sits above 64 KB of LDS, beyond the reach of a DS instruction's 16-bit offset field: left to constant
+    // folding, every distinct (region base + row offset) became a loop-invariant address register of its own -- hundreds, spilled.
+    // One opaque per-wave base keeps every staging access at `base + small immediate`.
+    // One opaque per-wave base, renewed INSIDE the tile loop (a loop-invariant one is hoisted all the same), keeps every access
+    // at `base + small immediate`; the weights get the same treatment.
+    const unsigned stage_off0 = (unsigned)(kLFusedStage + wv * kFusedStage) * 4u;
+    const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
+    // Three of the four layers: at one wave per SIMD the compiler puts EVERY MFMA result into the 256 accumulation registers,
+    // the layer tiles of the moment (64) included, which leaves 192 = three 64x64 gradients.  The trunk layer's dH is the one
+    // matrix that still goes out (51 MB instead of 205), to a quarter-size run of the weight-gradient kernel.
+    f32x16 dW[kNR][2][2];
+    float db[kNR][2];
+#pragma unroll
+    for (int l = 0; l < kNR; l++) {
+        zero_tile(dW[l][0]);
+        zero_tile(dW[l][1]);
+        db[l][0] = db[l][1] = 0.f;
+    }
+    float dW2[3][4], db2[3];                           // lane = feature; db2: lane n < 4 holds output n
+#pragma unroll
+    for (int k = 0; k < 3; k++) { db2[k] = 0.f; dW2[k][0] = dW2[k][1] = dW2[k][2] = dW2[k][3] = 0.f; }
+
+    for (int t = t_begin + wv; t < t_end; t += 4) {
+        const int g = t * 32 + col;
+        const bool ok = g < P;
+        unsigned stage_off = stage_off0, lds_off = 0;
+        asm volatile("" : "+v"(stage_off), "+v"(lds_off));
+        float* sA = reinterpret_cast<float*>(reinterpret_cast<char*>(lds) + stage_off);
+        float* sX = sA + kHid * kStageStride;
+        float* sD = sX + kHid * kStageStride;           // dout[32 gaussians][4]
+        const float* L = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + lds_off);
+        f32x16 dA0[2];
+        {
+            f32x16 a0[2];
+            load_feat(a0g, g, ok, h, a0);
+            __builtin_amdgcn_wave_barrier();
+            stage_tile(sX, a0, col, h);                // X of the three head layers, and their B operand (read back from here)
+            __builtin_amdgcn_wave_barrier();
+        }
+        zero_tile(dA0);
+#pragma unroll
+        for (int head = 0; head < 3; head++) {
+            const int nout = head == 2 ? 4 : 3;
+            f32x16 a1[2];
+            init_bias(L + kLB + (1 + head) * kHid, a1, h);
+            layer64_ldsB(L + kLW + (1 + head) * kWFloats, sX, a1, col, h);
+            relu_tile(a1);
+            const float* __restrict__ dsrc = head == 0 ? dpts : (head == 1 ? dscales : drots);
+            float dout[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) dout[k] = (ok && k < nout) ? dsrc[nout * g + k] : 0.f;
+            __builtin_amdgcn_wave_barrier();
+            stage_tile(sA, a1, col, h);
+            if (h == 0) *reinterpret_cast<float4*>(sD + 4 * col) = make_float4(dout[0], dout[1], dout[2], dout[3]);
+            __builtin_amdgcn_wave_barrier();
+            {   // output layer: dW2[n][f] += sum_g dout[n][g] a1[f][g]; db2[n] += sum_g dout[n][g]   (lane = f)
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f, bsum = 0.f;
+#pragma unroll 1
+                for (int g0 = 0; g0 < 32; g0 += 8)     // rolled: unrolled whole, its 160 operand registers are loaded up front
+#pragma unroll
+                    for (int gg = g0; gg < g0 + 8; gg++) {
+                        const float v = sA[lane * kStageStride + gg];
+                        const float4 d = *reinterpret_cast<const float4*>(sD + 4 * gg);
+                        w0 += d.x * v; w1 += d.y * v; w2 += d.z * v; w3 += d.w * v;
+                        bsum += sD[4 * gg + (lane & 3)];
+                    }
+                dW2[head][0] += w0; dW2[head][1] += w1; dW2[head][2] += w2; dW2[head][3] += w3; db2[head] += bsum;
+            }
+            // dH1 = relu'(h1) * W2^T dout, in place of a1
+            const float* __restrict__ W2l = L + kLW2 + head * 4 * kHid;
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 wa = *reinterpret_cast<const float4*>(W2l + 0 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float4 wb = *reinterpret_cast<const float4*>(W2l + 1 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float4 wc = *reinterpret_cast<const float4*>(W2l + 2 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float4 wd = *reinterpret_cast<const float4*>(W2l + 3 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float v0 = wa.x * dout[0] + wb.x * dout[1] + wc.x * dout[2] + wd.x * dout[3];
+                    const float v1 = wa.y * dout[0] + wb.y * dout[1] + wc.y * dout[2] + wd.y * dout[3];
+                    const float v2 = wa.z * dout[0] + wb.z * dout[1] + wc.z * dout[2] + wd.z * dout[3];
+                    const float v3 = wa.w * dout[0] + wb.w * dout[1] + wc.w * dout[2] + wd.w * dout[3];
+                    a1[mt][4 * q + 0] = a1[mt][4 * q + 0] > 0.f ? v0 : 0.f;
+                    a1[mt][4 * q + 1] = a1[mt][4 * q + 1] > 0.f ? v1 : 0.f;
+                    a1[mt][4 * q + 2] = a1[mt][4 * q + 2] > 0.f ? v2 : 0.f;
+                    a1[mt][4 * q + 3] = a1[mt][4 * q + 3] > 0.f ? v3 : 0.f;
+                }
+            __builtin_amdgcn_wave_barrier();
+            stage_tile(sA, a1, col, h);                // dH1^T for the weight gradient (the staged a1 has been consumed)
+            __builtin_amdgcn_wave_barrier();
+            dw_accumulate(sA, sX, dW[kNR - 3 + head], db[kNR - 3 + head], col, h);
+            layer64<true>(L + kLW + (1 + head) * kWFloats, a1, dA0, col, h);     // dA0 += W1^T dH1
+            __builtin_amdgcn_sched_barrier(0);          // the heads stay apart: interleaved by the scheduler they spill
+        }
+        // through the ReLU between trunk and heads (a0 = relu(h0) is still staged in sX)
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                dA0[mt][r] = sX[(32 * mt + fmap(r, h)) * kStageStride + col] > 0.f ? dA0[mt][r] : 0.f;
+        if constexpr (kNR == 3) {
+            store_feat(dH0, g, ok, h, dA0);           // the trunk layer's weight gradient: deform_bwd_dw_kernel, layer 0 only
+        } else {
+            f32x16 x[2];
+            load_feat(feat, g, ok, h, x);              // X of the trunk layer
+            __builtin_amdgcn_wave_barrier();
+            stage_tile(sA, dA0, col, h);
+            stage_tile(sX, x, col, h);
+            __builtin_amdgcn_wave_barrier();
+            dw_accumulate(sA, sX, dW[0], db[0], col, h);
+        }
+        {
+            f32x16 df[2];
+            zero_tile(df);
+            layer64<true>(L + kLW, dA0, df, col, h);    // dfeat = W0^T dH0
+            store_feat(dfeat, g, ok, h, df);
+        }
+    }
+    // ---- reductions over the workgroup's four waves, then one float atomic per weight per workgroup
+    __syncthreads();
+    float* R = lds;                                     // the weights are no longer needed
+    for (int i = threadIdx.x; i < 12 * kHid + 16; i += blockDim.x) R[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int n = 0; n < 4; n++) atomicAdd(&R[(k * 4 + n) * kHid + lane], dW2[k][n]);
+        if (lane < 4) atomicAdd(&R[12 * kHid + k * 4 + lane], db2[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 12 * kHid; i += blockDim.x) {
+        const int k = i >> 8, n = (i >> 6) & 3, f = i & 63;
+        const int nout = k == 2 ? 4 : 3;
+        const float v = R[i];
+        if (n < nout && v != 0.f) atomicAdd(&m.dW2[k][n * kHid + f], v);
+    }
+    if (threadIdx.x < 12) {
+        const int k = threadIdx.x >> 2, n = threadIdx.x & 3;
+        const int nout = k == 2 ? 4 : 3;
+        const float v = R[12 * kHid + threadIdx.x];
+        if (n < nout && v != 0.f) atomicAdd(&m.db2[k][n], v);
+    }
+    __syncthreads();
+    // the four 64x64 layers: the waves take turns on one shared tile with plain read-add-write (LDS float atomics cost ~190
+    // cycles per wave instruction: tools/probe/lds_atomic_probe.hip)
+#pragma unroll
+    for (int l = 0; l < kNR; l++) {
+        const float b_lo = db[l][0] + __shfl_xor(db[l][0], 32), b_hi = db[l][1] + __shfl_xor(db[l][1], 32);
+#pragma unroll 1
+        for (int turn = 0; turn < 4; turn++) {
+            __syncthreads();
+            if (wv == turn) {
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {     // tile row = out feature 32mt+fmap(r,h), column = in feature 32kt+col
+                            float* a = &R[(32 * mt + fmap(r, h)) * kHid + 32 * kt + col];
+                            *a = (turn == 0 ? 0.f : *a) + dW[l][mt][kt][r];
+                        }
+                if (h == 0) {
+                    float* a = &R[kHid * kHid + col];
+                    a[0] = (turn == 0 ? 0.f : a[0]) + b_lo;
+                    a[32] = (turn == 0 ? 0.f : a[32]) + b_hi;
+                }
+            }
+        }
+        __syncthreads();
+        float* dst = (kNR == 4 && l == 0) ? m.dW0 : m.dW1[l - (kNR - 3)];
+        float* dbs = (kNR == 4 && l == 0) ? m.db0 : m.db1[l - (kNR - 3)];
+        for (int i = threadIdx.x; i < kHid * kHid; i += 256) {
+            const float v = R[i];
+            if (v != 0.f) atomicAdd(&dst[i], v);
+        }
+        if (threadIdx.x < kHid) {
+            const float v = R[kHid * kHid + threadIdx.x];
+            if (v != 0.f) atomicAdd(&dbs[threadIdx.x], v);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mom_deform_forward(const MomDeformMLP* w, int P, const float* feat, const float* xyz, const float* scaling,
@@ -407,6 +674,52 @@ extern "C" int mom_deform_forward_activated(const MomDeformMLP* w, int P, const 
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
+// dx and the head layers' dW in one kernel; only the trunk's dH (the first [P,64] of `scratch`) goes through memory
+static int deform_backward_fused(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
+                                 const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream,
+                                 mom_stream_t dw_stream)
+{
+    if (P < 0) return MOM_EINVAL;
+    if (P == 0) return MOM_OK;
+    if (!feat || !a0 || !dpts || !dscales || !drots || !dfeat || !scratch) return MOM_EINVAL;
+    MlpDev d;
+    int rc = fill_dev(w, &d);
+    if (rc) return rc;
+    if (!d.dW0 || !d.db0) return MOM_EINVAL;
+    for (int i = 0; i < 3; i++)
+        if (!d.dW1[i] || !d.db1[i] || !d.dW2[i] || !d.db2[i]) return MOM_EINVAL;
+    float* dH0 = (float*)scratch;
+    const int tiles = (P + 31) / 32;
+    const int blocks = tiles < 256 * 4 ? (tiles + 3) / 4 : 256;      // persistent: one workgroup of four waves per CU
+    static bool attr_set = false;
+    const size_t lds_bytes = sizeof(float) * kLFusedTotal;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return MOM_ELAUNCH;
+        attr_set = true;
+    }
+    MomProfScope ps(MOM_P_MLP_BWD, (hipStream_t)stream);
+    hipLaunchKernelGGL(deform_bwd_fused_kernel, dim3(blocks), dim3(256), lds_bytes, (hipStream_t)stream, d, P, tiles, feat, a0, dpts,
+                       dscales, drots, dfeat, dH0);
+    if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
+    if (kNR == 4) return MOM_OK;
+    hipStream_t ws = (hipStream_t)dw_stream;
+    if (ws != (hipStream_t)stream) {
+        static hipEvent_t dx_done = nullptr;
+        if (!dx_done && hipEventCreateWithFlags(&dx_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
+        if (hipEventRecord(dx_done, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
+        if (hipStreamWaitEvent(ws, dx_done, 0) != hipSuccess) return MOM_ELAUNCH;
+    }
+    // the trunk layer's weight gradient: the weight-gradient kernel on layer 0 only (dH laid out as its first matrix)
+    const int waves = 1024;
+    int chunk = (P + waves - 1) / waves;
+    chunk += chunk & 1;
+    hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, dim3(waves / 4, 1), dim3(256), sizeof(float) * (kHid * kHid + kHid), ws, d, P, chunk, feat,
+                       a0, dH0);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+
 extern "C" size_t mom_deform_backward_scratch_bytes(int P) { return (size_t)4 * (size_t)(P > 0 ? P : 1) * kHid * sizeof(float); }
 
 extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
@@ -422,6 +735,9 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
     if (P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!feat || !a0 || !dpts || !dscales || !drots || !dfeat || !scratch) return MOM_EINVAL;
+    // MOM_MLP_BWD=fused: the one-kernel variant above (opt-in, measured slower; read per call so a test can compare the two)
+    const char* e = getenv("MOM_MLP_BWD");
+    if (e && e[0] == 'f') return deform_backward_fused(w, P, feat, a0, dpts, dscales, drots, dfeat, scratch, stream, dw_stream);
     MlpDev d;
     int rc = fill_dev(w, &d);
     if (rc) return rc;
@@ -473,3 +789,4 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
         hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
+

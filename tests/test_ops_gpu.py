@@ -473,3 +473,34 @@ def test_deform_backward_split_on_a_second_stream_equals_the_single_stream_call(
     assert torch.equal(f1, f2)
     for a, b in zip(g1, g2):         # float atomics: same terms, possibly another order
         assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_deform_backward_fused_variant_equals_the_two_kernel_backward(monkeypatch):
+    """MOM_MLP_BWD=fused (dx and the head layers' dW in one kernel, csrc/deform_mlp.hip (C)) against the default two kernels:
+    same dfeat bit for bit (same MFMA chain), weight gradients equal up to the order of the float additions."""
+    P = 50021
+    params, mk = _mlp_state(P, 11)
+    feat, xyz, scal, rot, flow = mk(P, 64) * 3, mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 3)
+    dpts, dsc, drot = mk(P, 3), mk(P, 3), mk(P, 4)
+    lib, s = N.lib(), N.current_stream()
+
+    def run(mode):
+        monkeypatch.setenv("MOM_MLP_BWD", mode)
+        grads = [torch.zeros_like(p) for p in params]
+        d = ops.DeformMLPFunction._desc(params, grads)
+        pts, sc_d, rot_d, a0 = (torch.empty(P, k, device="cuda") for k in (3, 3, 4, 64))
+        N.check(lib.mom_deform_forward(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                       flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), a0.data_ptr(), s), "fwd")
+        dfeat = torch.empty(P, 64, device="cuda")
+        scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device="cuda")
+        N.check(lib.mom_deform_backward_split(C.byref(d), P, feat.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(),
+                                              drot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s, s), "bwd")
+        torch.cuda.synchronize()
+        return dfeat, grads
+
+    f1, g1 = run("split")
+    f2, g2 = run("fused")
+    assert torch.equal(f1, f2)
+    for a, b in zip(g1, g2):
+        assert float(b.abs().max()) > 0 or float(a.abs().max()) == 0
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
