@@ -717,6 +717,175 @@ deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const flo
 #endif
 }
 
+
+// ---- HexPlane backward, pass 1 (gather) in the forward's layout ------------------------------------------------------------
+// Same contract as hexplane_bwd5_gather_kernel (hexplane.hip): per (point, level) the six samples, their product, the six
+// gv = dfeat * (product of the other five) rows STORED at the point's position in the order of the space plane each row is
+// scattered with, and the position gradient reduced over the channels.  What changes is the shape: eight lanes own one
+// (point, level) with four channels each, so the 18 texel rows (the space-time planes are this frame's lines: two rows instead
+// of four) are 18 sixteen-byte loads per lane and one wave instruction serves eight (point, level) units; the lane-per-channel
+// kernel issued 24 four-byte loads per two units and spent half its time issuing vector instructions (37 M per launch).  A wave
+// takes both levels of its 32 points, so a point's gradient is complete in registers and is added to dxyz without atomics.
+constexpr int kRec6Dw = 16;                           // dwords of one (point, level) record of the backward
+
+__device__ __forceinline__ float4 sub4(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 fma44(float s, float4 a, float4 c)      // s * a + c
+{
+    return make_float4(__builtin_fmaf(s, a.x, c.x), __builtin_fmaf(s, a.y, c.y), __builtin_fmaf(s, a.z, c.z), __builtin_fmaf(s, a.w, c.w));
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b, float acc)
+{
+    acc = __builtin_fmaf(a.x, b.x, acc);
+    acc = __builtin_fmaf(a.y, b.y, acc);
+    acc = __builtin_fmaf(a.z, b.z, acc);
+    return __builtin_fmaf(a.w, b.w, acc);
+}
+// sum over the eight lanes of a unit (lanes 8k .. 8k+7): row_shr-free butterfly inside a DPP row
+__device__ __forceinline__ float unit_sum(float v)
+{
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+
+#ifndef HX6_WAVES
+#define HX6_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, HX6_WAVES)
+hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __restrict__ lines, const float* __restrict__ xyz,
+                            const float* __restrict__ dfeat, float* __restrict__ dxyz, const uint32_t* __restrict__ inv /* [3][levels][P] */,
+                            float* __restrict__ gvbuf /* [6][levels][P][32] */)
+{
+    __shared__ uint4 s_rec[4][64 * (kRec6Dw / 4)];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    uint4* __restrict__ rec = s_rec[wv];
+    const int g8 = lane >> 3, c = lane & 7;
+    const unsigned cb = (unsigned)c * 16u;
+    const size_t plane_floats = (size_t)a.P * 32;
+
+    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
+        // phase A: lane = unit (point lane & 31 of the chunk, level lane >> 5)
+        const int gi = chunk * 32 + (lane & 31);
+        const int g_mine = gi < a.P ? (a.order ? (int)a.order[gi] : gi) : -1;
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int lvl = lane >> 5;
+            uint4 R0 = make_uint4(0, 0, 0, 0), R2 = make_uint4(0, 0, 0, 0), R3 = make_uint4(0, 0, 0, 0xffffffffu);
+            float4 R1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_mine >= 0) {
+                make_record(a, xyz, g_mine, lvl, R0, R1);
+                float cc[4];
+                norm_coords(a, xyz, g_mine, cc);
+                float gm[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float m;
+                    (void)unnorm_clip(cc[k], a.res[lvl][k], m);
+                    // d(ix)/d(world coordinate): (size-1)/2 * 2/(aabb1 - aabb0), 0 where the coordinate was clipped at the border
+                    gm[k] = m != 0.f ? ((float)(a.res[lvl][k] - 1) / 2.f) * (2.0f / (a.a1[k] - a.a0[k])) : 0.f;
+                }
+                R2 = make_uint4(__float_as_uint(gm[0]), __float_as_uint(gm[1]), __float_as_uint(gm[2]), 0u);
+#pragma unroll
+                for (int k = 0; k < 3; k++) (&R3.x)[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * 128u;
+                R3.w = (unsigned)g_mine;
+            }
+            rec[4 * lane] = R0;
+            rec[4 * lane + 1] = make_uint4(__float_as_uint(R1.x), __float_as_uint(R1.y), __float_as_uint(R1.z), 0u);
+            rec[4 * lane + 2] = R2;
+            rec[4 * lane + 3] = R3;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // phase B: pass u = 4 lvl + i covers the points 8 i .. 8 i + 7 of the chunk at level lvl; the gradient of level 0 waits in
+        // registers for level 1's (same lanes, four passes later)
+        float gsum[4][3];
+#pragma unroll 1
+        for (int lvl = 0; lvl < 2; lvl++) {
+            const unsigned rowx = (unsigned)a.res[lvl][0] * 128u, rowy = (unsigned)a.res[lvl][1] * 128u;
+            const float* __restrict__ pxy = a.planes[lvl][0];
+            const float* __restrict__ pxz = a.planes[lvl][1];
+            const float* __restrict__ pyz = a.planes[lvl][3];
+            const float* __restrict__ lx = lines + lt.off[lvl][0];
+            const float* __restrict__ ly = lines + lt.off[lvl][1];
+            const float* __restrict__ lz = lines + lt.off[lvl][2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int unit = 32 * lvl + 8 * i + g8;
+                const uint4 R0 = rec[4 * unit], R1u = rec[4 * unit + 1], R2 = rec[4 * unit + 2], R3 = rec[4 * unit + 3];
+                const bool live = R3.w != 0xffffffffu;
+                const float bx = __uint_as_float(R1u.x), by = __uint_as_float(R1u.y), bz = __uint_as_float(R1u.z);
+                const unsigned sx = (R0.x & 1u) ? 128u : 0u, sy = (R0.x & 2u) ? 128u : 0u, sz = (R0.y & 2u) ? 128u : 0u;
+                const unsigned ry_x = (R0.x & 2u) ? rowx : 0u, rz_x = (R0.y & 2u) ? rowx : 0u, rz_y = (R0.y & 2u) ? rowy : 0u;
+                const unsigned x0 = R0.w & 1023u, y0 = (R0.w >> 10) & 1023u, z0 = R0.w >> 20;
+                const unsigned oxy = (R0.x & ~127u) + cb, oxz = (R0.y & ~127u) + cb, oyz = (R0.z & ~127u) + cb;
+                float4 t[18];
+                t[0] = ld4(pxy, oxy); t[1] = ld4(pxy, oxy + sx); t[2] = ld4(pxy, oxy + ry_x); t[3] = ld4(pxy, oxy + sx + ry_x);
+                t[4] = ld4(pxz, oxz); t[5] = ld4(pxz, oxz + sx); t[6] = ld4(pxz, oxz + rz_x); t[7] = ld4(pxz, oxz + sx + rz_x);
+                t[8] = ld4(pyz, oyz); t[9] = ld4(pyz, oyz + sy); t[10] = ld4(pyz, oyz + rz_y); t[11] = ld4(pyz, oyz + sy + rz_y);
+                t[12] = ld4(lx, x0 * 128u + cb); t[13] = ld4(lx, x0 * 128u + cb + sx);
+                t[14] = ld4(ly, y0 * 128u + cb); t[15] = ld4(ly, y0 * 128u + cb + sy);
+                t[16] = ld4(lz, z0 * 128u + cb); t[17] = ld4(lz, z0 * 128u + cb + sz);
+                float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) go = *reinterpret_cast<const float4*>(dfeat + (size_t)R3.w * (a.levels * 32) + 32 * lvl + 4 * c);
+                // bilinear sample and the two raw derivatives of a space plane (corners nw ne sw se; b0 along the row, b1 across rows)
+                float4 v[6], da[6], db[3];
+                auto space = [&](const float4* q, float b0, float b1, float4& val, float4& d_first, float4& d_second) {
+                    const float4 d0 = sub4(q[1], q[0]), d1 = sub4(q[3], q[2]);
+                    const float4 tx0 = fma44(b0, d0, q[0]), tx1 = fma44(b0, d1, q[2]);
+                    const float4 dy = sub4(tx1, tx0);
+                    val = fma44(b1, dy, tx0);
+                    d_first = fma44(b1, sub4(d1, d0), d0);
+                    d_second = dy;
+                };
+                auto line = [&](const float4* q, float b, float4& val, float4& d) {
+                    d = sub4(q[1], q[0]);
+                    val = fma44(b, d, q[0]);
+                };
+                // planes in the reference's order: 0 (x,y)  1 (x,z)  2 (x,t)  3 (y,z)  4 (y,t)  5 (z,t)
+                space(t, bx, by, v[0], da[0], db[0]);
+                space(t + 4, bx, bz, v[1], da[1], db[1]);
+                line(t + 12, bx, v[2], da[2]);
+                space(t + 8, by, bz, v[3], da[3], db[2]);
+                line(t + 14, by, v[4], da[4]);
+                line(t + 16, bz, v[5], da[5]);
+                float4 pre[6], suf[6];
+                pre[0] = go;                                   // dfeat rides in the prefix products
+#pragma unroll
+                for (int p = 1; p < 6; p++) pre[p] = mul44(pre[p - 1], v[p - 1]);
+                suf[5] = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+                for (int p = 4; p >= 0; p--) suf[p] = mul44(suf[p + 1], v[p + 1]);
+                float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+                for (int p = 0; p < 6; p++) {
+                    const float4 gv = p == 5 ? pre[5] : mul44(pre[p], suf[p]);
+                    const unsigned pos = p == 0 || p == 2 ? R3.x : (p == 1 || p == 5 ? R3.y : R3.z);     // order slot of the plane
+                    if (live)
+                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(gvbuf + ((size_t)p * a.levels + lvl) * plane_floats) + pos + cb) = gv;
+                    // first coordinate of the plane: x for 0 1 2, y for 3 4, z for 5; second: y for 0, z for 1 and 3
+                    if (p < 3) gx = dot4(gv, da[p], gx);
+                    else if (p < 5) gy = dot4(gv, da[p], gy);
+                    else gz = dot4(gv, da[p], gz);
+                    if (p == 0) gy = dot4(gv, db[0], gy);
+                    if (p == 1) gz = dot4(gv, db[1], gz);
+                    if (p == 3) gz = dot4(gv, db[2], gz);
+                }
+                gx = unit_sum(gx) * __uint_as_float(R2.x);
+                gy = unit_sum(gy) * __uint_as_float(R2.y);
+                gz = unit_sum(gz) * __uint_as_float(R2.z);
+                if (lvl == 0) { gsum[i][0] = gx; gsum[i][1] = gy; gsum[i][2] = gz; }
+                else if (dxyz && live && c == 0) {
+                    float* d = dxyz + 3 * (size_t)R3.w;
+                    d[0] += gsum[i][0] + gx;
+                    d[1] += gsum[i][1] + gy;
+                    d[2] += gsum[i][2] + gz;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int line_table(const MomHexPlane* hp, LineTab* lt)
@@ -728,6 +897,32 @@ static int line_table(const MomHexPlane* hp, LineTab* lt)
             if (l < hp->levels) off += (unsigned)hp->res[l][k] * 32u;
         }
     return (int)off;
+}
+
+// bytes of the time-line table (what mom_hexplane_backward_scratch_bytes adds for the gather below)
+size_t mom_hexplane_lines_bytes(const MomHexPlane* hp)
+{
+    LineTab lt;
+    return mom_align_up((size_t)line_table(hp, &lt) * sizeof(float)) + MOM_ALIGN;
+}
+
+// pass 1 of the two-pass HexPlane backward for a field mom_deform_field_supported() accepts (called by mom_hexplane_backward,
+// hexplane.hip): the frame's lines into `lines`, then the gather
+int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order, const float* dfeat,
+                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, hipStream_t s)
+{
+    HexArgs a;
+    fill_args(hp, P, nullptr, time, order, true, &a);
+    LineTab lt;
+    const int nline = line_table(hp, &lt);
+    hipLaunchKernelGGL(hexplane_lines_kernel, dim3((nline + 255) / 256), dim3(256), 0, s, a, lt, lines, nline);
+    const int nchunks = (P + 31) / 32;
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("MOM_HEX6_BLOCKS"); cap = e ? atoi(e) : 1536; if (cap < 1) cap = 1536;   // measured: 512 293 us, 1024 281, 1536 280, 4096 280 (gather + scatter beside dW) }
+    int blocks = (nchunks + 3) / 4;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(hexplane_bwd6_gather_kernel, dim3(blocks), dim3(256), 0, s, a, lt, nchunks, lines, xyz, dfeat, dxyz, plane_inverse, gvbuf);
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
 extern "C" size_t mom_deform_field_scratch_bytes(const MomHexPlane* hp, int P)

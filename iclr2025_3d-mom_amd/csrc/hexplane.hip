@@ -687,10 +687,18 @@ extern "C" int mom_hexplane_orders(const MomHexPlane* hp, int P, const float* xy
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
+// deform_field.hip: the gather in the fused forward's layout, for fields mom_deform_field_supported() accepts
+size_t mom_hexplane_lines_bytes(const MomHexPlane* hp);
+int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order, const float* dfeat,
+                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, hipStream_t s);
+extern "C" int mom_deform_field_supported(const MomHexPlane* hp);
+
+static size_t gv_bytes(const MomHexPlane* hp, int P) { return mom_align_up((size_t)6 * (size_t)P * (size_t)hp->levels * 32 * sizeof(float)); }
+
 extern "C" size_t mom_hexplane_backward_scratch_bytes(const MomHexPlane* hp, int P)
 {
     if (!hp || P <= 0) return MOM_ALIGN;
-    return (size_t)6 * (size_t)P * (size_t)hp->levels * 32 * sizeof(float) + MOM_ALIGN;
+    return gv_bytes(hp, P) + mom_hexplane_lines_bytes(hp) + MOM_ALIGN;    // gv rows | this frame's time lines
 }
 
 extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
@@ -731,7 +739,13 @@ extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* 
             const char* e2 = getenv("MOM_HEX_SBLOCKS");
             blocks_s = e2 ? atoi(e2) : 512;
         }
-        {
+        static int gather6 = -1;          // MOM_HEX_GATHER=5: the lane-per-channel gather (measurement)
+        if (gather6 < 0) { const char* e = getenv("MOM_HEX_GATHER"); gather6 = (e && e[0] == '5') ? 0 : 1; }
+        if (gather6 && mom_deform_field_supported(hp)) {
+            float* lines = (float*)mom_align_ptr((char*)gvbuf + gv_bytes(hp, P));
+            int rc = mom_launch_hexplane_gather6(hp, P, xyz, time, order, dfeat, dxyz, plane_inverse, gvbuf, lines, (hipStream_t)stream);
+            if (rc) return rc;
+        } else {
             const int nchunks = (P + kChunk5 - 1) / kChunk5;
             int blocks = (nchunks + 3) / 4;
             if (blocks > blocks_g) blocks = blocks_g;
