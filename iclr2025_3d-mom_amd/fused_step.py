@@ -87,6 +87,7 @@ class FusedStep:
 
     RING = 64
     OVERLAP_DW = os.environ.get("MOM_OVERLAP_DW", "1") != "0"     # the MLP weight-gradient kernel on a second stream, beside the HexPlane backward
+    EARLY_ADAM = os.environ.get("MOM_EARLY_ADAM", "1") != "0"     # the appearance parameters' Adam on that stream, beside the MLP backward
     side = None
     keep_all_tiles = False            # True: bin whole rectangles like the reference (MomRasterArgs.keep_all_tiles; measurement only)
     HEADROOM, MARGIN = 1.5, 65536     # binning capacity = HEADROOM x an earlier frame's instance count + MARGIN
@@ -134,7 +135,9 @@ class FusedStep:
         return planes, mlp
 
     # ------------------------------------------------------------------ one iteration (forward + backward)
-    def forward_backward(self, cam, delta_scale=1):
+    def forward_backward(self, cam, delta_scale=1, early_adam=None):
+        """early_adam: callable(list of parameters) or None -- see EARLY_ADAM below; the caller promises that its optimizer step
+        for this iteration follows with nothing in between that reads or replaces those parameters."""
         g, lib, s = self.g, self.lib, N.current_stream()
         dev = g._xyz.device
         P = g._xyz.shape[0]
@@ -331,6 +334,16 @@ class FusedStep:
         if self.side is None:
             self.side = torch.cuda.Stream(device=dev)
         side = self.side.cuda_stream if self.OVERLAP_DW else s
+        if early_adam is not None and dc is None and self.EARLY_ADAM:
+            # The appearance parameters' gradients (SH, scaling, rotation, opacity: 56 of a Gaussian's 59 floats) are final here.
+            # Their Adam update -- a pure HBM stream, 335 of Adam's 412 MB -- goes to the second stream now and runs underneath the
+            # MLP backward (matrix pipe, 2 TB/s); nothing on this stream reads those parameters again before the join below.
+            for p, gbuf in ((g._features_dc, self.gdc), (g._features_rest, self.grest), (g._scaling, self.gsc),
+                            (g._rotation, self.grot), (g._opacity, self.gop)):
+                p.grad = gbuf
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity])
         if sl is None:
             N.check(lib.mom_deform_backward_split(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
                                                   d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),

@@ -521,6 +521,8 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, maximize=False, foreach=None,
                                       capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False))
         self._plan = None
+        self._plans = {}            # "early" / "late": the plans of a step taken in two parts (step_partial)
+        self._early = None          # ids of the parameters step_partial() has already advanced in this iteration
         # int32 device word or None.  While it is nonzero on the device a step() changes neither parameters nor moments:
         # the asynchronous training step points it at the rasterizer's sticky overflow word, so that a step whose image was
         # truncated never reaches the model; the host notices later and replays (train.Trainer._recover, rewind()).
@@ -555,15 +557,7 @@ class FusedAdam(torch.optim.Optimizer):
         arrs = {cfg: (N.MomAdamTensor * len(ts))(*ts) for cfg, ts in by_cfg.items()}
         return {"key": key, "entries": entries, "steps": steps, "arrs": arrs}
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        live = [(group, p) for group in self.param_groups for p in group["params"] if p.grad is not None]
-        if not live:
-            return loss
+    def _launch(self, live, which):
         for _, p in live:
             st = self.state[p]
             if len(st) == 0:
@@ -572,9 +566,13 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
                      id(self.state[p]["step"])) for _, p in live)
-        plan = self._plan
+        plan = self._plan if which is None else self._plans.get(which)
         if plan is None or plan["key"] != key:
-            plan = self._plan = self._build_plan(live, key)
+            plan = self._build_plan(live, key)
+            if which is None:
+                self._plan = plan
+            else:
+                self._plans[which] = plan
         torch._foreach_add_(plan["steps"], 1)
         arrs = plan["arrs"]
         for (group, b1, b2, cfg, i), st_step in zip(plan["entries"], plan["steps"]):
@@ -587,6 +585,32 @@ class FusedAdam(torch.optim.Optimizer):
             N.check(N.lib().mom_adam_step(arr, len(arr), b1, b2, eps,
                                           None if self.skip_flag is None else self.skip_flag.data_ptr(), N.current_stream()),
                     "mom_adam_step")
+
+    @torch.no_grad()
+    def step_partial(self, params):
+        """Advance only `params` (their gradients are final) on the CURRENT stream; the step() that follows in the same iteration
+        advances the rest.  The fused training step uses it to put the Gaussians' appearance parameters -- 56 of their 59 floats,
+        four fifths of Adam's bytes -- on its second stream underneath the deformation backward (fused_step.py).  Element for
+        element the same update as one step(): Adam is element-wise."""
+        ids = {id(p) for p in params}
+        live = [(group, p) for group in self.param_groups for p in group["params"] if id(p) in ids and p.grad is not None]
+        if not live:
+            return
+        self._launch(live, "early")
+        self._early = {id(p) for _, p in live}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        early, self._early = self._early, None
+        live = [(group, p) for group in self.param_groups for p in group["params"]
+                if p.grad is not None and (early is None or id(p) not in early)]
+        if not live:
+            return loss
+        self._launch(live, None if early is None else "late")
         return loss
 
 

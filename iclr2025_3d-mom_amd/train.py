@@ -235,12 +235,22 @@ class Trainer:
         self._skip = None
         return loss
 
+    def _early_adam(self, params):
+        self.g.optimizer.skip_flag = self.fused.flags
+        self.g.optimizer.step_partial(params)
+
     def _step_fused(self, iteration, cam, replay=False):
         with torch.no_grad():
             if not replay:
                 self._serial += 1
             self.fused.next_tag = (self._serial & 0x7FFFFFFF) + 1
-            loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale)
+            # Adam for the appearance parameters starts inside the step, beside the deformation backward -- on iterations whose
+            # host logic touches no parameter between backward and optimizer.step() (a densify / prune round replaces them and
+            # the reference's step() then skips them: train_4DGS.py:266-297)
+            early = None
+            if self.dist is None and iteration < self.opt.iterations and not self._boundary(iteration):
+                early = self._early_adam
+            loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale, early_adam=early)
             self.g.optimizer.skip_flag = self._skip = self.fused.flags
             if self.dist is not None:
                 # the step began its all-reduces as each bucket became final (fused_step.py); radii and vsp_grad come

@@ -504,3 +504,39 @@ def test_deform_backward_fused_variant_equals_the_two_kernel_backward(monkeypatc
     for a, b in zip(g1, g2):
         assert float(b.abs().max()) > 0 or float(a.abs().max()) == 0
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_adam_step_taken_in_two_parts_equals_one_step():
+    """FusedAdam.step_partial(some) on a second stream followed by step() (the rest) -- how the fused training step overlaps the
+    appearance parameters' update with the deformation backward -- against one step(): bit-identical parameters, moments and
+    step counters over several iterations; a parameter is advanced exactly once per iteration."""
+    torch.manual_seed(3)
+    shapes = [(5000, 3), (5000, 1, 3), (5000, 15, 3), (5000, 4), (1, 32, 64, 64), (64, 64)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 1e-3, 1.6e-3, 1.6e-4]
+    init = [torch.randn(*s, device="cuda") for s in shapes]
+    grads = [[torch.randn(*s, device="cuda") * 10 ** (-i) for s in shapes] for i in range(3)]
+
+    def run(split):
+        ps = [torch.nn.Parameter(p.clone()) for p in init]
+        opt = ops.FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(ps, lrs)], lr=0.0, eps=1e-15)
+        side = torch.cuda.Stream()
+        for gs in grads:
+            for p, g in zip(ps, gs):
+                p.grad = g.clone()
+            if split:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    opt.step_partial([ps[1], ps[2], ps[3]])
+                torch.cuda.current_stream().wait_stream(side)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        return ps, opt
+
+    pa, oa = run(False)
+    pb, ob = run(True)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+        sa, sb = oa.state[a], ob.state[b]
+        assert float(sa["step"]) == float(sb["step"]) == 3.0
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
