@@ -918,7 +918,8 @@ int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, 
     hipLaunchKernelGGL(hexplane_lines_kernel, dim3((nline + 255) / 256), dim3(256), 0, s, a, lt, lines, nline);
     const int nchunks = (P + 31) / 32;
     static int cap = 0;
-    if (!cap) { const char* e = getenv("MOM_HEX6_BLOCKS"); cap = e ? atoi(e) : 1536; if (cap < 1) cap = 1536;   // measured: 512 293 us, 1024 281, 1536 280, 4096 280 (gather + scatter beside dW) }
+    // workgroups (MOM_HEX6_BLOCKS overrides); measured, gather + scatter beside dW: 512 293 us, 1024 281, 1536 280, 4096 280
+    if (!cap) { const char* e = getenv("MOM_HEX6_BLOCKS"); cap = e ? atoi(e) : 1536; if (cap < 1) cap = 1536; }
     int blocks = (nchunks + 3) / 4;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(hexplane_bwd6_gather_kernel, dim3(blocks), dim3(256), 0, s, a, lt, nchunks, lines, xyz, dfeat, dxyz, plane_inverse, gvbuf);

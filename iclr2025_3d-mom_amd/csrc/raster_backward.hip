@@ -81,6 +81,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     float ga[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) ga[i] = vis ? a.gacc[(size_t)idx * 12 + i] : 0.f;
+    // the compositing backward leaves raw sums (raster_render.hip): d(pixel)/d(ndc) with the sign for the mean, -1/2 for the conic
+    ga[0] *= -0.5f * (float)a.W;
+    ga[1] *= -0.5f * (float)a.H;
+    ga[2] *= -0.5f;
+    ga[3] *= -0.5f;
+    ga[4] *= -0.5f;
 
     a.dmeans2D[3 * idx + 0] = ga[0];
     a.dmeans2D[3 * idx + 1] = ga[1];

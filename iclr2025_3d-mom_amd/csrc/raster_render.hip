@@ -310,6 +310,38 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     }
 }
 
+// The same for nine values (no depth gradient: training): v[8] needs no pair step.
+__device__ __forceinline__ float reduce_scatter9(const float (&v)[9], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    const float a0 = dpp_pair<0xB1>(v[0], v[1], b0);
+    const float a1 = dpp_pair<0xB1>(v[2], v[3], b0);
+    const float a2 = dpp_pair<0xB1>(v[4], v[5], b0);
+    const float a3 = dpp_pair<0xB1>(v[6], v[7], b0);
+    const float a4 = dpp_add<0xB1, 0xF>(v[8]);
+    float c0 = dpp_pair<0x4E>(a0, a1, b1);
+    float c1 = dpp_pair<0x4E>(a2, a3, b1);
+    float c2 = dpp_add<0x4E, 0xF>(a4);                   // every lane of the quad: v[8] over the quad
+    c0 = dpp_add<0x124, 0xF>(c0); c1 = dpp_add<0x124, 0xF>(c1); c2 = dpp_add<0x124, 0xF>(c2);
+    c0 = dpp_add<0x128, 0xF>(c0); c1 = dpp_add<0x128, 0xF>(c1); c2 = dpp_add<0x128, 0xF>(c2);
+    const int k = lane & 15;
+    float m = k < 4 ? c0 : (k < 8 ? c1 : c2);
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return m;
+}
+
+// DEPTH: a gradient arrives for the depth image too (dL_dpixel_depths != null; never in training).
+// The record this kernel leaves per Gaussian (gacc, 12 floats) holds RAW sums: slots 0-1 the mean's, without the factors
+// -W/2 and -H/2 of d(pixel)/d(ndc) and the sign; slots 2-4 the conic's, without their -1/2.  The projection backward
+// (raster_backward.hip) applies those constants once per Gaussian instead of this loop once per (pixel, splat) pair.
+template <bool DEPTH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_MIN, MOM_BWD_WAVES)))   // LDS (31 KB) allows 5 workgroups per CU
 render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
@@ -352,10 +384,9 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         dp0 = dL_dpixels[pix];
         dp1 = dL_dpixels[HW + pix];
         dp2 = dL_dpixels[2 * HW + pix];
-        dpd = dL_dpixel_depths ? dL_dpixel_depths[pix] : 0.f;
+        dpd = DEPTH ? dL_dpixel_depths[pix] : 0.f;
     }
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
     // splats behind the last contributor of every pixel of this wave need no work at all
     int wave_last = last_contributor;
@@ -425,28 +456,36 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 g_c0 = w * dp0;
                 g_c1 = w * dp1;
                 g_c2 = w * dp2;
-                accum_d = last_alpha * last_depth + (1.f - last_alpha) * accum_d;
-                last_depth = r0.z;
-                dL_dalpha += (r0.z - accum_d) * dpd;
-                g_d = w * dpd;
+                if (DEPTH) {
+                    accum_d = last_alpha * last_depth + (1.f - last_alpha) * accum_d;
+                    last_depth = r0.z;
+                    dL_dalpha += (r0.z - accum_d) * dpd;
+                    g_d = w * dpd;
+                }
                 dL_dalpha *= T;
                 last_alpha = alpha;
                 dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
-                // no derivative for the 0.99 cap, exactly as the reference (backward.cu:571)
-                const float dL_dG = r1.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * r1.x - gdy * r1.y;
-                const float dG_ddely = -gdy * r1.z - gdx * r1.y;
-                g_mx = dL_dG * dG_ddelx * ddelx_dx;
-                g_my = dL_dG * dG_ddely * ddely_dy;
-                g_cx = -0.5f * gdx * dx * dL_dG;
-                g_cy = -0.5f * gdx * dy * dL_dG;
-                g_cw = -0.5f * gdy * dy * dL_dG;
+                // no derivative for the 0.99 cap, exactly as the reference (backward.cu:571).  With a = dL/dG * G:
+                //   dL/d mean   = -(W/2, H/2) * a * (conic (dx, dy))      dL/d conic = -1/2 * a * (dx^2, dx dy, dy^2)
+                // (backward.cu:573-586; the constant factors wait for the projection backward)
                 g_op = G * dL_dalpha;
+                const float a = r1.w * g_op;
+                const float ax = a * dx, ay = a * dy;
+                g_mx = ax * r1.x + ay * r1.y;
+                g_my = ay * r1.z + ax * r1.y;
+                g_cx = ax * dx;
+                g_cy = ax * dy;
+                g_cw = ay * dy;
             }
-            const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};
-            const float v = reduce_scatter10(gv, lane);
-            if (lane < 10) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
+            if (DEPTH) {
+                const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};
+                const float v = reduce_scatter10(gv, lane);
+                if (lane < 10) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
+            } else {
+                const float gv[9] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2};
+                const float v = reduce_scatter9(gv, lane);
+                if (lane < 9) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
+            }
           }
         }
     }
@@ -483,8 +522,12 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     mom_tile_rows(a, gy, &ry0, &ry1);
     const int nt = gx * (ry1 - ry0);
     if (nt == 0) return MOM_OK;
-    hipLaunchKernelGGL(render_bwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
-                       g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
+    if (dL_ddepth)
+        hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
+                           g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
+    else
+        hipLaunchKernelGGL(render_bwd_kernel<false>, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
+                           g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
