@@ -310,6 +310,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     }
 }
 
+#ifndef MOM_BWD_PEND
+#define MOM_BWD_PEND 4                // splats per atomic instruction (1..4)
+#endif
 // The same for nine values (no depth gradient: training): v[8] needs no pair step.
 __device__ __forceinline__ float reduce_scatter9(const float (&v)[9], int lane)
 {
@@ -387,6 +390,10 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         dpd = DEPTH ? dL_dpixel_depths[pix] : 0.f;
     }
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    constexpr int kVals = DEPTH ? 10 : 9;
+    float pend = 0.f;                 // reduced records waiting for their atomic: row q of the wave holds the q-th
+    uint32_t pend_id = 0;
+    int npend = 0;                    // wave-uniform
     const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
     // splats behind the last contributor of every pixel of this wave need no work at all
     int wave_last = last_contributor;
@@ -480,18 +487,28 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             // (Letting the lanes of a splat that reaches only one or two pixels of the strip add their nine values themselves --
             // nine one-lane atomic instructions instead of the reduction and one nine-lane instruction -- was measured: 284 / 298 us
             // for thresholds 1 / 2 against 274.  An atomic INSTRUCTION costs the CU more than the 33 vector instructions.)
+            float v;
             if (DEPTH) {
                 const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};
-                const float v = reduce_scatter10(gv, lane);
-                if (lane < 10) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
+                v = reduce_scatter10(gv, lane);
             } else {
                 const float gv[9] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2};
-                const float v = reduce_scatter9(gv, lane);
-                if (lane < 9) atomicAdd(&gacc[(size_t)s_id[j] * 12 + lane], v);
+                v = reduce_scatter9(gv, lane);
+            }
+            // Every 16-lane row now holds the totals (lane k of a row: value k).  Row q keeps them for the q-th splat since the
+            // last flush, and ONE atomic instruction adds four splats' records: the CU pays per atomic instruction (~50 ns), not
+            // per lane, and one instruction per (wave, splat) was exactly this kernel's time.
+            const bool mine = (lane >> 4) == npend;
+            pend = mine ? v : pend;
+            pend_id = mine ? s_id[j] : pend_id;
+            if (++npend == MOM_BWD_PEND) {
+                if ((lane & 15) < kVals && (lane >> 4) < MOM_BWD_PEND) atomicAdd(&gacc[(size_t)pend_id * 12 + (lane & 15)], pend);
+                npend = 0;
             }
           }
         }
     }
+    if (npend && (lane & 15) < kVals && (lane >> 4) < npend) atomicAdd(&gacc[(size_t)pend_id * 12 + (lane & 15)], pend);
 }
 
 }  // namespace

@@ -149,7 +149,6 @@ class FusedStep:
         dn = g._deformation.deformation_net
         field = dn.grid
         planes, mlp = self._deform_grads()
-        self._dg_flat.zero_()
         xyz, scal, rot, opac = g._xyz.detach(), g._scaling.detach(), g._rotation.detach(), g._opacity.detach()
         flow = g._scene_flow if g._scene_flow.is_contiguous() else g._scene_flow.contiguous()
         for t in (xyz, scal, rot, opac, g._features_dc, g._features_rest):
@@ -174,6 +173,39 @@ class FusedStep:
             self._desc_key, self._reg_arr = dkey, None
         hp, keep, md = self._desc
         coef = float(delta_scale * cam.frame_num)
+        # ---- second stream, first job: clear the deformation field's gradient bucket and run the plane regularisers (value +
+        # gradient; they depend on the planes only, so they need not wait for the backward) while this stream renders.  The
+        # backward's kernels then ADD into what the regulariser left; this stream waits for the event before its first write
+        # to the bucket (the projection backward's d xyz).
+        dc = self.dist
+        reg_scale = 1.0 / dc.world if dc is not None else 1.0
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+            self.regacc = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._bucket_ready = torch.cuda.Event()
+        hy = self.hyper
+        reg = None
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self._dg_flat.zero_()
+            if hy.time_smoothness_weight != 0:
+                rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, reg_scale)
+                if self._reg_arr is None or self._reg_arr[0] != rkey:
+                    arr = (N.MomRegPlane * len(planes))()
+                    for i, p in enumerate(planes):
+                        st, gs = ops.plane_storage(p.detach()), ops.plane_storage(self._dg_planes[i])
+                        arr[i].plane, arr[i].grad = st.data_ptr(), gs.data_ptr()
+                        arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+                        tplane = (i % 6) in (2, 4, 5)
+                        arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
+                        arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
+                        arr[i].grad_scale = reg_scale      # identical on every rank: the sum over ranks restores it
+                    self._reg_arr = (rkey, arr)
+                arr = self._reg_arr[1]
+                self.regacc.zero_()
+                N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regacc.data_ptr(), N.current_stream()), "plane_reg")
+                reg = self.regacc
+            self._bucket_ready.record(self.side)
         # HexPlane lookup + MLP + the activations (exp / normalize / sigmoid) in one kernel (csrc/deform_field.hip)
         dc = self.dist
         sl = None
@@ -278,6 +310,7 @@ class FusedStep:
         if dc is not None and dc.mode == "camera":
             self.dimg.mul_(inv_world)
         # ---- rasterizer backward
+        torch.cuda.current_stream().wait_event(self._bucket_ready)      # the gradient bucket is cleared and holds the regulariser's share
         gr = N.MomRasterGrads()
         gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = self.g2d.data_ptr(), self.gcol.data_ptr(), self.gop_act.data_ptr()
         gr.dL_dmeans3D, gr.dL_dcov3D = self.gxyz.data_ptr(), self.gcov.data_ptr()
@@ -376,25 +409,6 @@ class FusedStep:
                                                   None if spo is None else spo[0].data_ptr(), None if spo is None else spo[1].data_ptr(),
                                                   None if spo is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
             dc.start_gather([self.gxyz_rows], S)
-        # ---- plane regularisers (value + gradient added into the plane gradients)
-        hy = self.hyper
-        reg = None
-        if hy.time_smoothness_weight != 0:
-            rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, reg_scale)
-            if self._reg_arr is None or self._reg_arr[0] != rkey:
-                arr = (N.MomRegPlane * len(planes))()
-                for i, p in enumerate(planes):
-                    st, gs = ops.plane_storage(p.detach()), ops.plane_storage(self._dg_planes[i])
-                    arr[i].plane, arr[i].grad = st.data_ptr(), gs.data_ptr()
-                    arr[i].H, arr[i].W = st.shape[0], st.shape[1]
-                    tplane = (i % 6) in (2, 4, 5)
-                    arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
-                    arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
-                    arr[i].grad_scale = reg_scale      # identical on every rank: the sum over ranks restores it
-                self._reg_arr = (rkey, arr)
-            arr = self._reg_arr[1]
-            N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regval.data_ptr(), s), "plane_reg")
-            reg = self.regval
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         if dc is not None and dc.mode == "camera":
