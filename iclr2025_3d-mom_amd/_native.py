@@ -98,6 +98,7 @@ def _sig(lib):
     lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
     lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
     lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp]
+    lib.mom_hexplane_backward_lines.argtypes = [C.POINTER(MomHexPlane), i32, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_hexplane_backward_scratch_bytes.restype = sz
     lib.mom_hexplane_backward_scratch_bytes.argtypes = [C.POINTER(MomHexPlane), i32]
     lib.mom_hexplane_orders_scratch_bytes.restype = sz
@@ -160,7 +161,7 @@ class MomRowSelect(C.Structure):
 EXPORTS = [
     "mom_version", "mom_raster_geom_bytes", "mom_raster_image_bytes", "mom_raster_binning_bytes", "mom_raster_layout",
     "mom_raster_forward_geometry", "mom_raster_forward_render", "mom_raster_backward", "mom_mark_visible",
-    "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_adam_step", "mom_l1_loss",
+    "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_hexplane_backward_lines", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
     "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_forward_activated", "mom_deform_backward_scratch_bytes", "mom_deform_backward", "mom_deform_backward_split",

@@ -909,13 +909,13 @@ size_t mom_hexplane_lines_bytes(const MomHexPlane* hp)
 // pass 1 of the two-pass HexPlane backward for a field mom_deform_field_supported() accepts (called by mom_hexplane_backward,
 // hexplane.hip): the frame's lines into `lines`, then the gather
 int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order, const float* dfeat,
-                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, hipStream_t s)
+                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, bool lines_ready, hipStream_t s)
 {
     HexArgs a;
     fill_args(hp, P, nullptr, time, order, true, &a);
     LineTab lt;
     const int nline = line_table(hp, &lt);
-    hipLaunchKernelGGL(hexplane_lines_kernel, dim3((nline + 255) / 256), dim3(256), 0, s, a, lt, lines, nline);
+    if (!lines_ready) hipLaunchKernelGGL(hexplane_lines_kernel, dim3((nline + 255) / 256), dim3(256), 0, s, a, lt, lines, nline);
     const int nchunks = (P + 31) / 32;
     static int cap = 0;
     // workgroups (MOM_HEX6_BLOCKS overrides); measured, gather + scatter beside dW: 512 293 us, 1024 281, 1536 280, 4096 280

@@ -690,7 +690,7 @@ extern "C" int mom_hexplane_orders(const MomHexPlane* hp, int P, const float* xy
 // deform_field.hip: the gather in the fused forward's layout, for fields mom_deform_field_supported() accepts
 size_t mom_hexplane_lines_bytes(const MomHexPlane* hp);
 int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order, const float* dfeat,
-                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, hipStream_t s);
+                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, bool lines_ready, hipStream_t s);
 extern "C" int mom_deform_field_supported(const MomHexPlane* hp);
 
 static size_t gv_bytes(const MomHexPlane* hp, int P) { return mom_align_up((size_t)6 * (size_t)P * (size_t)hp->levels * 32 * sizeof(float)); }
@@ -701,9 +701,29 @@ extern "C" size_t mom_hexplane_backward_scratch_bytes(const MomHexPlane* hp, int
     return gv_bytes(hp, P) + mom_hexplane_lines_bytes(hp) + MOM_ALIGN;    // gv rows | this frame's time lines
 }
 
+static int hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
+                             const uint32_t* order, const float* dfeat, float* dxyz, const uint32_t* plane_order,
+                             const uint32_t* plane_inverse, void* scratch, const void* field_scratch, mom_stream_t stream);
+
 extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
                                      const uint32_t* order, const float* dfeat, float* dxyz, const uint32_t* plane_order,
                                      const uint32_t* plane_inverse, void* scratch, mom_stream_t stream)
+{
+    return hexplane_backward(hp, P, xyz, times, time, order, dfeat, dxyz, plane_order, plane_inverse, scratch, nullptr, stream);
+}
+
+extern "C" int mom_hexplane_backward_lines(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order,
+                                           const float* dfeat, float* dxyz, const uint32_t* plane_order,
+                                           const uint32_t* plane_inverse, void* scratch, const void* field_scratch,
+                                           mom_stream_t stream)
+{
+    if (!field_scratch || !plane_order || !plane_inverse || !scratch) return MOM_EINVAL;
+    return hexplane_backward(hp, P, xyz, nullptr, time, order, dfeat, dxyz, plane_order, plane_inverse, scratch, field_scratch, stream);
+}
+
+static int hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
+                             const uint32_t* order, const float* dfeat, float* dxyz, const uint32_t* plane_order,
+                             const uint32_t* plane_inverse, void* scratch, const void* field_scratch, mom_stream_t stream)
 {
     if (!hp || hp->channels != 32 || hp->levels < 1 || hp->levels > 4 || P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
@@ -742,8 +762,11 @@ extern "C" int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* 
         static int gather6 = -1;          // MOM_HEX_GATHER=5: the lane-per-channel gather (measurement)
         if (gather6 < 0) { const char* e = getenv("MOM_HEX_GATHER"); gather6 = (e && e[0] == '5') ? 0 : 1; }
         if (gather6 && mom_deform_field_supported(hp)) {
-            float* lines = (float*)mom_align_ptr((char*)gvbuf + gv_bytes(hp, P));
-            int rc = mom_launch_hexplane_gather6(hp, P, xyz, time, order, dfeat, dxyz, plane_inverse, gvbuf, lines, (hipStream_t)stream);
+            // the frame's time lines: the table mom_deform_field_forward left at the head of its scratch, or computed here
+            float* lines = field_scratch ? (float*)mom_align_ptr(const_cast<void*>(field_scratch))
+                                         : (float*)mom_align_ptr((char*)gvbuf + gv_bytes(hp, P));
+            int rc = mom_launch_hexplane_gather6(hp, P, xyz, time, order, dfeat, dxyz, plane_inverse, gvbuf, lines, field_scratch != nullptr,
+                                                 (hipStream_t)stream);
             if (rc) return rc;
         } else {
             const int nchunks = (P + kChunk5 - 1) / kChunk5;

@@ -487,6 +487,9 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             // (Letting the lanes of a splat that reaches only one or two pixels of the strip add their nine values themselves --
             // nine one-lane atomic instructions instead of the reduction and one nine-lane instruction -- was measured: 284 / 298 us
             // for thresholds 1 / 2 against 274.  An atomic INSTRUCTION costs the CU more than the 33 vector instructions.)
+            // Nor is the atomic instruction RATE the limit: parking the reduced records of four splats in the four 16-lane rows
+            // and adding them with one instruction per four (wave, splat) pairs measured 272 us against 274, and the step the
+            // same (900-905 steps/s either way).  The kernel is bound by vector-instruction issue.
             float v;
             if (DEPTH) {
                 const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};

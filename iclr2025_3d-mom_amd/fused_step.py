@@ -220,12 +220,12 @@ class FusedStep:
             if g1 > g0:
                 v = lambda t: t[g0:g1]
                 so = field._slice_order(xyz, g0, g1)
-                ops.field_forward(hp, md, g1 - g0, v(xyz), time, so, v(scal), v(rot), v(flow), coef, v(self.pts), v(self.sc_d),
+                lines_kept = ops.field_forward(hp, md, g1 - g0, v(xyz), time, so, v(scal), v(rot), v(flow), coef, v(self.pts), v(self.sc_d),
                                   v(self.rot_d), v(self.feat), v(self.a0), v(opac), v(self.sc), v(self.rot), v(self.op), s)
             dc.start_gather([self.pts, self.sc, self.rot, self.op, self.rot_d], S)
             dc.finish()
         else:
-            ops.field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, self.pts, self.sc_d, self.rot_d, self.feat, self.a0,
+            lines_kept = ops.field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, self.pts, self.sc_d, self.rot_d, self.feat, self.a0,
                               opac, self.sc, self.rot, self.op, s)
         # ---- rasterizer forward (async: capacity from the previous iterations, checked below)
         a = N.MomRasterArgs()
@@ -384,10 +384,16 @@ class FusedStep:
             if porders is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (P, hp.levels)):
                 self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
                 self._hex_scratch_key = (P, hp.levels)
-            N.check(lib.mom_hexplane_backward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.dfeat.data_ptr(),
-                                              self.gxyz.data_ptr(), None if porders is None else porders[0].data_ptr(),
-                                              None if porders is None else porders[1].data_ptr(),
-                                              None if porders is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
+            if porders is not None and lines_kept:      # the forward's time lines are still in the field scratch
+                N.check(lib.mom_hexplane_backward_lines(C.byref(hp), P, xyz.data_ptr(), time, optr, self.dfeat.data_ptr(),
+                                                        self.gxyz.data_ptr(), porders[0].data_ptr(), porders[1].data_ptr(),
+                                                        self._hex_scratch.data_ptr(), ops.field_scratch(hp, dev).data_ptr(), s),
+                        "hexplane_bwd")
+            else:
+                N.check(lib.mom_hexplane_backward(C.byref(hp), P, xyz.data_ptr(), None, time, optr, self.dfeat.data_ptr(),
+                                                  self.gxyz.data_ptr(), None if porders is None else porders[0].data_ptr(),
+                                                  None if porders is None else porders[1].data_ptr(),
+                                                  None if porders is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
         else:
             # tile-row shard: the deformation backward of this rank's slice only.  Its weight / plane gradients are partial sums
             # (summed over the ranks below); its position gradients complete gxyz for the slice's rows, which the ranks then

@@ -177,12 +177,13 @@ def field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, pts, sc_d,
                                              rot.data_ptr(), flow.data_ptr(), float(coef), pts.data_ptr(), sc_d.data_ptr(),
                                              rot_d.data_ptr(), q(feat), q(a0), q(opac), q(sc), q(rot_act), q(op),
                                              field_scratch(hp, xyz.device, 0 if feat is not None else P).data_ptr(), s), "deform_field_fwd")
-        return
+        return True          # the device's field scratch now holds this frame's time lines (mom_hexplane_backward_lines)
     f = feat if feat is not None else scratch_feat
     N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, float(time), q(order), f.data_ptr(), s), "hexplane_fwd")
     N.check(lib.mom_deform_forward_activated(C.byref(md), P, f.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
                                              flow.data_ptr(), float(coef), pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), q(a0),
                                              q(opac), q(sc), q(rot_act), q(op), s), "deform_fwd")
+    return False
 
 
 # --------------------------------------------------------------------------- fused deformation MLP

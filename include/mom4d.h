@@ -217,6 +217,13 @@ size_t mom_hexplane_backward_scratch_bytes(const MomHexPlane* hp, int P);
 int mom_hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, const float* times, float time,
                           const uint32_t* order, const float* dfeat, float* dxyz, const uint32_t* plane_order,
                           const uint32_t* plane_inverse, void* scratch, mom_stream_t stream);
+/* The same (two-pass path, one timestamp) for a caller that ran mom_deform_field_forward on this field at this `time` just
+ * before: field_scratch is that call's scratch, whose head still holds the frame's time lines (the three space-time planes
+ * interpolated at `time`), so they are not computed again.  The caller guarantees that neither the planes nor the scratch
+ * changed in between (the fused training step: forward and backward of one camera).  Reference: as mom_hexplane_backward. */
+int mom_hexplane_backward_lines(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order,
+                                const float* dfeat, float* dxyz, const uint32_t* plane_order, const uint32_t* plane_inverse,
+                                void* scratch, const void* field_scratch, mom_stream_t stream);
 /* Per-plane processing orders for the two-pass backward: for each space plane (x,y), (x,z), (y,z) and each level the
  * permutation of 0..P-1 that sorts the points by the texel cell of that level they fall into (2-D Morton order over the
  * cells), and its inverse.  Like `order`, they never change a result; they may be reused while the points drift (refresh
