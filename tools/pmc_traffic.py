@@ -29,7 +29,7 @@ import sys
 # kernel symbol -> the name bench.py / profiling.py use
 NAMES = {
     "render_bwd_kernel": "render_bwd", "render_fwd_kernel": "render_fwd", "hexplane_bwd5_gather_kernel": "hexplane_bwd_gather",
-    "hexplane_bwd5_scatter_kernel": "hexplane_bwd_scatter",
+    "hexplane_bwd5_scatter_kernel": "hexplane_bwd_scatter", "hexplane_bwd6_gather_kernel": "hexplane_bwd_gather",
     "hexplane_fwd4_kernel": "hexplane_fwd", "adam_kernel": "adam", "l1_kernel": "l1_loss",
     "preprocess_fwd_kernel": "preprocess_fwd", "preprocess_bwd_kernel": "preprocess_bwd", "tile_sort_kernel": "tile_sort",
     "deform_fwd_kernel": "mlp_fwd", "deform_bwd_dx_kernel": "mlp_bwd_dx", "deform_bwd_dw_kernel": "mlp_bwd_dw",
@@ -63,6 +63,11 @@ def main():
         if not fv or not wv:
             continue
         f_kib, w_kib = sum(fv) / len(fv), sum(wv) / len(wv)
+        if sym == "adam_kernel":
+            # the optimizer step is taken in two launches (appearance parameters early, on the second stream; the rest late): the
+            # figure is per STEP -- launches per step from the launch counts of adam and the compositing backward
+            per_step = max(1, round(len(fetch[sym]) / max(1, len(fetch.get("render_bwd_kernel", [])))))
+            f_kib, w_kib = f_kib * per_step, w_kib * per_step
         rd, wr = int(round(f_kib * 1024 * 2)), int(round(w_kib * 1024))
         rows.append([sym, len(fv), round(f_kib, 1), round(w_kib, 1), rd, wr, rd + wr])
         kernels[short] = {"launches_averaged": len(fv), "FETCH_SIZE_KiB_raw": round(f_kib, 1),
