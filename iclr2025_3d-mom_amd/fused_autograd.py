@@ -186,7 +186,7 @@ def _field_grads(st, f, direct=True):
                                   or not ops._buffers_free(c[3]) or not ops._buffers_free(c[2], 2))   # a caller kept last iteration's gradient tensors (planes: also in `targets`)
     if c is not None and c[0] == key and not own_busy:
         c[1].zero_()
-        return c[4], c[3], c[5], c[7], in_place
+        return [held[i] if in_place[i] else c[2][i] for i in range(len(c[2]))], c[3], c[5], c[7], in_place
     n = sum(p.numel() for p in st.planes + st.mlp)
     flat = torch.zeros(n, **f)
     off, gplanes, gmlp = 0, [], []
@@ -205,7 +205,10 @@ def _field_grads(st, f, direct=True):
     hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in field.grids], field.aabb, levels, aabb_host=field.aabb_host())
     md = ops.DeformMLPFunction._desc([p.detach() for p in st.mlp], gmlp)
     if not own_busy:
-        field._fa_grads = (key, flat, gplanes, gmlp, targets, hp, keep, md)
+        # (no reference to `held`: those are the regulariser's cached gradient views, and a reference kept here made ITS cache
+        # look busy in the next iteration -- it then made new buffers, this key changed, and both caches missed every iteration:
+        # 1 ms of host time per step, found with tools/host_profile.py --autograd)
+        field._fa_grads = (key, flat, gplanes, gmlp, None, hp, keep, md)
     return targets, gmlp, hp, md, in_place
 
 
