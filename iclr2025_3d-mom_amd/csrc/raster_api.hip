@@ -8,9 +8,9 @@ int mom_launch_mark_visible(int P, const float* means3D, const float* view, uint
 int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const ImageView& im, uint32_t* num_rendered_dev,
                              uint32_t* num_rendered_host, bool hist_done, hipStream_t s);
 int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
-                            uint32_t* status_dev, hipStream_t s);
+                            uint32_t* status_dev, bool render_sorts_small, hipStream_t s);
 int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
-                          float* out_color, float* out_depth, hipStream_t s);
+                          float* out_color, float* out_depth, bool sort_small, hipStream_t s);
 int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
                           const float* dL_dpix, const float* dL_ddepth, hipStream_t s);
 int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const GeomView& g, const MomRasterGrads* gr, hipStream_t s);
@@ -122,10 +122,12 @@ int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning,
     geom_view(mom_align_ptr(geom), a->P, &g);
     image_view(mom_align_ptr(image), a->W, a->H, &im);
     bin_view(mom_align_ptr(binning), capacity, &b);
-    rc = mom_launch_binning_sort(a, g, b, im, capacity, status_dev, s);
+    static int merged = -1;             // MOM_RENDER_SORT=0: every tile sorted by the binning's own launches (measurement)
+    if (merged < 0) { const char* e = getenv("MOM_RENDER_SORT"); merged = (e && e[0] == '0') ? 0 : 1; }
+    rc = mom_launch_binning_sort(a, g, b, im, capacity, status_dev, merged != 0, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
-    rc = mom_launch_render_fwd(a, g, b, im, capacity, out_color, out_depth, s);
+    rc = mom_launch_render_fwd(a, g, b, im, capacity, out_color, out_depth, merged != 0, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);
     return MOM_OK;

@@ -98,3 +98,56 @@ __device__ __forceinline__ uint64_t decide_instances(int x0, int y0, int x1, int
 
 
 }  // namespace
+
+// ---- per-tile sort ------------------------------------------------------------
+// Bitonic network in the "flip then disperse" form: every compare-exchange puts
+// the smaller key at the lower index, so virtual +inf padding above n never moves
+// and is simply skipped.
+//
+// All strides are powers of two: indices come from shifts and masks (a division by a run-time stride costs ~40
+// instructions per compare-exchange).  Thread t works on the compare-exchanges i = t, t + nthreads, ...; a wave's 64
+// consecutive i touch one aligned block of 128 keys whenever the stage's span (kk for a flip, 2j for a disperse step)
+// is at most 128, so two such stages in a row exchange data inside the wave only and need no workgroup barrier --
+// for 1024 keys that leaves 6 of 55.  A barrier is kept wherever either neighbour stage is wider.  With BLOCK_SYNC
+// false (the global-memory path of oversized buckets) every stage keeps its barrier.
+template <bool LOCAL_STAGES, class KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int nthreads, int tid)
+{
+    int lm = 0;
+    while ((1 << lm) < n) lm++;
+    const int half_m = (1 << lm) >> 1;
+    bool prev_wide = true;                                   // the loads before the first stage came from all waves
+    auto sync_before = [&](int span) {
+        const bool wide = !LOCAL_STAGES || span > 128;
+        if (wide || prev_wide) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
+        prev_wide = wide;
+    };
+    for (int lk = 1; lk <= lm; lk++) {
+        const int kk = 1 << lk, lh = lk - 1, half = kk >> 1;
+        sync_before(kk);
+        for (int i = tid; i < half_m; i += nthreads) {
+            const int blk = i >> lh, off = i & (half - 1);
+            const int a = (blk << lk) + off, b = (blk << lk) + kk - 1 - off;
+            if (b < n) {
+                const uint64_t ka = k[a], kb = k[b];
+                if (ka > kb) { k[a] = kb; k[b] = ka; }
+            }
+        }
+        for (int lj = lk - 2; lj >= 0; lj--) {
+            const int j = 1 << lj;
+            sync_before(2 * j);
+            for (int i = tid; i < half_m; i += nthreads) {
+                const int a = ((i >> lj) << (lj + 1)) + (i & (j - 1)), b = a + j;
+                if (b < n) {
+                    const uint64_t ka = k[a], kb = k[b];
+                    if (ka > kb) { k[a] = kb; k[b] = ka; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+
+constexpr int kRenderSortCap = 1536;

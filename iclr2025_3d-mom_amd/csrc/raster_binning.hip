@@ -248,56 +248,7 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
     }
 }
 
-// ---- per-tile sort ------------------------------------------------------------
-// Bitonic network in the "flip then disperse" form: every compare-exchange puts
-// the smaller key at the lower index, so virtual +inf padding above n never moves
-// and is simply skipped.
-//
-// All strides are powers of two: indices come from shifts and masks (a division by a run-time stride costs ~40
-// instructions per compare-exchange).  Thread t works on the compare-exchanges i = t, t + nthreads, ...; a wave's 64
-// consecutive i touch one aligned block of 128 keys whenever the stage's span (kk for a flip, 2j for a disperse step)
-// is at most 128, so two such stages in a row exchange data inside the wave only and need no workgroup barrier --
-// for 1024 keys that leaves 6 of 55.  A barrier is kept wherever either neighbour stage is wider.  With BLOCK_SYNC
-// false (the global-memory path of oversized buckets) every stage keeps its barrier.
-template <bool LOCAL_STAGES, class KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int nthreads, int tid)
-{
-    int lm = 0;
-    while ((1 << lm) < n) lm++;
-    const int half_m = (1 << lm) >> 1;
-    bool prev_wide = true;                                   // the loads before the first stage came from all waves
-    auto sync_before = [&](int span) {
-        const bool wide = !LOCAL_STAGES || span > 128;
-        if (wide || prev_wide) __syncthreads();
-        else __builtin_amdgcn_wave_barrier();
-        prev_wide = wide;
-    };
-    for (int lk = 1; lk <= lm; lk++) {
-        const int kk = 1 << lk, lh = lk - 1, half = kk >> 1;
-        sync_before(kk);
-        for (int i = tid; i < half_m; i += nthreads) {
-            const int blk = i >> lh, off = i & (half - 1);
-            const int a = (blk << lk) + off, b = (blk << lk) + kk - 1 - off;
-            if (b < n) {
-                const uint64_t ka = k[a], kb = k[b];
-                if (ka > kb) { k[a] = kb; k[b] = ka; }
-            }
-        }
-        for (int lj = lk - 2; lj >= 0; lj--) {
-            const int j = 1 << lj;
-            sync_before(2 * j);
-            for (int i = tid; i < half_m; i += nthreads) {
-                const int a = ((i >> lj) << (lj + 1)) + (i & (j - 1)), b = a + j;
-                if (b < n) {
-                    const uint64_t ka = k[a], kb = k[b];
-                    if (ka > kb) { k[a] = kb; k[b] = ka; }
-                }
-            }
-        }
-    }
-    __syncthreads();
-}
-
+// ---- per-tile sort: bitonic_sort lives in raster_bin_dev.h (the compositing forward sorts the small tiles itself) ----
 // CAP: keys this instantiation sorts in LDS; it handles the tiles with LO < n <= CAP (n > kSortLdsCap: in global memory) and
 // leaves the others to the sibling launch.  A single kernel sized for the worst case reserved 64 KB of LDS for every tile
 // and fitted two workgroups per CU, while the average tile at 960x540 has ~650 keys.
@@ -365,7 +316,7 @@ int mom_launch_binning_count(const MomRasterArgs* a, const GeomView& g, const Im
 }
 
 int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
-                            uint32_t* status_dev, hipStream_t s)
+                            uint32_t* status_dev, bool render_sorts_small, hipStream_t s)
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const int tiles = gx * gy;
@@ -394,6 +345,13 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     MomProfScope ps(MOM_P_SORT, s);
     const int nt = gx * (ry1 - ry0);      // the rows the geometry stage binned: the order covers exactly these tiles
     if (nt == 0) return MOM_OK;
+    if (render_sorts_small) {
+        // tiles of up to kRenderSortCap keys are sorted by the compositing forward itself (raster_render.hip), in the LDS it stages
+        // its splats in afterwards: one launch and one pass over the keys less; this launch takes the rest
+        hipLaunchKernelGGL((tile_sort_kernel<kRenderSortCap, kSortLdsCap>), dim3(nt), dim3(256), 0, s, im.ranges, im.tile_order, b.keys,
+                           b.point_list, cap);
+        return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+    }
     hipLaunchKernelGGL((tile_sort_kernel<0, kSortSmallCap>), dim3(nt), dim3(256), 0, s, im.ranges, im.tile_order, b.keys, b.point_list,
                        cap);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;

@@ -12,6 +12,7 @@
 // instruction per (wave, splat) into the per-Gaussian accumulator record
 // gacc[P][12].
 #include "mom_common.h"
+#include "raster_bin_dev.h"
 
 namespace {
 
@@ -186,7 +187,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FW
 render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-                  uint32_t capacity, L1Epilogue l1)
+                  uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys, uint32_t* __restrict__ sorted_out)
 {
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
@@ -210,6 +211,21 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + kRound - 1) / kRound;
+
+    // The tile's depth sort, for tiles whose keys fit the LDS the rounds below stage their splats in (sort_keys == null: the
+    // binning sorted every tile).  The sorted indices go to point_list -- the backward walks it too -- and are read back from
+    // there by this workgroup (same CU: its stores are visible to its loads after the barrier).
+    static_assert(kRenderSortCap * 8 <= kRound * 3 * 16, "the sort aliases the splat staging area");
+    if (sort_keys && toDo > 0 && toDo <= kRenderSortCap) {
+        uint64_t* sk = reinterpret_cast<uint64_t*>(s_rec);
+        const uint64_t* __restrict__ gk = sort_keys + range.x;
+        for (int i = threadIdx.x; i < toDo; i += 256) sk[i] = gk[i];
+        __syncthreads();
+        if (toDo > 1) bitonic_sort<true>(sk, toDo, 256, (int)threadIdx.x);
+        for (int i = threadIdx.x; i < toDo; i += 256) sorted_out[range.x + i] = (uint32_t)sk[i];
+        __threadfence_block();
+        __syncthreads();
+    }
 
     float T = 1.0f;
     uint32_t last_contributor = 0;
@@ -517,7 +533,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
 }  // namespace
 
 int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinView& b, const ImageView& im, size_t capacity,
-                          float* out_color, float* out_depth, hipStream_t s)
+                          float* out_color, float* out_depth, bool sort_small, hipStream_t s)
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
@@ -530,7 +546,7 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     if (!l1.grad || !l1.sums) l1.target = nullptr;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
-                       out_depth, cap, l1);
+                       out_depth, cap, l1, sort_small ? b.keys : nullptr, b.point_list);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
