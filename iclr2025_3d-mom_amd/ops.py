@@ -588,6 +588,17 @@ class FusedAdam(torch.optim.Optimizer):
                     "mom_adam_step")
 
     @torch.no_grad()
+    def ensure_state(self, params):
+        """Create the Adam state of `params` now, on the current stream (torch.optim.Adam creates it in the first step() that sees
+        a gradient; a step_partial() on a second stream would otherwise allocate the moments from that stream's pool)."""
+        for p in params:
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+
+    @torch.no_grad()
     def step_partial(self, params):
         """Advance only `params` (their gradients are final) on the CURRENT stream; the step() that follows in the same iteration
         advances the rest.  The fused training step uses it to put the Gaussians' appearance parameters -- 56 of their 59 floats,

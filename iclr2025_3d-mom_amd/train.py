@@ -250,6 +250,8 @@ class Trainer:
             early = None
             if self.dist is None and iteration < self.opt.iterations and not self._boundary(iteration):
                 early = self._early_adam
+                g_ = self.g
+                g_.optimizer.ensure_state([g_._features_dc, g_._features_rest, g_._scaling, g_._rotation, g_._opacity])
             loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale, early_adam=early)
             self.g.optimizer.skip_flag = self._skip = self.fused.flags
             if self.dist is not None:

@@ -17,10 +17,23 @@ for i in range(20):
 trainer.drain(); torch.cuda.synchronize()
 t0 = time.perf_counter()
 losses = []
+windows = os.environ.get("LONG_WINDOWS") == "1"        # wall time of every 100-iteration window, split at 10 steps after the boundary
+tw, marks = time.perf_counter(), []
 for i in range(20, 20 + n):
     l = trainer.step(it0 + i)
     if i % 100 == 0:
         losses.append((it0 + i, float(l), g.get_xyz.shape[0], trainer.replayed))
+    if windows and (it0 + i) % 100 in (10, 95):
+        trainer.drain(); torch.cuda.synchronize()
+        now = time.perf_counter()
+        marks.append(((it0 + i) % 100, now - tw))
+        tw = now
+if windows:
+    plain = [t for k, t in marks[1:] if k == 95]      # 85 iterations without a boundary
+    bound = [t for k, t in marks[1:] if k == 10]      # 15 iterations around a boundary
+    print("boundary windows (ms):", " ".join("%.1f" % (1e3 * t) for t in bound))
+    print("plain 85 iterations: %.1f ms (%.0f steps/s); 15 around a boundary: %.1f ms" % (
+        1e3 * sum(plain) / len(plain), 85 * len(plain) / sum(plain), 1e3 * sum(bound) / len(bound)))
 trainer.drain(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 for row in losses:
