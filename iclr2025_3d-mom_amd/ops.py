@@ -536,27 +536,29 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] -= float(n)
 
     def _build_plan(self, live, key):
-        """Validate every (param, grad, state) once and lay the MomAdamTensor arrays out; reused until a pointer moves
-        (densify / prune / reset_opacity replace parameters and state, load_state_dict replaces state)."""
-        by_cfg, entries, steps = {}, [], []
+        """Validate every (param, state) once and lay the MomAdamTensor arrays out; reused until a parameter or a moment moves
+        (densify / prune / reset_opacity replace parameters and state, load_state_dict replaces state).  The gradient pointers
+        are NOT part of the plan's identity: under autograd the gradients are fresh tensors every iteration, and a plan keyed on
+        them was rebuilt in four iterations out of ten (0.5 ms of host time each); they are refreshed per step instead."""
+        by_cfg, entries, steps, params = {}, [], [], []
         for group, p in live:
             _need_cuda(p, "FusedAdam")
             st = self.state[p]
-            g = p.grad
-            if not _same_layout(g, p) or not _dense(p):
-                raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
+            if not _dense(p):
+                raise N.MomError("FusedAdam: parameters must be dense")
             b1, b2 = group["betas"]
             cfg = (b1, b2, group["eps"])
             slot = by_cfg.setdefault(cfg, [])
             t = N.MomAdamTensor()
-            t.param, t.grad = p.data_ptr(), g.data_ptr()
+            t.param = p.data_ptr()
             t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             t.n = p.numel()
             entries.append((group, b1, b2, cfg, len(slot)))
             slot.append(t)
             steps.append(st["step"])
+            params.append(p)
         arrs = {cfg: (N.MomAdamTensor * len(ts))(*ts) for cfg, ts in by_cfg.items()}
-        return {"key": key, "entries": entries, "steps": steps, "arrs": arrs}
+        return {"key": key, "entries": entries, "steps": steps, "arrs": arrs, "params": params}
 
     def _launch(self, live, which):
         for _, p in live:
@@ -565,15 +567,21 @@ class FusedAdam(torch.optim.Optimizer):
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
-                     id(self.state[p]["step"])) for _, p in live)
-        plan = self._plan if which is None else self._plans.get(which)
+        key = tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                     id(self.state[p]["step"]), p.numel()) for _, p in live)
+        plan = self._plans.get(which)
         if plan is None or plan["key"] != key:
-            plan = self._build_plan(live, key)
-            if which is None:
-                self._plan = plan
-            else:
-                self._plans[which] = plan
+            plan = self._plans[which] = self._build_plan(live, key)
+        if which is None:
+            self._plan = plan
+        # this step's gradients: pointers refreshed and layouts checked every step (a pointer or an id() may be reused by another tensor)
+        for (group, b1, b2, cfg, i), p in zip(plan["entries"], plan["params"]):
+            g = p.grad
+            if g.shape != p.shape or not g.is_cuda or g.dtype != p.dtype:
+                raise N.MomError("FusedAdam: gradient of another shape, device or dtype than its parameter")
+            if g.stride() != p.stride() and not _same_layout(g, p):
+                raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
+            plan["arrs"][cfg][i].grad = g.data_ptr()
         torch._foreach_add_(plan["steps"], 1)
         arrs = plan["arrs"]
         for (group, b1, b2, cfg, i), st_step in zip(plan["entries"], plan["steps"]):
