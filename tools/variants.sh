@@ -7,7 +7,8 @@ make -j8 >/dev/null || exit 1
 mkdir -p ../lib/var
 base=$(basename $src .hip)
 extra=""
-case $base in raster_preprocess|knn) extra="-ffp-contract=off";; deform_field) extra="-fno-slp-vectorize";; esac
+extra="-fno-slp-vectorize"
+case $base in raster_preprocess|knn) extra="$extra -ffp-contract=off";; esac
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $extra $flags -c $base.hip -o ../lib/var/$name.o || exit 1
