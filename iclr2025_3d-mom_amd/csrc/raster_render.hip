@@ -503,9 +503,6 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             // (Letting the lanes of a splat that reaches only one or two pixels of the strip add their nine values themselves --
             // nine one-lane atomic instructions instead of the reduction and one nine-lane instruction -- was measured: 284 / 298 us
             // for thresholds 1 / 2 against 274.  An atomic INSTRUCTION costs the CU more than the 33 vector instructions.)
-            // Nor is the atomic instruction RATE the limit: parking the reduced records of four splats in the four 16-lane rows
-            // and adding them with one instruction per four (wave, splat) pairs measured 272 us against 274, and the step the
-            // same (900-905 steps/s either way).  The kernel is bound by vector-instruction issue.
             float v;
             if (DEPTH) {
                 const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};
@@ -515,8 +512,9 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 v = reduce_scatter9(gv, lane);
             }
             // Every 16-lane row now holds the totals (lane k of a row: value k).  Row q keeps them for the q-th splat since the
-            // last flush, and ONE atomic instruction adds four splats' records: the CU pays per atomic instruction (~50 ns), not
-            // per lane, and one instruction per (wave, splat) was exactly this kernel's time.
+            // last flush, and ONE atomic instruction adds four splats' records.  Measured 272 against 274 us with one instruction
+            // per (wave, splat) pair, the step the same: the atomic instruction rate is not this kernel's limit either (it is
+            // bound by vector-instruction issue); kept because it is never slower and quarters the atomic instructions.
             const bool mine = (lane >> 4) == npend;
             pend = mine ? v : pend;
             pend_id = mine ? s_id[j] : pend_id;
