@@ -370,11 +370,14 @@ deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat,
 // vector ALU, so a second wave per SIMD would not overlap its vector work with this wave's matrix work anyway:
 // tools/probe/mfma_valu_coissue.hip.)
 //
-// MEASURED (round 3, 200 k Gaussians): 333 us against 153 us for dx with the weight-gradient kernel hidden on the second
-// stream; the training step goes from 1213 to 1328 us.  One wave per SIMD has nobody to cover its LDS round trips (two operand
-// reads per MFMA in the recomputed head layer, the staging transposes, 30 scratch reloads per tile), and the saved traffic was
-// never on the critical path: the two-kernel form overlaps the weight gradients with the HexPlane backward.  The kernel is
-// correct (tests/test_ops_gpu.py compares it with the two-kernel form) and stays opt-in: MOM_MLP_BWD=fused.
+// MEASURED (round 3, 200 k Gaussians).  First version: 333 us against 153 us for dx with the weight-gradient kernel hidden on the
+// second stream.  Second version (a0 kept in registers as the recomputed layers' B operand instead of two LDS reads per MFMA; the
+// 64 MFMAs of dA0 += W1^T dH1 placed between the staging writes and their read-back; no spills once the SLP vectoriser was off):
+// 266 us against 183 (dx with Adam's early launch beside it), the HexPlane backward beside it 222 us instead of 258 -- it has the
+// chip and 480 MB less traffic to share -- and the step 870 against 932 steps/s.  The arithmetic decides it: the one-kernel form
+// puts all 640 f32 MFMAs per tile on the critical path (119 us at the pipe's full rate, which these kernels reach to 55 %),
+// the two-kernel form 448, with the other 256 hidden on the second stream; the bytes saved buy back 36 us of the 83.
+// The kernel is correct (tests/test_ops_gpu.py compares it with the two-kernel form) and stays opt-in: MOM_MLP_BWD=fused.
 constexpr int kFusedStage = 2 * kHid * kStageStride + 4 * 32;          // sA | sX | dout[32][4]
 constexpr int kLFusedStage = kLFwdTotal;
 constexpr int kLFusedTotal = kLFusedStage + 4 * kFusedStage;
@@ -474,21 +477,18 @@ deform_bwd_fused_kernel(MlpDev m, int P, int tiles, const float* __restrict__ fe
         float* sX = sA + kHid * kStageStride;
         float* sD = sX + kHid * kStageStride;           // dout[32 gaussians][4]
         const float* L = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + lds_off);
-        f32x16 dA0[2];
-        {
-            f32x16 a0[2];
-            load_feat(a0g, g, ok, h, a0);
-            __builtin_amdgcn_wave_barrier();
-            stage_tile(sX, a0, col, h);                // X of the three head layers, and their B operand (read back from here)
-            __builtin_amdgcn_wave_barrier();
-        }
+        f32x16 dA0[2], a0[2];
+        load_feat(a0g, g, ok, h, a0);                  // stays in registers: the B operand of the three recomputed head layers
+        __builtin_amdgcn_wave_barrier();
+        stage_tile(sX, a0, col, h);                    // and, transposed, the X operand of their weight gradients
+        __builtin_amdgcn_wave_barrier();
         zero_tile(dA0);
 #pragma unroll
         for (int head = 0; head < 3; head++) {
             const int nout = head == 2 ? 4 : 3;
             f32x16 a1[2];
             init_bias(L + kLB + (1 + head) * kHid, a1, h);
-            layer64_ldsB(L + kLW + (1 + head) * kWFloats, sX, a1, col, h);
+            layer64<false>(L + kLW + (1 + head) * kWFloats, a0, a1, col, h);
             relu_tile(a1);
             const float* __restrict__ dsrc = head == 0 ? dpts : (head == 1 ? dscales : drots);
             float dout[4];
@@ -533,8 +533,9 @@ deform_bwd_fused_kernel(MlpDev m, int P, int tiles, const float* __restrict__ fe
             __builtin_amdgcn_wave_barrier();
             stage_tile(sA, a1, col, h);                // dH1^T for the weight gradient (the staged a1 has been consumed)
             __builtin_amdgcn_wave_barrier();
+            layer64<true>(L + kLW + (1 + head) * kWFloats, a1, dA0, col, h);     // dA0 += W1^T dH1: 64 MFMAs between the staging
+            __builtin_amdgcn_sched_barrier(0);                                   // writes above and their read-back below
             dw_accumulate(sA, sX, dW[kNR - 3 + head], db[kNR - 3 + head], col, h);
-            layer64<true>(L + kLW + (1 + head) * kWFloats, a1, dA0, col, h);     // dA0 += W1^T dH1
             __builtin_amdgcn_sched_barrier(0);          // the heads stay apart: interleaved by the scheduler they spill
         }
         // through the ReLU between trunk and heads (a0 = relu(h0) is still staged in sX)
