@@ -759,8 +759,9 @@ static int hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, con
             const char* e2 = getenv("MOM_HEX_SBLOCKS");
             blocks_s = e2 ? atoi(e2) : 512;
         }
-        static int gather6 = -1;          // MOM_HEX_GATHER=5: the lane-per-channel gather (measurement)
-        if (gather6 < 0) { const char* e = getenv("MOM_HEX_GATHER"); gather6 = (e && e[0] == '5') ? 0 : 1; }
+        // MOM_HEX_GATHER=5: the lane-per-channel gather (measurement, and the comparison in tests/test_ops_gpu.py; read per call)
+        const char* e_g = getenv("MOM_HEX_GATHER");
+        const int gather6 = (e_g && e_g[0] == '5') ? 0 : 1;
         if (gather6 && mom_deform_field_supported(hp)) {
             // the frame's time lines: the table mom_deform_field_forward left at the head of its scratch, or computed here
             float* lines = field_scratch ? (float*)mom_align_ptr(const_cast<void*>(field_scratch))

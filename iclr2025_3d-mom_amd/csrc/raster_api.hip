@@ -122,8 +122,10 @@ int mom_raster_forward_render(const MomRasterArgs* a, void* geom, void* binning,
     geom_view(mom_align_ptr(geom), a->P, &g);
     image_view(mom_align_ptr(image), a->W, a->H, &im);
     bin_view(mom_align_ptr(binning), capacity, &b);
-    static int merged = -1;             // MOM_RENDER_SORT=0: every tile sorted by the binning's own launches (measurement)
-    if (merged < 0) { const char* e = getenv("MOM_RENDER_SORT"); merged = (e && e[0] == '0') ? 0 : 1; }
+    // MOM_RENDER_SORT=0: every tile sorted by the binning's own launches (measurement, and the comparison in tests/test_raster_gpu.py;
+    // read per call for that)
+    const char* e_sort = getenv("MOM_RENDER_SORT");
+    const int merged = (e_sort && e_sort[0] == '0') ? 0 : 1;
     rc = mom_launch_binning_sort(a, g, b, im, capacity, status_dev, merged != 0, s);
     if (rc) return rc;
     MOM_CHECK_LAUNCH(a, s);

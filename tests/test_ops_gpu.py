@@ -540,3 +540,30 @@ def test_adam_step_taken_in_two_parts_equals_one_step():
         sa, sb = oa.state[a], ob.state[b]
         assert float(sa["step"]) == float(sb["step"]) == 3.0
         assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"])
+
+
+@pytest.mark.parametrize("res,n,t", [((64, 64, 64, 25), 20011, 0.41), ((16, 12, 10, 7), 1000, 1.0)])
+def test_hexplane_backward_gather_in_the_forward_layout_equals_the_lane_per_channel_gather(res, n, t, monkeypatch):
+    """hexplane_bwd6_gather (csrc/deform_field.hip: eight lanes per (point, level), the time planes as this frame's lines, both
+    levels per wave) against hexplane_bwd5_gather (MOM_HEX_GATHER=5), through the same scatter: plane gradients and position
+    gradients agree to the rounding of their different summation orders."""
+    f = _field(res, (1, 2)).cuda()
+    pts = _points(n)
+    w = torch.randn(n, f.feat_dim, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run(mode):
+        monkeypatch.setenv("MOM_HEX_GATHER", mode)
+        f.zero_grad()
+        p = pts.cuda().requires_grad_(True)
+        (f(p, t) * w).sum().backward()
+        torch.cuda.synchronize()
+        return p.grad.clone(), [[q.grad.clone() for q in g] for g in f.grids]
+
+    g5, p5 = run("5")
+    g6, p6 = run("6")
+    sc = float(g5.abs().max())
+    assert float((g5 - g6).abs().max()) <= 2e-5 * sc
+    for la, lb in zip(p5, p6):
+        for a, b in zip(la, lb):
+            assert float(b.abs().max()) > 0
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())

@@ -439,3 +439,22 @@ def test_tile_cull_with_degenerate_splats():
     for k in ("color", "depth", "final_T"):
         np.testing.assert_array_equal(a[k].view(np.uint32), b[k].view(np.uint32))
     np.testing.assert_array_equal(a["radii"], b["radii"])
+
+
+@pytest.mark.parametrize("seed,P,W,H,kw", [(51, 6000, 208, 112, {}), (52, 12800, 208, 112, {}), (53, 20000, 160, 96, {})])
+def test_tile_sort_inside_the_compositing_forward_changes_nothing(seed, P, W, H, kw, monkeypatch):
+    """The compositing forward sorts the tiles of up to 1536 keys itself (csrc/raster_render.hip); MOM_RENDER_SORT=0 leaves every
+    tile to the binning's sort launches.  Same per-tile lists, same images, same counters, bit for bit; the second scene has
+    tiles on both sides of the 1536-key limit."""
+    from hip_helpers import hip_forward
+    s = random_gaussians(P, seed=seed, W=W, H=H, **kw)
+    monkeypatch.setenv("MOM_RENDER_SORT", "0")
+    a = hip_forward(s)
+    monkeypatch.setenv("MOM_RENDER_SORT", "1")
+    b = hip_forward(s)
+    assert a["R"] == b["R"] > 0
+    n = (a["ranges"][:, 1] - a["ranges"][:, 0]).astype(np.int64)
+    if P == 12800:       # this scene has tiles on both sides of the limit (the first only below, the third only above)
+        assert n.max() > 1536 > n[n > 0].min(), (n.min(), n.max())
+    for k in ("ranges", "point_list", "color", "depth", "final_T", "n_contrib", "radii"):
+        np.testing.assert_array_equal(a[k], b[k])
