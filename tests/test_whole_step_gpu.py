@@ -86,7 +86,7 @@ def test_loss_curve_of_config_1_replayed_on_hip():
     the CPU oracle path.  The same 100 iterations on the HIP path (coarse: autograd path; fine: fused step) must follow the
     same curve.  Adam with eps = 1e-15 turns a sign flip of a vanishing gradient into a full learning-rate step, so two
     correct fp32 implementations drift apart slowly: the loss is held to 2e-3 relative over all 100 iterations (1e-4 over the
-    first 5 of each stage), the Gaussian count exactly, the parameter sums to 1e-3 of their absolute sums."""
+    first 5 of each stage), the Gaussian count exactly, the parameter sums to 1e-3 of their absolute sums (rotations: 3e-3, see below)."""
     from oracle.make_curve_fixture import run, N_COARSE
     d = np.load(os.path.join(ROOT, "tests", "golden", "g10_loss_curve.npz"))
     losses, points, cs, xyz = run("cuda", fused_fine=True)
@@ -95,8 +95,13 @@ def test_loss_curve_of_config_1_replayed_on_hip():
     rel = np.abs(losses - ref) / np.abs(ref)
     assert float(rel[:5].max()) <= 1e-4 and float(rel[N_COARSE:N_COARSE + 5].max()) <= 1e-4, (rel[:5], rel[N_COARSE:N_COARSE + 5])
     assert float(rel.max()) <= 2e-3, (int(rel.argmax()), float(rel.max()))
+    # Measured over 40 runs (tools/probe/curve_spread.py): every sum within 1.2e-4 of its absolute sum (10 x inside the bound) --
+    # except the rotations', 9.5e-4 in the median and up to 1.04e-3: the gradient of a quaternion along its own direction vanishes
+    # (the rasterizer normalises it), its sign is rounding noise, and Adam turns each sign into a full learning-rate step, so
+    # that component random-walks for 100 iterations on either implementation.  It gets the bound that goes with that.
     for k in cs:
         if k.startswith("sum_"):
             tot = float(d["abs_" + k[4:]])
-            assert abs(cs[k] - float(d[k])) <= 1e-3 * max(tot, 1e-12), (k, cs[k], float(d[k]), tot)
+            bound = 3e-3 if k == "sum_rotation" else 1e-3
+            assert abs(cs[k] - float(d[k])) <= bound * max(tot, 1e-12), (k, cs[k], float(d[k]), tot)
     np.testing.assert_allclose(xyz, d["xyz_sample"], rtol=0, atol=2e-3)
