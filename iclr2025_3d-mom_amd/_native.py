@@ -32,7 +32,8 @@ class MomRasterArgs(C.Structure):
                 ("forward_only", C.c_int),                          # no backward will follow: skip the state only it reads
                 ("overflow_tag", C.c_uint),                         # what an overflow of this call leaves in *status_dev
                 ("keep_all_tiles", C.c_int),                        # !=0: bin the whole rectangle like the reference (tests)
-                ("l1_target", C.c_void_p), ("l1_grad", C.c_void_p), ("l1_sums", C.c_void_p)]   # optional L1 epilogue of the forward
+                ("l1_target", C.c_void_p), ("l1_grad", C.c_void_p), ("l1_sums", C.c_void_p),   # optional L1 epilogue of the forward
+                ("accum_cleared", C.c_int)]
 
 
 class MomRasterGrads(C.Structure):

@@ -553,7 +553,7 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
-    if (hipMemsetAsync(g.gacc, 0, (size_t)a->P * 48, s) != hipSuccess) return MOM_ELAUNCH;
+    if (!a->accum_cleared && hipMemsetAsync(g.gacc, 0, (size_t)a->P * 48, s) != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_RENDER_BWD, s);
     int ry0, ry1;
     mom_tile_rows(a, gy, &ry0, &ry1);

@@ -188,6 +188,12 @@ class FusedStep:
         self.side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.side):
             self._dg_flat.zero_()
+            # the compositing backward's accumulator record too (MomRasterArgs.accum_cleared): its last reader, the previous
+            # step's projection backward, is behind this stream's wait above
+            gk = (P, W, H, self.geom.data_ptr())
+            if getattr(self, "_gacc_cache", (None,))[0] != gk:
+                self._gacc_cache = (gk, self._gacc_view(P, W, H))
+            self._gacc_cache[1].zero_()
             if hy.time_smoothness_weight != 0:
                 rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, reg_scale)
                 if self._reg_arr is None or self._reg_arr[0] != rkey:
@@ -230,6 +236,7 @@ class FusedStep:
         # ---- rasterizer forward (async: capacity from the previous iterations, checked below)
         a = N.MomRasterArgs()
         a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H
+        a.accum_cleared = 1                     # on the second stream, above
         a.background, a.means3D = self.bg.data_ptr(), self.pts.data_ptr()
         a.shs, a.shs_rest = g._features_dc.data_ptr(), g._features_rest.data_ptr()
         a.colors_precomp, a.opacities = None, self.op.data_ptr()

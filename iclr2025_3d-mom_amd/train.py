@@ -236,8 +236,13 @@ class Trainer:
         return loss
 
     def _early_adam(self, params):
+        """Runs on the fused step's second stream, right after the activation backward: Adam for the appearance parameters and
+        -- it only needs the radii and the screen-space gradient, both final by then -- the densification statistics."""
         self.g.optimizer.skip_flag = self.fused.flags
         self.g.optimizer.step_partial(params)
+        if self._early_iter < self.opt.densify_until_iter:
+            self.g.update_densification_stats(self.fused.radii, self.fused.g2d, skip_flag=self.fused.flags)
+            self._stats_done = True
 
     def _step_fused(self, iteration, cam, replay=False):
         with torch.no_grad():
@@ -248,8 +253,10 @@ class Trainer:
             # host logic touches no parameter between backward and optimizer.step() (a densify / prune round replaces them and
             # the reference's step() then skips them: train_4DGS.py:266-297)
             early = None
+            self._stats_done = False
             if self.dist is None and iteration < self.opt.iterations and not self._boundary(iteration):
                 early = self._early_adam
+                self._early_iter = iteration
                 g_ = self.g
                 g_.optimizer.ensure_state([g_._features_dc, g_._features_rest, g_._scaling, g_._rotation, g_._opacity])
             loss, radii, vsp_grad = self.fused.forward_backward(cam, self.delta_scale, early_adam=early)
@@ -278,7 +285,9 @@ class Trainer:
             if iteration < opt.densify_until_iter:
                 # same values as the reference's boolean-mask indexing (train_4DGS.py:266), without the host sync a
                 # nonzero() costs: invisible entries keep their old value
-                g.update_densification_stats(radii, vsp_grad, skip_flag=getattr(self, "_skip", None))
+                if not getattr(self, "_stats_done", False):      # (the fused step may have run them on its second stream)
+                    g.update_densification_stats(radii, vsp_grad, skip_flag=getattr(self, "_skip", None))
+                self._stats_done = False
                 if self.stage == "coarse":
                     op_thr, de_thr = opt.opacity_threshold_coarse, opt.densify_grad_threshold_coarse
                 else:

@@ -94,6 +94,12 @@ typedef struct MomRasterArgs {
     const float* l1_target;
     float* l1_grad;
     float* l1_sums;
+    /* !=0: the caller has already cleared the backward's per-Gaussian accumulator record in the geometry scratch
+     * (mom_raster_layout().geom_gacc, 48 bytes per Gaussian) since the last backward read it; mom_raster_backward /
+     * _backward_render then skip their own fill command.  (The reference zeroes its ten gradient tensors in
+     * RasterizeGaussiansBackwardCUDA, rasterize_points.cu:154-163; the fused training step does this fill on its second stream
+     * during the forward.) */
+    int accum_cleared;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
