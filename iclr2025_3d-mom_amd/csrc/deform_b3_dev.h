@@ -1,0 +1,85 @@
+// The exact three-way bf16 split of fp32 operands for v_mfma_f32_32x32x16_bf16 (see deform_field.hip for the scheme): shared by
+// the fused forward (pre-split weight fragments in LDS) and the MLP backward (weights split on the fly from their fp32 copy).
+#pragma once
+#include "deform_mlp_dev.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t hi16(float x) { return __float_as_uint(x) & 0xFFFF0000u; }
+// (a, b) -> three dwords, piece p = bf16(a_p) | bf16(b_p) << 16
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t (&p)[3])
+{
+    const uint32_t a1 = hi16(a), b1 = hi16(b);
+    const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+    const uint32_t a2 = hi16(ra), b2 = hi16(rb);
+    const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+    p[0] = (a1 >> 16) | b1;
+    p[1] = (a2 >> 16) | b2;
+    p[2] = (__float_as_uint(sa) >> 16) | hi16(sb);
+}
+struct Frag3 {
+    uint4 p[3];            // the three pieces of eight values: an MFMA operand each
+};
+__device__ __forceinline__ Frag3 split8(const float (&v)[8])
+{
+    Frag3 f;
+    uint32_t q[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; j++) split_pair(v[2 * j], v[2 * j + 1], q[j]);
+#pragma unroll
+    for (int p = 0; p < 3; p++) f.p[p] = make_uint4(q[0][p], q[1][p], q[2][p], q[3][p]);
+    return f;
+}
+// the B operand of the next layer: accumulator tile -> four K-steps of three pieces (RELU: through the ReLU first)
+template <bool RELU>
+__device__ __forceinline__ void split_tile(const f32x16 (&t)[2], Frag3 (&B)[4])
+{
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float x = t[s >> 1][8 * (s & 1) + j];
+            v[j] = RELU ? fmaxf(x, 0.f) : x;
+        }
+        B[s] = split8(v);
+    }
+}
+__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc[mt] += W x (TRANS: W^T x) with the weights read from their fp32 copy in LDS (Wl[in * kWStride + out]) and split on the
+// fly: the A operand of K-step s is the eight weights whose contraction index is 16 s + 4 h + (j & 3) + 8 (j >> 2), j = 0..7 --
+// the order in which an accumulator tile holds its features, so that B is a predecessor's accumulator, split in place.
+template <bool TRANS>
+__device__ __forceinline__ void layer_b3_otf(const float* __restrict__ Wl, const Frag3 (&B)[4], f32x16 (&acc)[2], int col, int h)
+{
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            float v[8];
+            const int m = 32 * mt + col;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int kk = 16 * s + 4 * h + (j & 3) + 8 * (j >> 2);
+                v[j] = TRANS ? Wl[m * kWStride + kk] : Wl[kk * kWStride + m];
+            }
+            const Frag3 A = split8(v);
+            f32x16 c = acc[mt];
+            c = mfma16(A.p[2], B[s].p[0], c);
+            c = mfma16(A.p[0], B[s].p[2], c);
+            c = mfma16(A.p[1], B[s].p[1], c);
+            c = mfma16(A.p[1], B[s].p[0], c);
+            c = mfma16(A.p[0], B[s].p[1], c);
+            c = mfma16(A.p[0], B[s].p[0], c);
+            acc[mt] = c;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+}  // namespace

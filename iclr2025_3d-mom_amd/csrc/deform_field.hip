@@ -19,6 +19,7 @@
 // order over the planes; only the two time rows are combined first (a reassociation of the same four products).
 #include "deform_mlp_dev.h"
 #include "hexplane_dev.h"
+#include "deform_b3_dev.h"
 #include <stdlib.h>
 
 namespace {
@@ -494,7 +495,6 @@ deform_field_fwd_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float*
 // j = 0..7: exactly the eight accumulator registers 8 (s & 1) .. + 7 of output tile s >> 1 of the previous layer, so a layer's
 // B operand is its predecessor's accumulator, split in place, with no shuffle.  The weight fragments are prepared once per
 // workgroup in that order: wfrag[layer][piece][mt][s][lane] = 16 bytes = a lane's A operand, 96 KB of LDS in all.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef MOM_B3_WAVES
 #define MOM_B3_WAVES 12
@@ -507,50 +507,6 @@ constexpr int kL3B = kL3Small, kL3W2 = kL3B + 4 * kHid, kL3B2 = kL3W2 + 3 * 4 * 
 constexpr int kL3Recs = kL3B2 + 16;
 constexpr int kL3Total = kL3Recs + kB3Waves * 64 * kRecDw;
 
-__device__ __forceinline__ uint32_t hi16(float x) { return __float_as_uint(x) & 0xFFFF0000u; }
-// (a, b) -> three dwords, piece p = bf16(a_p) | bf16(b_p) << 16
-__device__ __forceinline__ void split_pair(float a, float b, uint32_t (&p)[3])
-{
-    const uint32_t a1 = hi16(a), b1 = hi16(b);
-    const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
-    const uint32_t a2 = hi16(ra), b2 = hi16(rb);
-    const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
-    p[0] = (a1 >> 16) | b1;
-    p[1] = (a2 >> 16) | b2;
-    p[2] = (__float_as_uint(sa) >> 16) | hi16(sb);
-}
-struct Frag3 {
-    uint4 p[3];            // the three pieces of eight values: an MFMA operand each
-};
-__device__ __forceinline__ Frag3 split8(const float (&v)[8])
-{
-    Frag3 f;
-    uint32_t q[4][3];
-#pragma unroll
-    for (int j = 0; j < 4; j++) split_pair(v[2 * j], v[2 * j + 1], q[j]);
-#pragma unroll
-    for (int p = 0; p < 3; p++) f.p[p] = make_uint4(q[0][p], q[1][p], q[2][p], q[3][p]);
-    return f;
-}
-// the B operand of the next layer: accumulator tile -> four K-steps of three pieces (RELU: through the ReLU first)
-template <bool RELU>
-__device__ __forceinline__ void split_tile(const f32x16 (&t)[2], Frag3 (&B)[4])
-{
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float x = t[s >> 1][8 * (s & 1) + j];
-            v[j] = RELU ? fmaxf(x, 0.f) : x;
-        }
-        B[s] = split8(v);
-    }
-}
-__device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 // acc[mt] += W_layer x: 48 MFMAs, the smallest products first
 __device__ __forceinline__ void layer_b3(const uint4* __restrict__ wf /* [3][2][4][64] of this layer */, const Frag3 (&B)[4], f32x16 (&acc)[2], int lane)
 {
@@ -755,7 +711,7 @@ __device__ __forceinline__ float unit_sum(float v)
 __global__ void __launch_bounds__(256, HX6_WAVES)
 hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __restrict__ lines, const float* __restrict__ xyz,
                             const float* __restrict__ dfeat, float* __restrict__ dxyz, const uint32_t* __restrict__ inv /* [3][levels][P] */,
-                            float* __restrict__ gvbuf /* [6][levels][P][32] */)
+                            float* __restrict__ gvbuf /* [3 slots][levels][P][2][32] */)
 {
     __shared__ uint4 s_rec[4][64 * (kRec6Dw / 4)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -788,7 +744,7 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
                 }
                 R2 = make_uint4(__float_as_uint(gm[0]), __float_as_uint(gm[1]), __float_as_uint(gm[2]), 0u);
 #pragma unroll
-                for (int k = 0; k < 3; k++) (&R3.x)[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * 128u;
+                for (int k = 0; k < 3; k++) (&R3.x)[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * 256u;   // [position][space row | time row]
                 R3.w = (unsigned)g_mine;
             }
             rec[4 * lane] = R0;
@@ -862,7 +818,8 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
                     const float4 gv = p == 5 ? pre[5] : mul44(pre[p], suf[p]);
                     const unsigned pos = p == 0 || p == 2 ? R3.x : (p == 1 || p == 5 ? R3.y : R3.z);     // order slot of the plane
                     if (live)
-                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(gvbuf + ((size_t)p * a.levels + lvl) * plane_floats) + pos + cb) = gv;
+                        *reinterpret_cast<float4*>(reinterpret_cast<char*>(gvbuf + ((size_t)(p == 0 || p == 2 ? 0 : (p == 1 || p == 5 ? 1 : 2)) * a.levels + lvl) * 2 * plane_floats) +
+                                                   pos + (p == 2 || p == 4 || p == 5 ? 128u : 0u) + cb) = gv;
                     // first coordinate of the plane: x for 0 1 2, y for 3 4, z for 5; second: y for 0, z for 1 and 3
                     if (p < 3) gx = dot4(gv, da[p], gx);
                     else if (p < 5) gy = dot4(gv, da[p], gy);

@@ -26,6 +26,7 @@
 // 64x64 results live in 256 accumulator registers for the wave's whole range, and the bias gradients fall out of
 // the A operands for free.  No atomics until one float atomic per weight per workgroup at the very end.
 #include "deform_mlp_dev.h"
+#include "deform_b3_dev.h"
 #include <stdlib.h>
 
 namespace {
@@ -108,6 +109,10 @@ deform_fwd_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, co
 // (A) activations backward: dH for the four layers, d(features), output-layer weight gradients
 // 512 threads: two waves per SIMD share one copy of the weights (142 KB of LDS with the staging tiles), so that one wave's vector
 // and memory phases -- the thin output layers, the dH stores -- run under the other's MFMAs (4 waves: 288 us for dx + dW, 8: 276)
+// B3: the seven 64x64 products of a tile on the bf16 matrix pipe from exact three-way splits (deform_b3_dev.h), the weights split
+// on the fly from their fp32 copy in LDS -- pre-split fragments for seven matrices (168 KB) do not fit beside the staging tiles.
+// 0.375 of the f32 kernel's matrix cycles, and those co-issue with the other wave's vector work, which the f32 MFMA blocks.
+template <bool B3>
 __global__ void __launch_bounds__(64 * kDxWaves)
 deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, const float* __restrict__ dpts,
                      const float* __restrict__ dscales, const float* __restrict__ drots, float* __restrict__ dfeat,
@@ -147,12 +152,15 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
         load_feat(a0g, g, ok, h, a0);
 #endif
         zero_tile(dA0);
+        Frag3 Ba0[4];
+        if (B3) split_tile<false>(a0, Ba0);        // the recomputed head layers' B operand, split once per tile
 #pragma nounroll
         for (int head = 0; head < 3; head++) {   // rolled on purpose: unrolled, the scheduler interleaves the heads and spills
             const int nout = head == 2 ? 4 : 3;
             f32x16 a1[2];
             init_bias(lds + kLB + (1 + head) * kHid, a1, h);
-            layer64<false>(lds + kLW + (1 + head) * kWFloats, a0, a1, col, h);
+            if (B3) layer_b3_otf<false>(lds + kLW + (1 + head) * kWFloats, Ba0, a1, col, h);
+            else layer64<false>(lds + kLW + (1 + head) * kWFloats, a0, a1, col, h);
             relu_tile(a1);
             const float* __restrict__ dsrc = head == 0 ? dpts : (head == 1 ? dscales : drots);
             float dout[4];
@@ -195,7 +203,13 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
                     a1[mt][4 * q + 3] = a1[mt][4 * q + 3] > 0.f ? v3 : 0.f;
                 }
             store_feat(dH + (size_t)(1 + head) * PH, g, ok, h, a1);
-            layer64<true>(lds + kLW + (1 + head) * kWFloats, a1, dA0, col, h);   // dA0 += W1^T dH1
+            if (B3) {
+                Frag3 Bd[4];
+                split_tile<false>(a1, Bd);
+                layer_b3_otf<true>(lds + kLW + (1 + head) * kWFloats, Bd, dA0, col, h);
+            } else {
+                layer64<true>(lds + kLW + (1 + head) * kWFloats, a1, dA0, col, h);   // dA0 += W1^T dH1
+            }
         }
         // through the ReLU between trunk and heads
 #pragma unroll
@@ -206,7 +220,13 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
         {
             f32x16 df[2];
             zero_tile(df);
-            layer64<true>(lds + kLW, dA0, df, col, h);  // dfeat = W0^T dH0
+            if (B3) {
+                Frag3 Bd[4];
+                split_tile<false>(dA0, Bd);
+                layer_b3_otf<true>(lds + kLW, Bd, df, col, h);
+            } else {
+                layer64<true>(lds + kLW, dA0, df, col, h);  // dfeat = W0^T dH0
+            }
             store_feat(dfeat, g, ok, h, df);
         }
     }
@@ -767,14 +787,26 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
     const size_t lds_a = sizeof(float) * kLBwdTotal;
     const size_t lds_b = sizeof(float) * (kHid * kHid + kHid);
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_dx_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_dx_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_a) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_dx_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds_a) != hipSuccess)
             return MOM_ELAUNCH;
         attr_set = true;
     }
     MomProfScope ps(MOM_P_MLP_BWD, (hipStream_t)stream);
-    hipLaunchKernelGGL(deform_bwd_dx_kernel, dim3(blocks), dim3(64 * kDxWaves), lds_a, (hipStream_t)stream, d, P, tiles, a0, dpts, dscales, drots,
-                       dfeat, dH);
+    // MOM_DX_MODE=b3: the products on the bf16 pipe (read per call: tests compare the two).  Measured at 200 k Gaussians: the kernel
+    // alone 116 us against 144 (35.9 M vector instructions instead of 13.8 M, matrix pipe busy 67 M cycles instead of 179 M) -- and
+    // the training step NOT faster (930 against 943 steps/s): the stretch from dx to the HexPlane scatter moves 1.8 GB and is
+    // bound by memory bandwidth, so the 45 us this kernel gives up are taken by its neighbours (Adam's early launch no longer
+    // fits beside it and runs into the gather: gather 153 -> 173 us, scatter 104 -> 131).  Opt-in for that reason.
+    const char* e_dx = getenv("MOM_DX_MODE");
+    if (e_dx && e_dx[0] == 'b')
+        hipLaunchKernelGGL(deform_bwd_dx_kernel<true>, dim3(blocks), dim3(64 * kDxWaves), lds_a, (hipStream_t)stream, d, P, tiles, a0, dpts,
+                           dscales, drots, dfeat, dH);
+    else
+        hipLaunchKernelGGL(deform_bwd_dx_kernel<false>, dim3(blocks), dim3(64 * kDxWaves), lds_a, (hipStream_t)stream, d, P, tiles, a0, dpts,
+                           dscales, drots, dfeat, dH);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     hipStream_t ws = (hipStream_t)dw_stream;
     if (ws != (hipStream_t)stream) {

@@ -306,7 +306,7 @@ __device__ __forceinline__ void make_rec5(float cx, float cy, int Wd, int Hd, un
 __global__ void __launch_bounds__(256, HX_GATHER_WAVES)
 hexplane_bwd5_gather_kernel(HexArgs a, int nchunks, const float* __restrict__ xyz, const float* __restrict__ dfeat,
                             float* __restrict__ dxyz, const uint32_t* __restrict__ inv /* [3][P] */,
-                            float* __restrict__ gvbuf /* [6][P][levels][32] */)
+                            float* __restrict__ gvbuf /* [3 slots][levels][P][2][32] */)
 {
     __shared__ uint4 s_r1[4][kChunk5][6];
     __shared__ float4 s_r2[4][kChunk5][6];
@@ -331,7 +331,7 @@ hexplane_bwd5_gather_kernel(HexArgs a, int nchunks, const float* __restrict__ xy
             norm_coords(a, xyz, g_mine, c);
             unsigned pos[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) pos[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * 128u;
+            for (int k = 0; k < 3; k++) pos[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * 256u;   // a slot's two rows are adjacent
 #pragma unroll
             for (int q = 0; q < 3; q++) {
                 const int p0 = q, p1 = 3 + q;            // h == 0: (x,y) (x,z) (x,t); h == 1: (y,z) (y,t) (z,t)
@@ -393,7 +393,8 @@ hexplane_bwd5_gather_kernel(HexArgs a, int nchunks, const float* __restrict__ xy
             for (int p = 0; p < 6; p++) {
                 const float gv = gcur * (pre[p] * suf[p + 1]);
                 const int ca = kCombA[p], cb = kCombB[p];
-                float* __restrict__ dst = gvbuf + ((size_t)p * a.levels + lvl) * plane_floats;          // uniform
+                // [slot][level][position][space row | time row][32]: the two rows a scatter pass reads for one position are one 256-byte piece
+                float* __restrict__ dst = gvbuf + ((size_t)order_slot_of_plane(p) * a.levels + lvl) * 2 * plane_floats + ((p == 2 || p == 4 || p == 5) ? 32 : 0);          // uniform
                 *reinterpret_cast<float*>(reinterpret_cast<char*>(dst) + (s_r1[wv][16 * h + icur][p].w + chb)) = gv;
                 gc[ca] = __builtin_fmaf(gv, dgx[p], gc[ca]);
                 if (cb < 3) gc[cb] = __builtin_fmaf(gv, dgy[p], gc[cb]);
@@ -439,8 +440,8 @@ hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ 
     const int Wd = a.res[lvl][ca], Hd = a.res[lvl][cb], Ws = a.res[lvl][cs];
     float* __restrict__ gp = a.grads[lvl][p] + ch;
     const size_t plane_floats = (size_t)a.P * 32;
-    const float* __restrict__ src_s = gvbuf + ((size_t)p * a.levels + lvl) * plane_floats + ch;
-    const float* __restrict__ src_t = gvbuf + ((size_t)pt * a.levels + lvl) * plane_floats + ch;
+    const float* __restrict__ src_s = gvbuf + ((size_t)si * a.levels + lvl) * 2 * plane_floats + ch;     // [position][space row | time row][32]
+    const float* __restrict__ src_t = src_s + 32;
     const uint32_t* __restrict__ ord = order + ((size_t)si * a.levels + lvl) * a.P;
     const float lo_a = a.a0[ca], sc_a = 2.0f / (a.a1[ca] - a.a0[ca]), lo_b = a.a0[cb], sc_b = 2.0f / (a.a1[cb] - a.a0[cb]);
     float* __restrict__ my_line = s_line + ch;
@@ -514,8 +515,8 @@ hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < kBatch5s; j++) {
                 const int q = min(b0 + j, npts - 1);
-                val[j] = src_s[(size_t)(base + q) * 32];
-                vat[j] = src_t[(size_t)(base + q) * 32];
+                val[j] = src_s[(size_t)(base + q) * 64];
+                vat[j] = src_t[(size_t)(base + q) * 64];
             }
 #pragma unroll
             for (int j = 0; j < kBatch5s; j++) {
@@ -741,7 +742,7 @@ static int hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, con
             if (hp->res[l][k] > wmax) wmax = hp->res[l][k];
     const size_t lds_s = sizeof(float) * ((size_t)4 * 64 * kRec5s + (size_t)wmax * 32);
     // gv rows are addressed with 32-bit byte offsets inside one (plane, level) buffer
-    const bool fits32 = (unsigned long long)P * 128ull < (1ull << 32);
+    const bool fits32 = (unsigned long long)P * 256ull < (1ull << 32);
     if (!times && plane_order && plane_inverse && scratch && lds_s <= 160 * 1024 && fits32) {
         // two-pass path: one shared timestamp, per-plane orders and the gv scratch given
         static bool attr_set = false;

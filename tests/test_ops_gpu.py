@@ -567,3 +567,35 @@ def test_hexplane_backward_gather_in_the_forward_layout_equals_the_lane_per_chan
         for a, b in zip(la, lb):
             assert float(b.abs().max()) > 0
             assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+def test_deform_backward_on_the_bf16_pipe_equals_the_f32_products(monkeypatch):
+    """MOM_DX_MODE=b3: the seven 64x64 products of the MLP backward from exact three-way bf16 splits (csrc/deform_b3_dev.h, weights
+    split on the fly) against the f32-MFMA kernel: every retained product term is exact, so the two differ like two fp32 summation
+    orders do."""
+    P = 30011
+    params, mk = _mlp_state(P, 13)
+    feat, xyz, scal, rot, flow = mk(P, 64) * 3, mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 3)
+    dpts, dsc, drot = mk(P, 3), mk(P, 3), mk(P, 4)
+    lib, s = N.lib(), N.current_stream()
+
+    def run(mode):
+        monkeypatch.setenv("MOM_DX_MODE", mode)
+        grads = [torch.zeros_like(p) for p in params]
+        d = ops.DeformMLPFunction._desc(params, grads)
+        pts, sc_d, rot_d, a0 = (torch.empty(P, k, device="cuda") for k in (3, 3, 4, 64))
+        N.check(lib.mom_deform_forward(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                       flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), a0.data_ptr(), s), "fwd")
+        dfeat = torch.empty(P, 64, device="cuda")
+        scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device="cuda")
+        N.check(lib.mom_deform_backward_split(C.byref(d), P, feat.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(),
+                                              drot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s, s), "bwd")
+        torch.cuda.synchronize()
+        return dfeat, grads
+
+    f1, g1 = run("f32")
+    f2, g2 = run("b3")
+    sc = float(f1.abs().max())
+    assert float((f1 - f2).abs().max()) <= 2e-6 * sc, (float((f1 - f2).abs().max()), sc)
+    for a, b in zip(g1, g2):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
