@@ -52,9 +52,6 @@ constexpr int kLFlags = kLFwdTotal;                  // [4 SIMDs][kNG][2] ints: 
 constexpr int kLBufs = kLFlags + 32;
 constexpr int kLFieldTotal = kLBufs + 4 * kNB * kBufFloats;
 
-struct LineTab {
-    unsigned off[4][3];                              // float offset of line (level, axis) inside the table
-};
 
 // lines[level][axis][r][32] = ay * plane_(axis,t)[t0][r][:] + by * plane_(axis,t)[t1][r][:]
 __global__ void __launch_bounds__(256) hexplane_lines_kernel(HexArgs a, LineTab lt, float* __restrict__ lines, int total)
@@ -708,10 +705,11 @@ __device__ __forceinline__ float unit_sum(float v)
 #ifndef HX6_WAVES
 #define HX6_WAVES 3
 #endif
+template <bool CROWS>
 __global__ void __launch_bounds__(256, HX6_WAVES)
 hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __restrict__ lines, const float* __restrict__ xyz,
                             const float* __restrict__ dfeat, float* __restrict__ dxyz, const uint32_t* __restrict__ inv /* [3][levels][P] */,
-                            float* __restrict__ gvbuf /* [3 slots][levels][P][2][32] */)
+                            float* __restrict__ gvbuf /* [3 slots][levels][P][2][32]; CROWS: common-factor rows [3 slots][levels][P][32] */)
 {
     __shared__ uint4 s_rec[4][64 * (kRec6Dw / 4)];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -744,7 +742,7 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
                 }
                 R2 = make_uint4(__float_as_uint(gm[0]), __float_as_uint(gm[1]), __float_as_uint(gm[2]), 0u);
 #pragma unroll
-                for (int k = 0; k < 3; k++) (&R3.x)[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * 256u;   // [position][space row | time row]
+                for (int k = 0; k < 3; k++) (&R3.x)[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * (CROWS ? 128u : 256u);   // CROWS: [slot][level][position][32], else [..][position][space | time][32]
                 R3.w = (unsigned)g_mine;
             }
             rec[4 * lane] = R0;
@@ -816,10 +814,11 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
 #pragma unroll
                 for (int p = 0; p < 6; p++) {
                     const float4 gv = p == 5 ? pre[5] : mul44(pre[p], suf[p]);
-                    const unsigned pos = p == 0 || p == 2 ? R3.x : (p == 1 || p == 5 ? R3.y : R3.z);     // order slot of the plane
-                    if (live)
+                    if (!CROWS && live) {
+                        const unsigned pos = p == 0 || p == 2 ? R3.x : (p == 1 || p == 5 ? R3.y : R3.z);     // order slot of the plane
                         *reinterpret_cast<float4*>(reinterpret_cast<char*>(gvbuf + ((size_t)(p == 0 || p == 2 ? 0 : (p == 1 || p == 5 ? 1 : 2)) * a.levels + lvl) * 2 * plane_floats) +
                                                    pos + (p == 2 || p == 4 || p == 5 ? 128u : 0u) + cb) = gv;
+                    }
                     // first coordinate of the plane: x for 0 1 2, y for 3 4, z for 5; second: y for 0, z for 1 and 3
                     if (p < 3) gx = dot4(gv, da[p], gx);
                     else if (p < 5) gy = dot4(gv, da[p], gy);
@@ -827,6 +826,21 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
                     if (p == 0) gy = dot4(gv, db[0], gy);
                     if (p == 1) gz = dot4(gv, db[1], gz);
                     if (p == 3) gz = dot4(gv, db[2], gz);
+                }
+                // CROWS: what goes to memory is ONE row per order slot, not the two gv rows of the slot's planes: the factor they share,
+                // c = dfeat * (product of the four OTHER planes' samples).  The scatter pass multiplies it by the time line's sample
+                // (gv of the space plane) and by the space plane's own sample (gv of the time plane) -- both of which it has at hand:
+                // the line values sit in its LDS and the space plane's four texel rows are the rows it is accumulating into.
+                // 154 MB of rows written and read back per step instead of 307 MB each way, on a stretch bound by memory bandwidth.
+                //   slot 0 = (x,y) + (x,t): planes 0, 2     slot 1 = (x,z) + (z,t): planes 1, 5     slot 2 = (y,z) + (y,t): planes 3, 4
+                if (CROWS && live) {
+                    const float4 c0 = mul44(mul44(go, v[1]), suf[2]);                    // go v1 (v3 v4 v5)
+                    const float4 c1 = mul44(pre[1], mul44(mul44(v[2], v[3]), v[4]));     // (go v0) v2 v3 v4
+                    const float4 c2 = mul44(pre[3], v[5]);                               // (go v0 v1 v2) v5
+                    char* crow = reinterpret_cast<char*>(gvbuf + (size_t)lvl * plane_floats) + cb;
+                    *reinterpret_cast<float4*>(crow + R3.x) = c0;
+                    *reinterpret_cast<float4*>(crow + (size_t)a.levels * plane_floats * 4 + R3.y) = c1;
+                    *reinterpret_cast<float4*>(crow + (size_t)2 * a.levels * plane_floats * 4 + R3.z) = c2;
                 }
                 gx = unit_sum(gx) * __uint_as_float(R2.x);
                 gy = unit_sum(gy) * __uint_as_float(R2.y);
@@ -845,17 +859,6 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
 
 }  // namespace
 
-static int line_table(const MomHexPlane* hp, LineTab* lt)
-{
-    unsigned off = 0;
-    for (int l = 0; l < 4; l++)
-        for (int k = 0; k < 3; k++) {
-            lt->off[l][k] = off;
-            if (l < hp->levels) off += (unsigned)hp->res[l][k] * 32u;
-        }
-    return (int)off;
-}
-
 // bytes of the time-line table (what mom_hexplane_backward_scratch_bytes adds for the gather below)
 size_t mom_hexplane_lines_bytes(const MomHexPlane* hp)
 {
@@ -866,7 +869,7 @@ size_t mom_hexplane_lines_bytes(const MomHexPlane* hp)
 // pass 1 of the two-pass HexPlane backward for a field mom_deform_field_supported() accepts (called by mom_hexplane_backward,
 // hexplane.hip): the frame's lines into `lines`, then the gather
 int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order, const float* dfeat,
-                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, bool lines_ready, hipStream_t s)
+                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, bool lines_ready, bool crows, hipStream_t s)
 {
     HexArgs a;
     fill_args(hp, P, nullptr, time, order, true, &a);
@@ -879,7 +882,10 @@ int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, 
     if (!cap) { const char* e = getenv("MOM_HEX6_BLOCKS"); cap = e ? atoi(e) : 1536; if (cap < 1) cap = 1536; }
     int blocks = (nchunks + 3) / 4;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(hexplane_bwd6_gather_kernel, dim3(blocks), dim3(256), 0, s, a, lt, nchunks, lines, xyz, dfeat, dxyz, plane_inverse, gvbuf);
+    if (crows)
+        hipLaunchKernelGGL(hexplane_bwd6_gather_kernel<true>, dim3(blocks), dim3(256), 0, s, a, lt, nchunks, lines, xyz, dfeat, dxyz, plane_inverse, gvbuf);
+    else
+        hipLaunchKernelGGL(hexplane_bwd6_gather_kernel<false>, dim3(blocks), dim3(256), 0, s, a, lt, nchunks, lines, xyz, dfeat, dxyz, plane_inverse, gvbuf);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

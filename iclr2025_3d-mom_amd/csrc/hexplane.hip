@@ -424,11 +424,17 @@ constexpr int kChunk5s = 32;           // sorted positions per half-wave and chu
 constexpr int kBatch5s = 16;           // gv rows in flight per lane and plane
 constexpr int kRec5s = 4 + 4 + 4 + 2;  // dwords of one pass-2 record: int4 ids | float4 ws | float4 {lw0, lw1, flag, -} | int2 ride ids
 
+// CROWS: the gather left ONE row per (order slot, position) -- c = dfeat * (product of the four planes outside the slot), see
+// hexplane_bwd6_gather_kernel -- instead of the slot's two gv rows; this pass forms them itself: gv(space plane) = c * (time line's
+// sample), from the frame's line values staged in LDS, and gv(time plane) = c * (space plane's sample), from the four texel rows
+// it keeps pending anyway (their VALUES ride along with the pending gradient rows and are fetched when a slot takes a new row).
+template <bool CROWS>
 __global__ void __launch_bounds__(256)
 hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ xyz,
-                             const uint32_t* __restrict__ order /* [3][levels][P] */, const float* __restrict__ gvbuf)
+                             const uint32_t* __restrict__ order /* [3][levels][P] */, const float* __restrict__ gvbuf,
+                             const float* __restrict__ lines, LineTab lt)
 {
-    extern __shared__ float s_dyn5[];                  // [4 waves] x (int4 ids[64] | float4 ws[64] | float4 rd[64] | int2 rid[64]) | line [W][32]
+    extern __shared__ float s_dyn5[];                  // [4 waves] x (int4 ids[64] | float4 ws[64] | float4 rd[64] | int2 rid[64]) | line [W][32] (| line values [W][32])
     constexpr int kPer = 64 * kRec5s;                  // dwords per wave
     float* s_line = s_dyn5 + 4 * kPer;
     const int lane = threadIdx.x & 63, ch = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
@@ -440,13 +446,20 @@ hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ 
     const int Wd = a.res[lvl][ca], Hd = a.res[lvl][cb], Ws = a.res[lvl][cs];
     float* __restrict__ gp = a.grads[lvl][p] + ch;
     const size_t plane_floats = (size_t)a.P * 32;
-    const float* __restrict__ src_s = gvbuf + ((size_t)si * a.levels + lvl) * 2 * plane_floats + ch;     // [position][space row | time row][32]
+    // 6-row form: [slot][level][position][space row | time row][32]; CROWS: [slot][level][position][32]
+    const float* __restrict__ src_s = gvbuf + ((size_t)si * a.levels + lvl) * (CROWS ? 1 : 2) * plane_floats + ch;
     const float* __restrict__ src_t = src_s + 32;
+    constexpr int kRowF = CROWS ? 32 : 64;             // floats between consecutive positions
+    const float* __restrict__ plane_v = a.planes[lvl][p] + ch;
     const uint32_t* __restrict__ ord = order + ((size_t)si * a.levels + lvl) * a.P;
     const float lo_a = a.a0[ca], sc_a = 2.0f / (a.a1[ca] - a.a0[ca]), lo_b = a.a0[cb], sc_b = 2.0f / (a.a1[cb] - a.a0[cb]);
     float* __restrict__ my_line = s_line + ch;
+    // CROWS: the carried time plane's line at this frame's timestamp, read from the table itself when a line row changes (rare in
+    // this order; the 73 KB table lives in the L1 / L2 -- a copy in LDS cost the kernel two of its five workgroups per CU)
+    const float* __restrict__ my_lval = CROWS ? lines + lt.off[lvl][cs] + ch : nullptr;
     for (int i = threadIdx.x; i < Ws * 32; i += 256) s_line[i] = 0.f;
     __syncthreads();
+    float tv[4] = {0.f, 0.f, 0.f, 0.f}, lv[2] = {0.f, 0.f};   // CROWS: the VALUES of the pending texel rows / line rows
 
     int pid[4] = {-1, -1, -1, -1};
     float pacc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -515,8 +528,8 @@ hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ 
 #pragma unroll
             for (int j = 0; j < kBatch5s; j++) {
                 const int q = min(b0 + j, npts - 1);
-                val[j] = src_s[(size_t)(base + q) * 64];
-                vat[j] = src_t[(size_t)(base + q) * 64];
+                val[j] = src_s[(size_t)(base + q) * kRowF];
+                vat[j] = CROWS ? 0.f : src_t[(size_t)(base + q) * kRowF];
             }
 #pragma unroll
             for (int j = 0; j < kBatch5s; j++) {
@@ -526,6 +539,24 @@ hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ 
                 const int flag = __float_as_int(rd.z);
                 const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
                 const float lw[2] = {rd.x, rd.y};
+                float g_space = val[j], g_time = vat[j];      // the two planes' gv at this position
+                if (CROWS) {
+                    // the time line's rows first (their values give the space plane's gv)
+                    if (flag & 2) {
+                        const int2 r2 = w_rid[32 * h + b0 + j];
+                        const int lid[2] = {r2.x, r2.y};
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            if (lid[k] != lpid[k] && lid[k] >= 0) {
+                                if (lpid[k] >= 0) atomicAdd(&my_line[lpid[k]], lacc[k]);
+                                lpid[k] = lid[k];
+                                lacc[k] = 0.f;
+                                lv[k] = my_lval[lid[k]];
+                            }
+                        }
+                    }
+                    g_space = val[j] * (lw[0] * lv[0] + lw[1] * lv[1]);
+                }
                 if (flag & 1) {
                     // the cell changed (or touches the border): a slot whose row differs flushes its pending row and restarts
                     const int4 id4 = w_ids[32 * h + b0 + j];
@@ -533,33 +564,40 @@ hexplane_bwd5_scatter_kernel(HexArgs a, int per_half, const float* __restrict__ 
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         if (ids[k] == pid[k]) {
-                            pacc[k] = __builtin_fmaf(val[j], ws[k], pacc[k]);
+                            pacc[k] = __builtin_fmaf(g_space, ws[k], pacc[k]);
                         } else if (ids[k] >= 0) {
                             if (pid[k] >= 0) atomicAdd(&gp[pid[k]], pacc[k]);
                             pid[k] = ids[k];
-                            pacc[k] = val[j] * ws[k];
+                            pacc[k] = g_space * ws[k];
+                            if (CROWS) tv[k] = plane_v[ids[k]];
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pacc[k] = __builtin_fmaf(val[j], ws[k], pacc[k]);
+                    for (int k = 0; k < 4; k++) pacc[k] = __builtin_fmaf(g_space, ws[k], pacc[k]);
                 }
-                if (flag & 2) {
+                if (CROWS) {
+                    // the space plane's sample from the pending rows' values (a corner outside the plane has weight exactly 0 and
+                    // keeps whatever finite value its slot held), then the time plane's gv into the line accumulators
+                    g_time = val[j] * (ws[0] * tv[0] + ws[1] * tv[1] + ws[2] * tv[2] + ws[3] * tv[3]);
+#pragma unroll
+                    for (int k = 0; k < 2; k++) lacc[k] = __builtin_fmaf(g_time, lw[k], lacc[k]);
+                } else if (flag & 2) {
                     const int2 r2 = w_rid[32 * h + b0 + j];
                     const int lid[2] = {r2.x, r2.y};
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         if (lid[k] == lpid[k]) {
-                            lacc[k] = __builtin_fmaf(vat[j], lw[k], lacc[k]);
+                            lacc[k] = __builtin_fmaf(g_time, lw[k], lacc[k]);
                         } else if (lid[k] >= 0) {
                             if (lpid[k] >= 0) atomicAdd(&my_line[lpid[k]], lacc[k]);
                             lpid[k] = lid[k];
-                            lacc[k] = vat[j] * lw[k];
+                            lacc[k] = g_time * lw[k];
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 2; k++) lacc[k] = __builtin_fmaf(vat[j], lw[k], lacc[k]);
+                    for (int k = 0; k < 2; k++) lacc[k] = __builtin_fmaf(g_time, lw[k], lacc[k]);
                 }
             }
         }
@@ -691,7 +729,7 @@ extern "C" int mom_hexplane_orders(const MomHexPlane* hp, int P, const float* xy
 // deform_field.hip: the gather in the fused forward's layout, for fields mom_deform_field_supported() accepts
 size_t mom_hexplane_lines_bytes(const MomHexPlane* hp);
 int mom_launch_hexplane_gather6(const MomHexPlane* hp, int P, const float* xyz, float time, const uint32_t* order, const float* dfeat,
-                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, bool lines_ready, hipStream_t s);
+                                float* dxyz, const uint32_t* plane_inverse, float* gvbuf, float* lines, bool lines_ready, bool crows, hipStream_t s);
 extern "C" int mom_deform_field_supported(const MomHexPlane* hp);
 
 static size_t gv_bytes(const MomHexPlane* hp, int P) { return mom_align_up((size_t)6 * (size_t)P * (size_t)hp->levels * 32 * sizeof(float)); }
@@ -747,7 +785,9 @@ static int hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, con
         // two-pass path: one shared timestamp, per-plane orders and the gv scratch given
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(hexplane_bwd5_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(hexplane_bwd5_scatter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(hexplane_bwd5_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     160 * 1024) != hipSuccess)
                 return MOM_ELAUNCH;
             attr_set = true;
@@ -763,13 +803,28 @@ static int hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, con
         // MOM_HEX_GATHER=5: the lane-per-channel gather (measurement, and the comparison in tests/test_ops_gpu.py; read per call)
         const char* e_g = getenv("MOM_HEX_GATHER");
         const int gather6 = (e_g && e_g[0] == '5') ? 0 : 1;
-        if (gather6 && mom_deform_field_supported(hp)) {
+        const size_t lds_c = lds_s;
+        const bool use6 = gather6 && mom_deform_field_supported(hp);
+        // One common-factor row per (slot, position) instead of the slot's two gv rows (see the scatter kernel); MOM_HEX_CROWS=0: the
+        // six-row form.  Measured at 200 k Gaussians: alone the two passes take 83 + 81 us instead of 105 + 84 and move 307 MB
+        // less; beside the MLP's weight-gradient kernel, where they run in the training step, 117 + 141 against 160 + 105 (the
+        // scatter now waits for the texel values of every new cell in the middle of its walk, and a walk that waits suffers more
+        // from a neighbour than one that streams).  The step, same box, alternating runs: +0.2 ... +1.4 % at 200 k Gaussians,
+        // +5 % at 1 M (1080p), +6 % at 4 M.  (Staging the line values in LDS cost two of five workgroups per CU: 106 us; requesting
+        // the flagged positions' texel values with the batch's rows, after a scan of the batch's flags: 116 us.)
+        const char* e_c = getenv("MOM_HEX_CROWS");
+        const bool crows = use6 && !(e_c && e_c[0] == '0');
+        const float* lines_c = nullptr;
+        LineTab lt;
+        line_table(hp, &lt);
+        if (use6) {
             // the frame's time lines: the table mom_deform_field_forward left at the head of its scratch, or computed here
             float* lines = field_scratch ? (float*)mom_align_ptr(const_cast<void*>(field_scratch))
                                          : (float*)mom_align_ptr((char*)gvbuf + gv_bytes(hp, P));
             int rc = mom_launch_hexplane_gather6(hp, P, xyz, time, order, dfeat, dxyz, plane_inverse, gvbuf, lines, field_scratch != nullptr,
-                                                 (hipStream_t)stream);
+                                                 crows, (hipStream_t)stream);
             if (rc) return rc;
+            lines_c = lines;
         } else {
             const int nchunks = (P + kChunk5 - 1) / kChunk5;
             int blocks = (nchunks + 3) / 4;
@@ -784,8 +839,12 @@ static int hexplane_backward(const MomHexPlane* hp, int P, const float* xyz, con
             int per_half = (P + halves - 1) / halves;
             per_half = ((per_half + kChunk5s - 1) / kChunk5s) * kChunk5s;
             const int blocks = (int)(((long long)P + (long long)per_half * 8 - 1) / ((long long)per_half * 8));
-            hipLaunchKernelGGL(hexplane_bwd5_scatter_kernel, dim3(blocks, 3, hp->levels), dim3(256), lds_s, (hipStream_t)stream, a,
-                               per_half, xyz, plane_order, gvbuf);
+            if (crows)       // the gather left one common-factor row per (slot, position): this pass forms the two gv rows itself
+                hipLaunchKernelGGL(hexplane_bwd5_scatter_kernel<true>, dim3(blocks, 3, hp->levels), dim3(256), lds_c, (hipStream_t)stream, a,
+                                   per_half, xyz, plane_order, gvbuf, lines_c, lt);
+            else
+                hipLaunchKernelGGL(hexplane_bwd5_scatter_kernel<false>, dim3(blocks, 3, hp->levels), dim3(256), lds_s, (hipStream_t)stream, a,
+                                   per_half, xyz, plane_order, gvbuf, lines_c, lt);
         }
         return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
     }

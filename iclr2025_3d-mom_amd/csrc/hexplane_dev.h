@@ -34,6 +34,12 @@ struct HexArgs {
     const uint32_t* order;  // optional processing order (a permutation of 0..P-1, e.g. Morton order); null -> identity
 };
 
+// The per-frame table of time lines (deform_field.hip, hexplane_lines_kernel): for level l and axis k the rows
+// lines[off[l][k] + r * 32 .. + 31] = the space-time plane (k, t) interpolated at the frame's timestamp, row r along axis k.
+struct LineTab {
+    unsigned off[4][3];                              // float offset of line (level, axis) inside the table
+};
+
 __constant__ int kCombA[6] = {0, 0, 0, 1, 1, 2};
 __constant__ int kCombB[6] = {1, 2, 3, 2, 3, 3};
 
@@ -69,3 +75,13 @@ static void fill_args(const MomHexPlane* hp, int P, const float* times, float ti
     for (int k = 0; k < 3; k++) { a->a0[k] = hp->aabb[k]; a->a1[k] = hp->aabb[3 + k]; }
 }
 
+static int line_table(const MomHexPlane* hp, LineTab* lt)
+{
+    unsigned off = 0;
+    for (int l = 0; l < 4; l++)
+        for (int k = 0; k < 3; k++) {
+            lt->off[l][k] = off;
+            if (l < hp->levels) off += (unsigned)hp->res[l][k] * 32u;
+        }
+    return (int)off;
+}

@@ -599,3 +599,29 @@ def test_deform_backward_on_the_bf16_pipe_equals_the_f32_products(monkeypatch):
     assert float((f1 - f2).abs().max()) <= 2e-6 * sc, (float((f1 - f2).abs().max()), sc)
     for a, b in zip(g1, g2):
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
+
+
+def test_hexplane_backward_with_common_factor_rows_equals_the_six_row_form(monkeypatch):
+    """MOM_HEX_CROWS=1: the gather leaves one row per (order slot, position) -- dfeat times the samples of the four planes outside
+    the slot -- and the scatter forms the slot's two gv rows itself from the time line's and the space plane's own samples
+    (csrc/hexplane.hip, hexplane_bwd5_scatter_kernel<true>).  Same plane and position gradients as the six-row form, to rounding."""
+    f = _field((64, 64, 64, 25), (1, 2)).cuda()
+    n, t = 20011, 0.41
+    pts = _points(n)
+    w = torch.randn(n, f.feat_dim, generator=torch.Generator().manual_seed(6)).cuda()
+
+    def run(mode):
+        monkeypatch.setenv("MOM_HEX_CROWS", mode)
+        f.zero_grad()
+        p = pts.cuda().requires_grad_(True)
+        (f(p, t) * w).sum().backward()
+        torch.cuda.synchronize()
+        return p.grad.clone(), [[q.grad.clone() for q in g] for g in f.grids]
+
+    g0, p0 = run("0")
+    g1, p1 = run("1")
+    assert float((g0 - g1).abs().max()) <= 2e-5 * float(g0.abs().max())
+    for la, lb in zip(p0, p1):
+        for a, b in zip(la, lb):
+            assert float(b.abs().max()) > 0
+            assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
