@@ -266,12 +266,18 @@ deform_bwd_dx_kernel(MlpDev m, int P, int tiles, const float* __restrict__ a0g, 
 template <int NL>
 __global__ void __launch_bounds__(256)
 deform_bwd_dw_kernel(MlpDev m, int P, int chunk, const float* __restrict__ feat, const float* __restrict__ a0g,
-                     const float* __restrict__ dH)
+                     const float* __restrict__ dH, int ny)
 {
     extern __shared__ float lds[];                     // [64][64] reduction scratch
     const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int L0 = NL * blockIdx.y;                    // first layer of this workgroup row
+    // One-dimensional grid of (ranges of Gaussians) x (ny layer groups), numbered so that the ny workgroups of one range are 8
+    // ids apart inside a run of 8 ny ids: workgroup ids go to the eight XCDs in turn, so the layer groups of a range land on the
+    // SAME XCD at about the same time, and the rows of a0 the three head layers all read come out of that XCD's L2 twice out of
+    // three times (a two-dimensional grid ran all ranges of layer 0, then all of layer 1, ...: three trips to memory).
+    const int lin = blockIdx.x, run = 8 * ny;
+    const int bx = (lin / run) * 8 + (lin % run) % 8, by = (lin % run) / 8;
+    const int wave = (bx * 256 + threadIdx.x) >> 6;
+    const int L0 = NL * by;                            // first layer of this workgroup
     const size_t PH = (size_t)P * kHid;
     const int g_begin = wave * chunk, g_end = min(P, g_begin + chunk);   // chunk is even
 
@@ -751,8 +757,8 @@ static int deform_backward_fused(const MomDeformMLP* w, int P, const float* feat
     const int waves = 1024;
     int chunk = (P + waves - 1) / waves;
     chunk += chunk & 1;
-    hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, dim3(waves / 4, 1), dim3(256), sizeof(float) * (kHid * kHid + kHid), ws, d, P, chunk, feat,
-                       a0, dH0);
+    hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, dim3(waves / 4), dim3(256), sizeof(float) * (kHid * kHid + kHid), ws, d, P, chunk, feat,
+                       a0, dH0, 1);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
@@ -828,13 +834,14 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
         nl = e ? atoi(e) : 1;                 // measured: dx + dW 344 / 339 / 326 us for 4 / 2 / 1 layers per wave
         if (nl != 1 && nl != 2 && nl != 4) nl = 1;
     }
-    const dim3 grid(waves / 4, 4 / nl);
+    const int ny = 4 / nl;
+    const dim3 grid((waves / 4) * ny);                 // one-dimensional: the kernel deals (range, layer group) to the XCDs itself
     if (nl == 4)
-        hipLaunchKernelGGL(deform_bwd_dw_kernel<4>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH);
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<4>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH, ny);
     else if (nl == 2)
-        hipLaunchKernelGGL(deform_bwd_dw_kernel<2>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH);
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<2>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH, ny);
     else
-        hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH);
+        hipLaunchKernelGGL(deform_bwd_dw_kernel<1>, grid, dim3(256), lds_b, ws, d, P, chunk, feat, a0, dH, ny);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
