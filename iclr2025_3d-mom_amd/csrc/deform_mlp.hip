@@ -823,8 +823,9 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
         if (hipEventRecord(dx_done, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
         if (hipStreamWaitEvent(ws, dx_done, 0) != hipSuccess) return MOM_ELAUNCH;
     }
-    // weight gradients: 1024 waves, each a contiguous (even-sized) range of gaussians
-    const int waves = 1024;
+    // weight gradients: 1024 waves, each a contiguous (even-sized) range of gaussians (MOM_DW_WAVES: a multiple of 32, measurement)
+    static int waves = 0;
+    if (!waves) { const char* e = getenv("MOM_DW_WAVES"); waves = e ? atoi(e) : 1024; if (waves < 32 || waves % 32) waves = 1024; }
     int chunk = (P + waves - 1) / waves;
     chunk += chunk & 1;
     // layers per wave (MOM_DW_NL = 4, 2 or 1): fewer layers -> fewer accumulators -> more waves and more loads in flight per CU

@@ -140,10 +140,10 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
 #define MOM_FWD_WAVES 8
 #endif
 #ifndef MOM_BWD_WAVES
-#define MOM_BWD_WAVES 6
+#define MOM_BWD_WAVES 5
 #endif
 #ifndef MOM_BWD_MIN
-#define MOM_BWD_MIN 4
+#define MOM_BWD_MIN 5
 #endif
 // Optional loss epilogue of the forward kernel (MomRasterArgs.l1_target): target null = none.
 struct L1Epilogue {
