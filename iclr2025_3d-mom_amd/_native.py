@@ -21,8 +21,12 @@ class MomError(RuntimeError):
     pass
 
 
+ABI_VERSION = 4          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
+
+
 class MomRasterArgs(C.Structure):
-    _fields_ = [("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
+    _fields_ = [("struct_size", C.c_uint),                          # sizeof(MomRasterArgs): set by __init__, checked by every entry point
+                ("P", C.c_int), ("D", C.c_int), ("M", C.c_int), ("W", C.c_int), ("H", C.c_int),
                 ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p),
                 ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p), ("scales", C.c_void_p),
                 ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p), ("viewmatrix", C.c_void_p),
@@ -34,6 +38,10 @@ class MomRasterArgs(C.Structure):
                 ("keep_all_tiles", C.c_int),                        # !=0: bin the whole rectangle like the reference (tests)
                 ("l1_target", C.c_void_p), ("l1_grad", C.c_void_p), ("l1_sums", C.c_void_p),   # optional L1 epilogue of the forward
                 ("accum_cleared", C.c_int)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_size = C.sizeof(type(self))
 
 
 class MomRasterGrads(C.Structure):
@@ -83,6 +91,10 @@ def build(verbose: bool = False) -> str:
 def _sig(lib):
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     lib.mom_version.restype = C.c_char_p
+    lib.mom_abi_version.restype = i32
+    lib.mom_abi_version.argtypes = []
+    lib.mom_abi_sizeof.restype = sz
+    lib.mom_abi_sizeof.argtypes = [i32]
     lib.mom_raster_geom_bytes.restype = sz
     lib.mom_raster_geom_bytes.argtypes = [i32]
     lib.mom_raster_image_bytes.restype = sz
@@ -160,7 +172,7 @@ class MomRowSelect(C.Structure):
 
 # every symbol include/mom4d.h declares (tests/test_abi.py checks this list against the header)
 EXPORTS = [
-    "mom_version", "mom_raster_geom_bytes", "mom_raster_image_bytes", "mom_raster_binning_bytes", "mom_raster_layout",
+    "mom_version", "mom_abi_version", "mom_abi_sizeof", "mom_raster_geom_bytes", "mom_raster_image_bytes", "mom_raster_binning_bytes", "mom_raster_layout",
     "mom_raster_forward_geometry", "mom_raster_forward_render", "mom_raster_backward", "mom_mark_visible",
     "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_hexplane_backward_lines", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
@@ -175,6 +187,52 @@ EXPORTS = [
 ]
 
 
+# the MOM_STRUCT_* ids of include/mom4d.h, in order, with the ctypes mirror of each struct
+ABI_STRUCTS = None
+
+
+def _abi_structs():
+    return [("MOM_STRUCT_RASTER_ARGS", MomRasterArgs), ("MOM_STRUCT_RASTER_GRADS", MomRasterGrads),
+            ("MOM_STRUCT_RASTER_LAYOUT", MomRasterLayout), ("MOM_STRUCT_HEXPLANE", MomHexPlane),
+            ("MOM_STRUCT_ADAM_TENSOR", MomAdamTensor), ("MOM_STRUCT_ROW_SELECT", MomRowSelect),
+            ("MOM_STRUCT_REG_PLANE", MomRegPlane), ("MOM_STRUCT_DEFORM_MLP", MomDeformMLP)]
+
+
+_CTYPE_NAMES = {C.c_int: "C.c_int", C.c_uint: "C.c_uint", C.c_float: "C.c_float", C.c_void_p: "C.c_void_p",
+                C.c_size_t: "C.c_size_t"}
+
+
+def ctypes_mirror_source(cls, width=112):
+    """Python source of the ctypes mirror of one ABI struct, generated from its `_fields_` -- the text INTEGRATION.md section 3
+    shows a maintainer; tests/test_abi.py regenerates it and compares, so the document cannot drift from the binding."""
+    items = [f'("{n}", {_CTYPE_NAMES[t]})' for n, t in cls._fields_]
+    lines, cur = [], "    _fields_ = ["
+    for i, it in enumerate(items):
+        piece = it + ("," if i + 1 < len(items) else "]")
+        if len(cur) + len(piece) + 1 > width:
+            lines.append(cur.rstrip())
+            cur = " " * 16
+        cur += piece + " "
+    lines.append(cur.rstrip())
+    return (f"class {cls.__name__}(C.Structure):           # include/mom4d.h: {cls.__name__}, ABI version {ABI_VERSION}\n"
+            + "\n".join(lines) + "\n\n"
+            "    def __init__(self, *args, **kw):\n"
+            "        super().__init__(*args, **kw)\n"
+            "        self.struct_size = C.sizeof(type(self))   # checked by every entry point: a short struct is MOM_EINVAL\n")
+
+
+def check_abi(lib):
+    """Refuse a library whose ABI is not the one this mirror was written against: the version number, and sizeof of every
+    argument struct as the library was compiled against the ctypes mirror's (a short struct would be read past its end)."""
+    v = lib.mom_abi_version()
+    if v != ABI_VERSION:
+        raise MomError(f"{LIB_PATH}: ABI version {v}, this binding was written against {ABI_VERSION} (rebuild the library)")
+    for which, (name, cls) in enumerate(_abi_structs()):
+        n = lib.mom_abi_sizeof(which)
+        if n != C.sizeof(cls):
+            raise MomError(f"{LIB_PATH}: sizeof({cls.__name__}) is {n} in the library, {C.sizeof(cls)} in the binding ({name})")
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -185,7 +243,9 @@ def lib():
         # loaded before torch, libmom4d pulls in /opt/rocm's runtime, the process then holds two, and every launch on one of
         # torch's streams fails (seen as "HIP launch/runtime failure" in smoke() when build() had loaded the library first)
         import torch  # noqa: F401
-        _lib = _sig(C.CDLL(LIB_PATH))
+        l = _sig(C.CDLL(LIB_PATH))
+        check_abi(l)
+        _lib = l
     return _lib
 
 

@@ -17,7 +17,8 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
 
 static int check_args(const MomRasterArgs* a)
 {
-    if (!a || a->P < 0 || a->W <= 0 || a->H <= 0) return MOM_EINVAL;
+    if (!a || a->struct_size != sizeof(MomRasterArgs)) return MOM_EINVAL;   // a binder built against another header: refuse
+    if (a->P < 0 || a->W <= 0 || a->H <= 0) return MOM_EINVAL;
     if (a->tile_row0 < 0 || a->tile_row1 < a->tile_row0 || a->tile_row1 > (a->H + MOM_TILE - 1) / MOM_TILE) return MOM_EINVAL;
     if (a->P == 0) return MOM_OK;
     if (!a->means3D || !a->opacities || !a->viewmatrix || !a->projmatrix || !a->campos || !a->background) return MOM_EINVAL;
@@ -42,7 +43,22 @@ extern "C" {
 #ifndef MOM_SRC_HASH
 #define MOM_SRC_HASH "unknown"
 #endif
-const char* mom_version(void) { return "mom4d 0.3 (gfx950) src " MOM_SRC_HASH; }
+const char* mom_version(void) { return "mom4d 0.4 (gfx950) src " MOM_SRC_HASH; }
+int mom_abi_version(void) { return MOM_ABI_VERSION; }
+size_t mom_abi_sizeof(int which)
+{
+    switch (which) {
+    case MOM_STRUCT_RASTER_ARGS: return sizeof(MomRasterArgs);
+    case MOM_STRUCT_RASTER_GRADS: return sizeof(MomRasterGrads);
+    case MOM_STRUCT_RASTER_LAYOUT: return sizeof(MomRasterLayout);
+    case MOM_STRUCT_HEXPLANE: return sizeof(MomHexPlane);
+    case MOM_STRUCT_ADAM_TENSOR: return sizeof(MomAdamTensor);
+    case MOM_STRUCT_ROW_SELECT: return sizeof(MomRowSelect);
+    case MOM_STRUCT_REG_PLANE: return sizeof(MomRegPlane);
+    case MOM_STRUCT_DEFORM_MLP: return sizeof(MomDeformMLP);
+    default: return 0;
+    }
+}
 
 size_t mom_raster_geom_bytes(int P) { return geom_view(nullptr, P, nullptr) + MOM_ALIGN; }
 size_t mom_raster_image_bytes(int W, int H) { return image_view(nullptr, W, H, nullptr) + MOM_ALIGN; }

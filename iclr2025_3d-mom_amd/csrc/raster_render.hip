@@ -184,10 +184,10 @@ __device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* 
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FWD_WAVES, MOM_FWD_WAVES)))
-render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
+render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read AND, for the tiles sorted here, written: no restrict */, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-                  uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys, uint32_t* __restrict__ sorted_out)
+                  uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys)
 {
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
@@ -222,7 +222,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         for (int i = threadIdx.x; i < toDo; i += 256) sk[i] = gk[i];
         __syncthreads();
         if (toDo > 1) bitonic_sort<true>(sk, toDo, 256, (int)threadIdx.x);
-        for (int i = threadIdx.x; i < toDo; i += 256) sorted_out[range.x + i] = (uint32_t)sk[i];
+        for (int i = threadIdx.x; i < toDo; i += 256) point_list[range.x + i] = (uint32_t)sk[i];
         __threadfence_block();
         __syncthreads();
     }
@@ -544,7 +544,7 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     if (!l1.grad || !l1.sums) l1.target = nullptr;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
-                       out_depth, cap, l1, sort_small ? b.keys : nullptr, b.point_list);
+                       out_depth, cap, l1, sort_small ? b.keys : nullptr);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

@@ -70,15 +70,14 @@ def _check_overflow(lag):
         if not (int(host[0]) & 1):
             _state["verified"] = serial
             continue
-        if True:
-            q.clear()
-            torch.cuda.current_stream().synchronize()      # nothing that still tests the word is in flight when it is cleared
-            _state["flag"].zero_()
-            _state["cap_hint"] = max(_state["cap_hint"], int(count[0]) * 2)
-            raise BinningOverflow("libmom4d: an async-mode forward overflowed its binning capacity (instance count "
-                               f"{int(count[0])}); its image and every image since were truncated.  Optimizer steps were skipped "
-                               "on the device from that forward on if FusedAdam.skip_flag is overflow_flag(); the capacity "
-                               "hint has been doubled -- repeat those iterations, or use set_sync_mode('exact')", serial)
+        q.clear()
+        torch.cuda.current_stream().synchronize()      # nothing that still tests the word is in flight when it is cleared
+        _state["flag"].zero_()
+        _state["cap_hint"] = max(_state["cap_hint"], int(count[0]) * 2)
+        raise BinningOverflow("libmom4d: an async-mode forward overflowed its binning capacity (instance count "
+                              f"{int(count[0])}); its image and every image since were truncated.  Optimizer steps were skipped "
+                              "on the device from that forward on if FusedAdam.skip_flag is overflow_flag(); the capacity "
+                              "hint has been doubled -- repeat those iterations, or use set_sync_mode('exact')", serial)
 
 
 def set_sync_mode(mode: str, capacity_hint: int = 0) -> None:

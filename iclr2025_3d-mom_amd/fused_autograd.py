@@ -292,6 +292,6 @@ class FusedRenderFunction(torch.autograd.Function):
 
 def render(cam, pc, pipe, bg, delta_scale, scaling_modifier, screenspace_points):
     planes, mlp = field_params(pc)
-    return FusedRenderFunction.apply(pc, cam, bg, 1 if delta_scale is None else delta_scale, scaling_modifier, pipe.debug,
+    return FusedRenderFunction.apply(pc, cam, bg, delta_scale, scaling_modifier, pipe.debug,
                                      screenspace_points, pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation,
                                      pc._opacity, *planes, *mlp)

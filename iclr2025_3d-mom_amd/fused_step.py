@@ -179,9 +179,12 @@ class FusedStep:
         # to the bucket (the projection backward's d xyz).
         dc = self.dist
         reg_scale = 1.0 / dc.world if dc is not None else 1.0
+        # each on its own check: `side` is a public attribute a caller may have set
         if self.side is None:
             self.side = torch.cuda.Stream(device=dev)
+        if getattr(self, "regacc", None) is None:
             self.regacc = torch.zeros(1, dtype=torch.float32, device=dev)
+        if getattr(self, "_bucket_ready", None) is None:
             self._bucket_ready = torch.cuda.Event()
         hy = self.hyper
         reg = None
@@ -371,8 +374,6 @@ class FusedStep:
         # ---- deformation backward: pts = xyz + dx(...) so d xyz starts as d pts (already in gxyz); the HexPlane adds its share
         # the MLP's weight-gradient kernel (matrix pipe) runs on a second stream beside the HexPlane backward (vector issue,
         # memory latency); joined below, before anything reads the weight gradients
-        if self.side is None:
-            self.side = torch.cuda.Stream(device=dev)
         side = self.side.cuda_stream if self.OVERLAP_DW else s
         if early_adam is not None and dc is None and self.EARLY_ADAM:
             # The appearance parameters' gradients (SH, scaling, rotation, opacity: 56 of a Gaussian's 59 floats) are final here.
@@ -412,7 +413,7 @@ class FusedStep:
                 N.check(lib.mom_deform_backward_split(C.byref(md), ns, v(self.feat).data_ptr(), v(self.a0).data_ptr(),
                                                       v(self.gxyz).data_ptr(), v(d_sc).data_ptr(), v(d_rot).data_ptr(),
                                                       v(self.dfeat).data_ptr(), self.dh_scratch.data_ptr(), s, side), "deform_bwd")
-                so = field._slice_order(xyz, g0, g1)
+                so = field._slice_order(xyz, g0, g1, bump=False)      # the forward's order of this step
                 spo = field._slice_plane_orders(xyz, g0, g1)
                 if spo is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (ns, hp.levels)):
                     self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), ns), dtype=torch.uint8, device=dev)

@@ -31,12 +31,17 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     """Background tensor (bg_color) must be on the GPU."""
     means3D = pc.get_xyz
     dev = means3D.device
+    if stage != "coarse" and delta_scale is None:
+        # the reference forms `delta_scale * (frame_num * scene_flow)` with whatever it was given (scene/deformation.py:114 via
+        # gaussian_renderer/__init__.py:101-103): None raises there, so it raises here, on every path
+        raise TypeError("unsupported operand type(s) for *: 'NoneType' and 'Tensor' (render(): delta_scale is required "
+                        "outside the coarse stage)")
     if _nograd_fast_path_applies(viewpoint_camera, pc, pipe, stage, override_color, cam_type):
         fr = getattr(pc, "_fused_render", None)
         if fr is None:
             from ..fused_render import FusedRender
             fr = pc._fused_render = FusedRender(pc)
-        image, depth, radii = fr.render(viewpoint_camera, bg_color, 1 if delta_scale is None else delta_scale, scaling_modifier,
+        image, depth, radii = fr.render(viewpoint_camera, bg_color, delta_scale, scaling_modifier,
                                         pipe.debug)
         return {"render": image, "viewspace_points": torch.zeros_like(means3D), "visibility_filter": radii > 0, "radii": radii,
                 "depth": depth, "flow_loss": 0}

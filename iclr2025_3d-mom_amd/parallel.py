@@ -65,12 +65,21 @@ class DistContext:
     MLP, forward and backward: half of a step) on its own SLICE of the Gaussians.  Exchanges per step: all-gather of the
     deformed state (15 floats per Gaussian), sum of the compositing backward's per-Gaussian record (12 floats), all-gather of
     the position gradients (3 floats), sum of the deformation field's gradients (2.9 M floats); projection, its backward, the
-    activations and Adam run replicated on identical inputs and stay bit-identical (fused step only)."""
+    activations and Adam run replicated on identical inputs and stay bit-identical (fused step only).
+
+    World sizes: the loss gradient (camera mode) and the regularisers (tile-row mode) carry the factor 1/world at their source
+    and the all-reduce sums `world` such terms: for a power-of-two world (1, 2, 4, 8: one node) that restores the unsharded
+    value EXACTLY; for any other world the replicas still agree with each other bit for bit (every rank receives the same
+    reduced buffer) but differ from a single-GPU run by the rounding of x/world.  `exact_scaling` says which case this is.
+    The RCCL branch of start_gather() (in-place all_gather_into_tensor, input a view of the output) has only ever run with
+    world == 1 (MOM_FORCE_DIST=1): no multi-GPU box is available to this repository's tests; the gloo list form is what
+    tests/test_two_process_gpu.py and tests/virtual_ranks.py exercise."""
 
     def __init__(self, rank, world, seed=6666, mode="camera"):
         if mode not in ("camera", "tile-row"):
             raise ValueError(f"unknown shard mode {mode!r}")
         self.rank, self.world, self.seed, self.mode = rank, world, seed, mode
+        self.exact_scaling = world >= 1 and (world & (world - 1)) == 0
         self._flat = None
         self._pending = []
         self.row_weights = None          # per-tile-row work estimate agreed by all ranks (rebalance_rows)

@@ -118,24 +118,28 @@ class HexPlaneField(nn.Module):
             self._porders_key = tuple(self.aabb_host())
         return self._porders
 
-    def _slice_order(self, pts, g0, g1):
+    def _slice_order(self, pts, g0, g1, bump=True):
         """Morton order of the points [g0, g1) (positions relative to g0): what a rank of a tile-row shard, which runs the
-        field on its slice of the Gaussians only, hands to the kernels.  Cached like the whole-cloud order."""
+        field on its slice of the Gaussians only, hands to the kernels.  Cached like the whole-cloud order: it ages once per
+        step -- the forward's call counts, the backward's (bump=False) takes the forward's order as it is, so a rebuild never
+        lands between the two halves of one step -- and the key carries the point tensor's storage and length, which densify /
+        prune replace even when the slice bounds happen to stay."""
         if not hasattr(ops.BACKEND, "morton_order") or g1 <= g0:
             return None
         c = getattr(self, "_sl_order", None)
-        key = (g0, g1, pts.device)
-        if c is None or c[0] != key or c[2] >= self.REORDER_EVERY:
+        key = (g0, g1, pts.device, pts.data_ptr(), pts.shape[0])
+        if c is None or c[0] != key or (bump and c[2] >= self.REORDER_EVERY):
             c = self._sl_order = [key, ops.BACKEND.morton_order(pts[g0:g1]), 0]
             self._sl_porders = None
-        c[2] += 1
+        if bump:
+            c[2] += 1
         return c[1]
 
     def _slice_plane_orders(self, pts, g0, g1):
         """Per-space-plane orders of the slice [g0, g1) for the two-pass backward; rebuilt with _slice_order (call it first)."""
         if not hasattr(ops.BACKEND, "hexplane_orders") or g1 <= g0 or not pts.is_cuda:
             return None
-        key = (g0, g1, tuple(self.aabb_host()))
+        key = (g0, g1, pts.data_ptr(), pts.shape[0], tuple(self.aabb_host()))
         po = getattr(self, "_sl_porders", None)
         if po is None or po[0] != key:
             po = self._sl_porders = (key, ops.BACKEND.hexplane_orders(pts[g0:g1], [list(g) for g in self.grids], self.aabb,

@@ -29,7 +29,9 @@ class FineSampler(Sampler):
                     cnt += 1
                     if cnt % 2 == 0 and len(sample_list) > 2:
                         now += random.sample(sample_list, 2)
-                sample_list += now
+            # once per frame, AFTER the four draws: the reference extends the list outside its `for j in range(4)` loop
+            # (utils/loader_utils.py:27-42), so only the fourth permutation of a frame survives
+            sample_list += now
         self.sample_list = sample_list
 
     def __iter__(self):

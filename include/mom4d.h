@@ -41,11 +41,30 @@ extern "C" {
 
 typedef void* mom_stream_t; /* hipStream_t */
 
+/* ---- ABI versioning ------------------------------------------------------------------------
+ * The argument structs below have grown between releases.  A binder built against an older header must not be able to
+ * pass a short struct silently, so:
+ *   - mom_abi_version() returns MOM_ABI_VERSION of the library that is loaded; a binder compares it with the value of
+ *     the header (or Python mirror) it was written against and refuses to continue on a mismatch;
+ *   - mom_abi_sizeof(which) returns sizeof of each argument struct as the library was compiled, so a foreign-language
+ *     mirror (ctypes, cffi) can verify its own layout field for field at load time;
+ *   - MomRasterArgs, the struct that changes most often, additionally starts with `struct_size`: every entry point that
+ *     takes it returns MOM_EINVAL unless struct_size == sizeof(MomRasterArgs) of the library.
+ * (The reference's counterpart is a C++ static-method signature, rasterizer.h:19-87: there the compiler checks it.) */
+#define MOM_ABI_VERSION 4
+int mom_abi_version(void);
+enum {
+    MOM_STRUCT_RASTER_ARGS = 0, MOM_STRUCT_RASTER_GRADS, MOM_STRUCT_RASTER_LAYOUT, MOM_STRUCT_HEXPLANE, MOM_STRUCT_ADAM_TENSOR,
+    MOM_STRUCT_ROW_SELECT, MOM_STRUCT_REG_PLANE, MOM_STRUCT_DEFORM_MLP, MOM_STRUCT_COUNT
+};
+size_t mom_abi_sizeof(int which);   /* 0 for an unknown id */
+
 /* Arguments of one rasterizer call; the field meanings are those of
  * CudaRasterizer::Rasterizer::forward (rasterizer.h:29-55).  Null pointers stand
  * for "absent" exactly as empty tensors do in the reference (forward.cu:205,241).
  * Matrices are the transposed (column-major) 4x4s the reference passes. */
 typedef struct MomRasterArgs {
+    uint32_t struct_size;  /* = sizeof(MomRasterArgs) of the header the caller was built against; anything else: MOM_EINVAL */
     int P;                 /* number of Gaussians */
     int D;                 /* active SH degree (0..3) */
     int M;                 /* SH coefficients per Gaussian in `shs` (0 if absent) */
