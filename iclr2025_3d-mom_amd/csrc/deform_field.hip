@@ -17,6 +17,13 @@
 //
 // Arithmetic follows ATen's grid_sampler_2d (weights nw, ne, sw, se from bx = ix - x0 and 1 - bx) and the reference's product
 // order over the planes; only the two time rows are combined first (a reassociation of the same four products).
+//
+// BUILD CONSTRAINT (correctness, not speed): no packed fp32 arithmetic in this file.  With v_pk_fma_f32 / v_pk_mul_f32 in the
+// gather -- the SLP vectoriser's output -- about one launch in ten left wrong values in lanes 48-63 while other waves of the SIMD
+// issued bf16 MFMAs (never without the MFMAs, never with scalar fp32).  The Makefile builds every file with
+// -fno-slp-vectorize; tests/test_isa.py disassembles the shipped code object and fails on any v_pk_*_f32 in a kernel of this file
+// or in any kernel that issues MFMAs, and tests/test_deform_field_gpu.py::test_soak_500_launches_are_bit_identical is the
+// behavioural guard.  Do not hand-write float2 arithmetic here either: clang lowers it to the same packed forms.
 #include "deform_mlp_dev.h"
 #include "hexplane_dev.h"
 #include "deform_b3_dev.h"

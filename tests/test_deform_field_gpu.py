@@ -123,3 +123,52 @@ def test_fused_forward_without_saved_tensors_and_refusals():
                                 'resolution': [8, 8, 8, 5]}, [1, 2, 4]).cuda()
     hp3, keep3 = ops._hexplane_desc([[p.detach() for p in lv] for lv in three.grids], three.aabb, None, aabb_host=three.aabb_host())
     assert lib.mom_deform_field_supported(C.byref(hp3)) == 0 and lib.mom_deform_field_supported(C.byref(hp)) == 1
+
+
+@pytest.mark.parametrize("with_order", [False, True])
+def test_soak_500_launches_are_bit_identical(with_order):
+    """DESIGN.md section 0 / ADVICE r3 (medium): with packed fp32 (v_pk_fma_f32 / v_pk_mul_f32) in the gather, about one launch in
+    ten of the fused field forward left wrong feature components while other waves issued bf16 MFMAs.  The build keeps packed
+    fp32 out of the file (-fno-slp-vectorize; tests/test_isa.py checks the shipped ISA); this soak is the behavioural guard: 500
+    launches on the config-2 field (200 k Gaussians, [64, 64, 64, 50]), every output of every launch bit-equal to the first
+    launch's, and the first launch within the gates of the two-kernel f32 path.  ~40 ms of GPU time per parameter."""
+    P, t = 200_000, 0.4237
+    f = _field((64, 64, 64, 50)).cuda()
+    params_cpu, mk = _mlp(11)
+    params = [p.cuda() for p in params_cpu]
+    xyz, scal, rot, flow, opac = (t_.cuda() for t_ in (_points(P), mk(P, 3), mk(P, 4), mk(P, 3), mk(P, 1)))
+    order = ops.morton_order(xyz) if with_order else None
+    lib, s = N.lib(), N.current_stream()
+    hp, keep = ops._hexplane_desc([[p.detach() for p in lv] for lv in f.grids], f.aabb, None, aabb_host=f.aabb_host())
+    md = ops.DeformMLPFunction._desc(params)
+    scratch = ops.field_scratch(hp, xyz.device, P)
+    names = ("pts", "sc_d", "rot_d", "feat", "a0", "sc", "rot", "op")
+    widths = (3, 3, 4, 64, 64, 3, 4, 1)
+
+    def launch(out):
+        N.check(lib.mom_deform_field_forward(C.byref(hp), C.byref(md), P, xyz.data_ptr(), t, N.ptr(order), scal.data_ptr(),
+                                             rot.data_ptr(), flow.data_ptr(), 0.7, out["pts"].data_ptr(), out["sc_d"].data_ptr(),
+                                             out["rot_d"].data_ptr(), out["feat"].data_ptr(), out["a0"].data_ptr(), opac.data_ptr(),
+                                             out["sc"].data_ptr(), out["rot"].data_ptr(), out["op"].data_ptr(), scratch.data_ptr(), s),
+                "mom_deform_field_forward")
+
+    first = {k: torch.full((P, w), float("nan"), device="cuda") for k, w in zip(names, widths)}
+    launch(first)
+    again = {k: torch.empty_like(v) for k, v in first.items()}
+    bad = torch.zeros(len(names), dtype=torch.int64, device="cuda")      # launches that differed, per output; no host sync in the loop
+    for _ in range(500):
+        for v in again.values():
+            v.fill_(float("nan"))
+        launch(again)
+        # bit comparison (NaN-safe: compare the words)
+        bad += torch.stack([(again[k].view(torch.int32) != first[k].view(torch.int32)).any() for k in names]).to(torch.int64)
+    torch.cuda.synchronize()
+    assert bad.tolist() == [0] * len(names), dict(zip(names, bad.tolist()))
+    for k in names:
+        assert torch.isfinite(first[k]).all(), k
+    ref = _run_forward(f, params, P, xyz, scal, rot, flow, opac, t, order, fused=False)       # two-kernel f32 path
+    fs = float(ref["feat"].abs().max())
+    assert float((first["feat"] - ref["feat"]).abs().max()) <= 2e-6 * max(1.0, fs)
+    for k in ("pts", "sc_d", "rot_d", "sc", "rot", "op"):
+        np.testing.assert_allclose(first[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=2e-5, atol=2e-5)
+    assert float((first["a0"] - ref["a0"]).abs().max()) <= 5e-5 * max(1.0, float(ref["a0"].abs().max()))
