@@ -13,9 +13,11 @@
  *  and its CUDA sources cannot be built here (no nvcc, no
  * CUDA GPU) => "parity unpinned by the reference".  The oracle is pinned
  * instead by tests/test_oracle_*.py: hand-derived known answers, structural
- * invariants, finite differences of the fp64 build of this same file, a
- * pure-torch autograd re-expression, and the reference's own importable Python
- * (eval_sh, build_covariance_from_scaling_rotation).
+ * invariants, finite differences of the fp64 build of this same file
+ * (tests/test_oracle_raster.py), an independent pure-torch statement of the
+ * forward whose torch.autograd gradients equal this file's backward to 1e-7
+ * (oracle/torch_raster.py, tests/test_oracle_torch.py), and the reference's
+ * own importable Python (eval_sh, build_covariance_from_scaling_rotation).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this file's shared object.
