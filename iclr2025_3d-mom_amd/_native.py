@@ -90,6 +90,26 @@ def build(verbose: bool = False) -> str:
 
 def _sig(lib):
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    if os.environ.get("MOM4D_LIB_LAX") == "1":
+        # A/B tooling only (tools/kbench.py with MOM4D_LIB naming an OLDER build of the library): bind what that build has
+        class _Lax:
+            def __init__(self, real):
+                object.__setattr__(self, "_real", real)
+
+            def __getattr__(self, name):
+                try:
+                    return getattr(self._real, name)
+                except AttributeError:
+                    class _Missing:
+                        restype = argtypes = None
+
+                        def __call__(self, *a):
+                            raise MomError(f"{name} is not in {LIB_PATH}")
+                    return _Missing()
+        lib = _Lax(lib)
+    else:
+        for name in EXPORTS:
+            getattr(lib, name)  # raises AttributeError if the library lacks a declared symbol
     lib.mom_version.restype = C.c_char_p
     lib.mom_abi_version.restype = i32
     lib.mom_abi_version.argtypes = []
@@ -109,6 +129,7 @@ def _sig(lib):
     lib.mom_raster_backward_geometry.argtypes = [C.POINTER(MomRasterArgs), vp, vp, C.POINTER(MomRasterGrads), vp]
     lib.mom_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.mom_selftest_wave_sum.argtypes = [vp, vp, i32, vp]
+    lib.mom_selftest_row_reduce.argtypes = [vp, vp, i32, i32, vp]
     lib.mom_hexplane_forward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp]
     lib.mom_hexplane_backward.argtypes = [C.POINTER(MomHexPlane), i32, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp]
     lib.mom_hexplane_backward_lines.argtypes = [C.POINTER(MomHexPlane), i32, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -157,8 +178,6 @@ def _sig(lib):
     lib.mom_knn_scratch_bytes.restype = sz
     lib.mom_knn_scratch_bytes.argtypes = [i32]
     lib.mom_knn_mean_dist2.argtypes = [i32, vp, vp, vp, vp]
-    for name in EXPORTS:
-        getattr(lib, name)  # raises AttributeError if the library lacks a declared symbol
     return lib
 
 
@@ -174,7 +193,7 @@ class MomRowSelect(C.Structure):
 EXPORTS = [
     "mom_version", "mom_abi_version", "mom_abi_sizeof", "mom_raster_geom_bytes", "mom_raster_image_bytes", "mom_raster_binning_bytes", "mom_raster_layout",
     "mom_raster_forward_geometry", "mom_raster_forward_render", "mom_raster_backward", "mom_mark_visible",
-    "mom_selftest_wave_sum", "mom_hexplane_forward", "mom_hexplane_backward", "mom_hexplane_backward_lines", "mom_adam_step", "mom_l1_loss",
+    "mom_selftest_wave_sum", "mom_selftest_row_reduce", "mom_hexplane_forward", "mom_hexplane_backward", "mom_hexplane_backward_lines", "mom_adam_step", "mom_l1_loss",
     "mom_plane_regulation", "mom_knn_scratch_bytes", "mom_knn_mean_dist2",
     "mom_profile_enable", "mom_profile_read", "mom_profile_name",
     "mom_morton_order_scratch_bytes", "mom_morton_order", "mom_activations_forward", "mom_activations_backward", "mom_deform_forward", "mom_deform_forward_activated", "mom_deform_backward_scratch_bytes", "mom_deform_backward", "mom_deform_backward_split",

@@ -8,9 +8,10 @@
 //
 // Backward: instead of the reference's 10 global float atomics per (pixel,
 // splat) pair, each wave reduces its 64 pixels' contributions in registers
-// (a packed DPP reduce-scatter, reduce_scatter10) and issues ONE 40-byte atomic
-// instruction per (wave, splat) into the per-Gaussian accumulator record
-// gacc[P][12].
+// (a packed DPP reduce-scatter inside the 16-lane rows, row_totals; the four rows
+// of four consecutive splats are summed by one transposition, rows_transpose_sum)
+// and issues ONE atomic instruction per four (wave, splat) pairs into the
+// per-Gaussian accumulator record gacc[P][12].
 #include "mom_common.h"
 #include "raster_bin_dev.h"
 
@@ -49,45 +50,6 @@ __device__ __forceinline__ float wave_sum(float v)
     v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
     v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3 -> row 3 holds the wave sum
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-// Pair step of a reduce-scatter: lanes whose `upper` bit is clear end up with the pair-sum of x, the others with the
-// pair-sum of y (the partner lane, CTRL, differs in exactly that bit).
-template <int CTRL>
-__device__ __forceinline__ float dpp_pair(float x, float y, bool upper)
-{
-    const float keep = upper ? y : x, send = upper ? x : y;
-    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, false));
-}
-// Sums ten per-lane values over the 64 lanes of the wave; lane k (k < 10) returns the total of v[k] (the other
-// lanes return totals of some component too -- callers only use lanes 0..9).  About half the instructions of ten
-// wave_sum calls: two scatter steps inside each quad pack the ten values into three registers (a lane's low two bits
-// pick its component), two row rotations sum those over the 16-lane rows, a lane select merges the three registers,
-// and gfx950's v_permlane16_swap / v_permlane32_swap add the four rows.
-__device__ __forceinline__ float reduce_scatter10(const float (&v)[10], int lane)
-{
-    const bool b0 = lane & 1, b1 = lane & 2;
-    const float a0 = dpp_pair<0xB1>(v[0], v[1], b0);     // quad_perm [1,0,3,2]
-    const float a1 = dpp_pair<0xB1>(v[2], v[3], b0);
-    const float a2 = dpp_pair<0xB1>(v[4], v[5], b0);
-    const float a3 = dpp_pair<0xB1>(v[6], v[7], b0);
-    const float a4 = dpp_pair<0xB1>(v[8], v[9], b0);
-    float c0 = dpp_pair<0x4E>(a0, a1, b1);               // quad_perm [2,3,0,1]: lane l holds v[l & 3] over its quad
-    float c1 = dpp_pair<0x4E>(a2, a3, b1);               //                      v[4 + (l & 3)]
-    float c2 = dpp_add<0x4E, 0xF>(a4);                   //                      v[8 + (l & 1)]
-    c0 = dpp_add<0x124, 0xF>(c0); c1 = dpp_add<0x124, 0xF>(c1); c2 = dpp_add<0x124, 0xF>(c2);   // row_ror:4
-    c0 = dpp_add<0x128, 0xF>(c0); c1 = dpp_add<0x128, 0xF>(c1); c2 = dpp_add<0x128, 0xF>(c2);   // row_ror:8
-    const int k = lane & 15;
-    float m = k < 4 ? c0 : (k < 8 ? c1 : c2);            // lane k of every row: row total of v[k]
-    {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    return m;
 }
 
 // The staging thread stores mom_power_bound(opacity) (mom_common.h) in the LDS copy of the record (r0.w, whose tile count
@@ -326,34 +288,98 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     }
 }
 
-#ifndef MOM_BWD_PEND
-#define MOM_BWD_PEND 4                // splats per atomic instruction (1..4)
-#endif
-// The same for nine values (no depth gradient: training): v[8] needs no pair step.
-__device__ __forceinline__ float reduce_scatter9(const float (&v)[9], int lane)
+// ---- the backward's reduction, priced by instruction class -----------------------------------------------------------------
+// tools/probe/valu_rate.hip (cycles a wave64 instruction holds the SIMD, two or more waves offering work): v_mul / v_add / v_sub /
+// v_mov / v_fma with three distinct registers 2.5; DPP adds, v_cmp, v_cndmask with an SGPR-pair mask, v_min / v_max, any operand
+// from an SGPR 4.2; v_exp / v_rcp / v_readlane / v_permlane{16,32}_swap 8.2; v_cndmask reading VCC 23.5.  Summed over the loop
+// body of round 3 these prices give 416 cycles per executed (wave, splat) pair = the measured 242 us, of which 176 were the
+// reduction and its bookkeeping.  What changed against that version, all of it arithmetic-neutral (the same sums in the same
+// order within a quad; the order across rows differs):
+//  * the two in-quad pair steps use the DPP bank mask instead of two selects and one add: a lane's low two bits ARE its bank,
+//    so `v_add_f32_dpp d, x, x quad_perm:[1,0,3,2] bank_mask:0x5` + the same on y with bank_mask:0xa leaves the pair sum of x in
+//    the even lanes and of y in the odd ones: 2 instructions instead of 3 (the compiler cannot be made to emit partial-mask DPP
+//    adds from builtins, hence the asm block; it begins with the wait states a DPP read needs after a write of EXEC);
+//  * the step over bit 2 is a pair step too (two selects, one rotation) instead of an all-reduce of both registers;
+//  * the four rows are NOT summed per splat.  The row totals of four consecutive splats wait in four registers and are summed
+//    by a 4 x 4 transposition: v_permlane16_swap(m0, m1) + add, the same on (m2, m3), v_permlane32_swap of the two sums + add
+//    = 3 swaps and 3 adds per FOUR splats, leaving splat q's totals in row q -- exactly where the one atomic instruction per four
+//    splats wants them.  Before: 2 swaps, 2 adds, 2 moves and a select on VCC per splat.
+#define MOM_ROR(d, x, y, n, bank) "v_add_f32_dpp " d ", " x ", " y " row_ror:" n " row_mask:0xf bank_mask:" bank "\n"
+#define MOM_QP(d, x, y, perm) "v_add_f32_dpp " d ", " x ", " y " quad_perm:[" perm "] row_mask:0xf bank_mask:0xf\n"
+// Row totals of N values: afterwards, in every 16-lane row, the lane mom_row_slot() == k holds the row's total of v[k].
+// A DPP bank is a QUAD of the row (bank i = lanes 4 i .. 4 i + 3; tools/probe/swap_probe.hip), i.e. bits 2 and 3 of the lane
+// index, so the two pair steps that need no select are the ROTATIONS:
+//   row_ror:4 (the lane four below has the other value of bit 2):  a_i = pair (v[2i], v[2i+1]); quads 0, 2 (bank mask 0x5) keep and
+//              sum the first, quads 1, 3 (0xa) the second; a4 = v8 (+ v9 the same way)
+//   row_ror:8 (bit 3):  c0 = pair (a0, a1), c1 = pair (a2, a3): quads 0, 1 (0x3) the first, quads 2, 3 (0xc) the second.
+//              Quad q now holds v[q] (c0), v[4 + q] (c1) and v[8] (c2; with ten values v[8 + (q & 1)]), each lane the sum over its
+//              column (the four lanes of the row with its index modulo 4)
+//   quad_perm [1,0,3,2] (bit 0):  the last pair step, with selects: even lanes keep c0, odd lanes c1
+//   quad_perm [2,3,0,1] (bit 1):  an all-reduce
+//   select:    lanes with index 2 modulo 4 take c2
+// bit0 / sel2: the lanes with bit 0 set / with index 2 modulo 4, as 64-bit masks (loop invariants in scalar registers).
+template <int N>
+__device__ __forceinline__ float row_totals(const float (&v)[N], uint64_t bit0, uint64_t sel2)
 {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    const float a0 = dpp_pair<0xB1>(v[0], v[1], b0);
-    const float a1 = dpp_pair<0xB1>(v[2], v[3], b0);
-    const float a2 = dpp_pair<0xB1>(v[4], v[5], b0);
-    const float a3 = dpp_pair<0xB1>(v[6], v[7], b0);
-    const float a4 = dpp_add<0xB1, 0xF>(v[8]);
-    float c0 = dpp_pair<0x4E>(a0, a1, b1);
-    float c1 = dpp_pair<0x4E>(a2, a3, b1);
-    float c2 = dpp_add<0x4E, 0xF>(a4);                   // every lane of the quad: v[8] over the quad
-    c0 = dpp_add<0x124, 0xF>(c0); c1 = dpp_add<0x124, 0xF>(c1); c2 = dpp_add<0x124, 0xF>(c2);
-    c0 = dpp_add<0x128, 0xF>(c0); c1 = dpp_add<0x128, 0xF>(c1); c2 = dpp_add<0x128, 0xF>(c2);
-    const int k = lane & 15;
-    float m = k < 4 ? c0 : (k < 8 ? c1 : c2);
-    {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    static_assert(N == 9 || N == 10, "nine values (training) or ten (with a depth gradient)");
+    float a0, a1, a2, a3, a4, c0, c1, c2, out;
+    // s_nop 4: five wait states between a write of EXEC (the end of the divergent block in front) and a DPP instruction; it also
+    // covers the two a DPP read needs after a vector write of its source.  Inside the block every DPP source is written at
+    // least two instructions before it is read.
+#define MOM_ROW_TAIL \
+        MOM_ROR("%5", "%0", "%0", "8", "0x3") MOM_ROR("%6", "%2", "%2", "8", "0x3")                                               \
+        MOM_ROR("%5", "%1", "%1", "8", "0xc") MOM_ROR("%6", "%3", "%3", "8", "0xc")                                               \
+        MOM_ROR("%7", "%4", "%4", "8", "0xf")                                                                                      \
+        "v_cndmask_b32_e64 %1, %6, %5, %9\n"          /* send: odd lanes c0 */                                                    \
+        "v_cndmask_b32_e64 %0, %5, %6, %9\n"          /* keep: odd lanes c1 */                                                    \
+        MOM_QP("%7", "%7", "%7", "1,0,3,2")                                                                                        \
+        MOM_QP("%0", "%1", "%0", "1,0,3,2")                                                                                        \
+        "s_nop 0\n"                                                                                                                 \
+        MOM_QP("%7", "%7", "%7", "2,3,0,1")                                                                                        \
+        MOM_QP("%0", "%0", "%0", "2,3,0,1")                                                                                        \
+        "v_cndmask_b32_e64 %8, %0, %7, %10\n"
+    if constexpr (N == 10) {
+        asm volatile("s_nop 4\n"
+                     MOM_ROR("%0", "%11", "%11", "4", "0x5") MOM_ROR("%1", "%13", "%13", "4", "0x5") MOM_ROR("%2", "%15", "%15", "4", "0x5")
+                     MOM_ROR("%3", "%17", "%17", "4", "0x5") MOM_ROR("%4", "%19", "%19", "4", "0x5")
+                     MOM_ROR("%0", "%12", "%12", "4", "0xa") MOM_ROR("%1", "%14", "%14", "4", "0xa") MOM_ROR("%2", "%16", "%16", "4", "0xa")
+                     MOM_ROR("%3", "%18", "%18", "4", "0xa") MOM_ROR("%4", "%20", "%20", "4", "0xa")
+                     MOM_ROW_TAIL
+                     : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(out)
+                     : "s"(bit0), "s"(sel2), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                       "v"(v[8]), "v"(v[N - 1]));
+    } else {
+        asm volatile("s_nop 4\n"
+                     MOM_ROR("%0", "%11", "%11", "4", "0x5") MOM_ROR("%1", "%13", "%13", "4", "0x5") MOM_ROR("%2", "%15", "%15", "4", "0x5")
+                     MOM_ROR("%3", "%17", "%17", "4", "0x5") MOM_ROR("%4", "%19", "%19", "4", "0xf")
+                     MOM_ROR("%0", "%12", "%12", "4", "0xa") MOM_ROR("%1", "%14", "%14", "4", "0xa") MOM_ROR("%2", "%16", "%16", "4", "0xa")
+                     MOM_ROR("%3", "%18", "%18", "4", "0xa")
+                     MOM_ROW_TAIL
+                     : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(out)
+                     : "s"(bit0), "s"(sel2), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
+                       "v"(v[8]));
     }
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-        m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-    }
-    return m;
+#undef MOM_ROW_TAIL
+    return out;
+}
+// Which of the N values a lane holds after row_totals (>= N: none): quad q = bits 2-3 of the lane index; lanes 0 / 1 / 2 modulo 4
+// hold v[q] / v[4 + q] / v[8 + q].
+__device__ __forceinline__ int mom_row_slot(int lane)
+{
+    const int q = (lane >> 2) & 3, r = lane & 3;
+    return r == 3 ? 15 : 4 * r + q;
+}
+// The two halves of the 4 x 4 transposition that sums the rows of four splats (see above): swap_add16(a, b) leaves, in row
+// pairs (0,1) and (2,3), the pair's sum of a (even row) and of b (odd row); swap_add32 does the same with the wave's halves.
+__device__ __forceinline__ float swap_add16(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add32(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // DEPTH: a gradient arrives for the depth image too (dL_dpixel_depths != null; never in training).
@@ -405,11 +431,43 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         dp2 = dL_dpixels[2 * HW + pix];
         dpd = DEPTH ? dL_dpixel_depths[pix] : 0.f;
     }
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
     constexpr int kVals = DEPTH ? 10 : 9;
-    float pend = 0.f;                 // reduced records waiting for their atomic: row q of the wave holds the q-th
-    uint32_t pend_id = 0;
+    // row totals of up to four splats wait for the transposition that sums their rows (rows_transpose_sum); their positions in
+    // the round's staging area ride in two scalars, sixteen bits each
+    // The transposition is taken in steps as the splats arrive, so that two registers hold what waits: h0 the row totals of an
+    // even splat until its odd partner comes (swap_add16), h1 the first pair's sums until the second pair's come (swap_add32).
+    // The count is wave-uniform: the branches below are scalar.  (Four registers indexed by the count became four selects on
+    // VCC -- 23.5 cycles each -- or a web of moves at every merge.)
+    float h0 = 0.f, h1 = 0.f;
+    uint64_t jp = 0;                  // wave-uniform: the four splats' positions in the staging area, sixteen bits each
     int npend = 0;                    // wave-uniform
+    const uint32_t row_shift = (lane & 16);            // 0 / 16: which half of the word holds this row's splat
+    const uint64_t kBit0 = 0xAAAAAAAAAAAAAAAAull, kSel2 = 0x4444444444444444ull;     // lanes with bit 0 set / with index 2 modulo 4
+    const int vslot = mom_row_slot(lane);              // which of the kVals values this lane holds after row_totals
+    const uint64_t m_inside = __builtin_amdgcn_ballot_w64(inside);
+    // n_real: how many of the four rows hold a splat (the last group of a round is padded with zeros)
+    auto push = [&](float v, int j, int n_real) {
+        jp = (jp & ~(0xFFFFull << (npend << 4))) | ((uint64_t)(uint32_t)j << (npend << 4));
+        if (!(npend & 1)) {
+            h0 = v;
+            npend++;
+        } else {
+            const float t = swap_add16(h0, v);
+            if (npend == 1) {
+                h1 = t;
+                npend = 2;
+            } else {
+                const float tot = swap_add32(h1, t);                   // row q: the totals of the group's splat q
+                const uint32_t jq = (((lane & 32) ? (uint32_t)(jp >> 32) : (uint32_t)jp) >> row_shift) & 0xFFFFu;     // two 32-bit halves: no 64-bit vector shift
+                if (vslot < kVals && (lane >> 4) < n_real) atomicAdd(&gacc[(size_t)s_id[jq] * 12 + vslot], tot);
+                npend = 0;
+            }
+        }
+    };
+    auto drain = [&]() {
+        const int n_real = npend;
+        while (npend) push(0.f, 0, n_real);
+    };
     const float bg_dot_dpixel = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
     // splats behind the last contributor of every pixel of this wave need no work at all
     int wave_last = last_contributor;
@@ -418,6 +476,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);
 
     for (int i = 0; i < rounds; i++, toDo -= kRoundB) {
+        drain();                     // s_id is about to be overwritten: what waits goes out now
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < kRoundB / 256; sl++) {
@@ -442,7 +501,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
 #pragma unroll
         for (int c = 0; c < kRoundChunksB; c++) {
-          const int nk = min(64, n_w - 64 * c);
+          const int nk = __builtin_amdgcn_readfirstlane(min(64, n_w - 64 * c));      // a scalar loop bound (left to itself the compiler compared in the vector unit)
           for (int k = 0; k < nk; k++) {
             const int j = __builtin_amdgcn_readlane(list[c], k);
             contributor = (uint32_t)(toDo - j - 1);        // position of splat j in the tile's list, counted from 0
@@ -455,77 +514,66 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             const float G = mom_exp(power);
             const float alpha = fminf(0.99f, r1.w * G);
             const bool valid = inside && ((int)contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (!__any(valid)) continue;  // wave-uniform skip
+            // wave-uniform skip.  A ballot of each comparison is the comparison's own lane mask, and the masks combine in the
+            // scalar unit; a ballot (or __any) of the combined bool made the compiler rebuild a mask with v_cndmask + v_cmp.
+            if ((m_inside & __builtin_amdgcn_ballot_w64((int)contributor < last_contributor) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+                 __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f))) == 0) continue;
 
-            float g_mx = 0.f, g_my = 0.f, g_cx = 0.f, g_cy = 0.f, g_cw = 0.f, g_op = 0.f, g_c0 = 0.f, g_c1 = 0.f, g_c2 = 0.f,
-                  g_d = 0.f;
+            // Inside the divergent block: what only the contributing lanes may do (their recurrences) and the two factors every
+            // gradient carries, w = alpha T and a = opacity G dL/dalpha.  The products with them are formed outside, by all lanes
+            // (an instruction costs the same whatever EXEC is), so that three registers need a zero for the other lanes, not nine.
+            float w = 0.f, a = 0.f, g_op = 0.f;
             if (valid) {
                 const float4 r2 = s_rec[j * 3 + 2];
                 // the reference divides (T = T / (1 - alpha), backward.cu:502); the hardware reciprocal is within 1 ulp of that
                 // quotient and costs one instruction instead of ten
-                const float inv_1ma = __builtin_amdgcn_rcpf(1.f - alpha);      // shared by T and the background term below
+                const float one_m_alpha = 1.f - alpha;
+                const float inv_1ma = __builtin_amdgcn_rcpf(one_m_alpha);      // shared by T and the background term below
                 T = T * inv_1ma;
-                const float w = alpha * T;
-                float dL_dalpha = 0.f;
-                accum0 = last_alpha * lc0 + (1.f - last_alpha) * accum0;
-                lc0 = r2.x;
-                dL_dalpha += (r2.x - accum0) * dp0;
-                accum1 = last_alpha * lc1 + (1.f - last_alpha) * accum1;
-                lc1 = r2.y;
+                w = alpha * T;
+                // accum_k: the colour composited behind this splat (backward.cu:525-541 carries last_alpha and last_color into
+                // the next iteration and blends there; blending at the end of this one is the same arithmetic without the
+                // four copies per iteration)
+                float dL_dalpha = (r2.x - accum0) * dp0;
                 dL_dalpha += (r2.y - accum1) * dp1;
-                accum2 = last_alpha * lc2 + (1.f - last_alpha) * accum2;
-                lc2 = r2.z;
                 dL_dalpha += (r2.z - accum2) * dp2;
-                g_c0 = w * dp0;
-                g_c1 = w * dp1;
-                g_c2 = w * dp2;
+                accum0 = alpha * r2.x + one_m_alpha * accum0;
+                accum1 = alpha * r2.y + one_m_alpha * accum1;
+                accum2 = alpha * r2.z + one_m_alpha * accum2;
                 if (DEPTH) {
-                    accum_d = last_alpha * last_depth + (1.f - last_alpha) * accum_d;
-                    last_depth = r0.z;
                     dL_dalpha += (r0.z - accum_d) * dpd;
-                    g_d = w * dpd;
+                    accum_d = alpha * r0.z + one_m_alpha * accum_d;
                 }
                 dL_dalpha *= T;
-                last_alpha = alpha;
                 dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
                 // no derivative for the 0.99 cap, exactly as the reference (backward.cu:571).  With a = dL/dG * G:
                 //   dL/d mean   = -(W/2, H/2) * a * (conic (dx, dy))      dL/d conic = -1/2 * a * (dx^2, dx dy, dy^2)
                 // (backward.cu:573-586; the constant factors wait for the projection backward)
                 g_op = G * dL_dalpha;
-                const float a = r1.w * g_op;
-                const float ax = a * dx, ay = a * dy;
-                g_mx = ax * r1.x + ay * r1.y;
-                g_my = ay * r1.z + ax * r1.y;
-                g_cx = ax * dx;
-                g_cy = ax * dy;
-                g_cw = ay * dy;
+                a = r1.w * g_op;
             }
+            const float g_c0 = w * dp0, g_c1 = w * dp1, g_c2 = w * dp2, g_d = DEPTH ? w * dpd : 0.f;
+            const float ax = a * dx, ay = a * dy;
+            const float g_mx = ax * r1.x + ay * r1.y;
+            const float g_my = ay * r1.z + ax * r1.y;
+            const float g_cx = ax * dx, g_cy = ax * dy, g_cw = ay * dy;
             // (Letting the lanes of a splat that reaches only one or two pixels of the strip add their nine values themselves --
             // nine one-lane atomic instructions instead of the reduction and one nine-lane instruction -- was measured: 284 / 298 us
-            // for thresholds 1 / 2 against 274.  An atomic INSTRUCTION costs the CU more than the 33 vector instructions.)
+            // for thresholds 1 / 2 against 274.  An atomic INSTRUCTION costs the CU more than the reduction.)
             float v;
             if (DEPTH) {
                 const float gv[10] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2, g_d};
-                v = reduce_scatter10(gv, lane);
+                v = row_totals<10>(gv, kBit0, kSel2);
             } else {
                 const float gv[9] = {g_mx, g_my, g_cx, g_cy, g_cw, g_op, g_c0, g_c1, g_c2};
-                v = reduce_scatter9(gv, lane);
+                v = row_totals<9>(gv, kBit0, kSel2);
             }
-            // Every 16-lane row now holds the totals (lane k of a row: value k).  Row q keeps them for the q-th splat since the
-            // last flush, and ONE atomic instruction adds four splats' records.  Measured 272 against 274 us with one instruction
-            // per (wave, splat) pair, the step the same: the atomic instruction rate is not this kernel's limit either (it is
-            // bound by vector-instruction issue); kept because it is never slower and quarters the atomic instructions.
-            const bool mine = (lane >> 4) == npend;
-            pend = mine ? v : pend;
-            pend_id = mine ? s_id[j] : pend_id;
-            if (++npend == MOM_BWD_PEND) {
-                if ((lane & 15) < kVals && (lane >> 4) < MOM_BWD_PEND) atomicAdd(&gacc[(size_t)pend_id * 12 + (lane & 15)], pend);
-                npend = 0;
-            }
+            // every 16-lane row now holds ITS totals (lane k of a row: value k); the rows are summed four splats at a time
+            push(v, j, 4);
           }
         }
     }
-    if (npend && (lane & 15) < kVals && (lane >> 4) < npend) atomicAdd(&gacc[(size_t)pend_id * 12 + (lane & 15)], pend);
+    drain();
 }
 
 }  // namespace
@@ -575,7 +623,34 @@ __global__ void wave_sum_test_kernel(const float* in, float* out)
     const float t = wave_sum(in[blockIdx.x * 64 + threadIdx.x]);
     if (threadIdx.x == 17) out[blockIdx.x] = t;
 }
+// The compositing backward's reduction, exactly as the kernel composes it: in [waves][4 splats][N values][64 lanes] ->
+// out [waves][4][N] = the sums over the 64 lanes.
+template <int N>
+__global__ void row_reduce_test_kernel(const float* in, float* out)
+{
+    const int lane = threadIdx.x;
+    const float* base = in + (size_t)blockIdx.x * 4 * N * 64;
+    float rows[4];
+    asm volatile("s_nop 4");
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float v[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) v[k] = base[(q * N + k) * 64 + lane];
+        rows[q] = row_totals<N>(v, 0xAAAAAAAAAAAAAAAAull, 0x4444444444444444ull);
+    }
+    const float tot = swap_add32(swap_add16(rows[0], rows[1]), swap_add16(rows[2], rows[3]));
+    const int slot = mom_row_slot(lane);
+    if (slot < N) out[((size_t)blockIdx.x * 4 + (lane >> 4)) * N + slot] = tot;
+}
 }  // namespace
+extern "C" int mom_selftest_row_reduce(const float* in, float* out, int waves, int nvals, mom_stream_t s)
+{
+    if (nvals == 9) hipLaunchKernelGGL(row_reduce_test_kernel<9>, dim3(waves), dim3(64), 0, (hipStream_t)s, in, out);
+    else if (nvals == 10) hipLaunchKernelGGL(row_reduce_test_kernel<10>, dim3(waves), dim3(64), 0, (hipStream_t)s, in, out);
+    else return MOM_EINVAL;
+    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
 extern "C" int mom_selftest_wave_sum(const float* in, float* out, int waves, mom_stream_t s)
 {
     hipLaunchKernelGGL(wave_sum_test_kernel, dim3(waves), dim3(64), 0, (hipStream_t)s, in, out);

@@ -442,6 +442,9 @@ const char* mom_profile_name(int slot);
 /* Self test of the wave64 DPP reduction used by the render backward:
  * out[w] = sum(in[64w .. 64w+63]). */
 int mom_selftest_wave_sum(const float* in, float* out, int waves, mom_stream_t stream);
+/* Self test of the render backward's packed reduction (row-level DPP reduce-scatter of nvals = 9 or 10 values per lane, then the
+ * 4 x 4 row transposition over four splats): in [waves][4][nvals][64] -> out [waves][4][nvals] = the sums over the 64 lanes. */
+int mom_selftest_row_reduce(const float* in, float* out, int waves, int nvals, mom_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -152,6 +152,21 @@ def test_wave_sum_selftest():
     np.testing.assert_allclose(out.cpu().numpy(), x.view(37, 64).double().sum(1).cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("nvals", [9, 10])
+def test_row_reduce_selftest(nvals):
+    """The compositing backward's reduction as the kernel composes it (DPP reduce-scatter inside the rows with bank-masked
+    rotations, then the 4 x 4 transposition over four splats' rows): every one of the 4 x nvals sums of every wave, against
+    float64 sums; the inputs are distinct in every lane, so a wrong lane pairing cannot cancel."""
+    from hip_helpers import N
+    waves = 53
+    g = torch.Generator(device="cpu").manual_seed(nvals)
+    x = torch.randn(waves, 4, nvals, 64, generator=g).cuda()
+    out = torch.full((waves, 4, nvals), float("nan"), device="cuda")
+    N.check(N.lib().mom_selftest_row_reduce(x.data_ptr(), out.data_ptr(), waves, nvals, N.current_stream()), "selftest")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), x.double().sum(-1).cpu().numpy(), rtol=2e-6, atol=2e-6)
+
+
 @pytest.mark.parametrize("seed,P,W,H,kw", [
     (0, 2000, 128, 96, {}),
     (1, 5000, 256, 256, {}),                       # BASELINE configs[0] geometry: 5k Gaussians, 256x256
@@ -159,6 +174,7 @@ def test_wave_sum_selftest():
     (3, 64, 33, 17, {}),
     (4, 20000, 320, 180, dict(scale=(-5.0, -3.0))),
     (5, 100000, 480, 270, dict(scale=(-5.5, -3.5))),      # mid size: half of config 2's Gaussians at a quarter of its pixels
+    (6, 200000, 960, 540, dict(scale=(-5.5, -3.5))),      # BASELINE configs[1] at full size: 200 k Gaussians, 960x540 (oracle on 16 threads)
 ])
 @pytest.mark.parametrize("keep_all_tiles", [True, False])
 def test_forward_parity(seed, P, W, H, kw, keep_all_tiles):
@@ -225,9 +241,12 @@ def test_empty_and_all_culled():
     (10, 1500, 128, 96, {}),
     (11, 400, 70, 45, dict(scale=(-3.0, -1.0))),
     (12, 5000, 256, 256, dict(scale=(-5.0, -3.0))),
+    (13, 100000, 480, 270, dict(scale=(-5.5, -3.5))),
+    (14, 200000, 960, 540, dict(scale=(-5.5, -3.5))),     # BASELINE configs[1] at full size: all eight gradient tensors against the oracle
 ])
 def test_backward_parity(seed, P, W, H, kw):
     from hip_helpers import hip_forward, hip_backward
+    ro.set_threads(16 if P >= 100000 else 1)
     s = random_gaussians(P, seed=seed, W=W, H=H, **kw)
     rng = np.random.default_rng(seed)
     dcol = rng.normal(size=(3, H, W)).astype(np.float32)
