@@ -49,6 +49,7 @@ struct BwdArgs {
     const int* radii;
     const uchar4* clamped;
     const float* gacc;
+    const float4* rec;           // the forward's per-Gaussian record: rec[3 i + 1] = {conic.x, conic.y, conic.z, opacity}
     float scale_modifier, tan_fovx, tan_fovy, h_x, h_y;
     int colors_from_sh;
     float *dmeans2D, *dcolors, *dopacity, *dmeans3D, *dcov3D, *dsh, *dsh_rest, *dscales, *drot;
@@ -81,7 +82,15 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     float ga[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) ga[i] = vis ? a.gacc[(size_t)idx * 12 + i] : 0.f;
-    // the compositing backward leaves raw sums (raster_render.hip): d(pixel)/d(ndc) with the sign for the mean, -1/2 for the conic
+    // the compositing backward leaves raw sums (raster_render.hip): for the mean, S_x = sum a dx and S_y = sum a dy -- the conic
+    // matrix that turns them into dL/d mean (backward.cu:573-579: a (conic (dx, dy))) is the Gaussian's own, so it is applied here,
+    // once per Gaussian, instead of there, once per (pixel, splat) pair -- then d(pixel)/d(ndc) with the sign; -1/2 for the conic
+    if (vis) {
+        const float4 co = a.rec[3 * (size_t)idx + 1];
+        const float sx = ga[0], sy = ga[1];
+        ga[0] = sx * co.x + sy * co.y;
+        ga[1] = sy * co.z + sx * co.y;
+    }
     ga[0] *= -0.5f * (float)a.W;
     ga[1] *= -0.5f * (float)a.H;
     ga[2] *= -0.5f;
@@ -333,7 +342,7 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
     b.means3D = a->means3D; b.shs = a->shs; b.shs_rest = a->shs_rest; b.scales = a->scales; b.rotations = a->rotations;
     b.cov3D = a->cov3D_precomp ? a->cov3D_precomp : g.cov3D;
     b.view = a->viewmatrix; b.proj = a->projmatrix; b.cam = a->campos;
-    b.radii = radii; b.clamped = g.clamped; b.gacc = g.gacc;
+    b.radii = radii; b.clamped = g.clamped; b.gacc = g.gacc; b.rec = g.rec;
     b.scale_modifier = a->scale_modifier; b.tan_fovx = a->tan_fovx; b.tan_fovy = a->tan_fovy;
     b.h_y = a->H / (2.0f * a->tan_fovy);
     b.h_x = a->W / (2.0f * a->tan_fovx);

@@ -323,9 +323,12 @@ __device__ __forceinline__ float row_totals(const float (&v)[N], uint64_t bit0, 
 {
     static_assert(N == 9 || N == 10, "nine values (training) or ten (with a depth gradient)");
     float a0, a1, a2, a3, a4, c0, c1, c2, out;
-    // s_nop 4: five wait states between a write of EXEC (the end of the divergent block in front) and a DPP instruction; it also
-    // covers the two a DPP read needs after a vector write of its source.  Inside the block every DPP source is written at
-    // least two instructions before it is read.
+    // s_nop 1: the two wait states a DPP read needs after a vector write of its source (what the compiler's hazard recogniser
+    // would insert; it does not look inside an asm statement).  EXEC is only ever written by scalar instructions in front of this
+    // block (s_or_b64 at the end of the divergent block), which is no DPP hazard: that one -- five wait states -- is for VECTOR
+    // writes of EXEC (v_cmpx), and the kernel has none (tests/test_isa.py checks).  Inside the block every DPP source is written
+    // at least two instructions before it is read.
+#define MOM_ROW_NOP "s_nop 1\n"
 #define MOM_ROW_TAIL \
         MOM_ROR("%5", "%0", "%0", "8", "0x3") MOM_ROR("%6", "%2", "%2", "8", "0x3")                                               \
         MOM_ROR("%5", "%1", "%1", "8", "0xc") MOM_ROR("%6", "%3", "%3", "8", "0xc")                                               \
@@ -339,7 +342,7 @@ __device__ __forceinline__ float row_totals(const float (&v)[N], uint64_t bit0, 
         MOM_QP("%0", "%0", "%0", "2,3,0,1")                                                                                        \
         "v_cndmask_b32_e64 %8, %0, %7, %10\n"
     if constexpr (N == 10) {
-        asm volatile("s_nop 4\n"
+        asm volatile(MOM_ROW_NOP
                      MOM_ROR("%0", "%11", "%11", "4", "0x5") MOM_ROR("%1", "%13", "%13", "4", "0x5") MOM_ROR("%2", "%15", "%15", "4", "0x5")
                      MOM_ROR("%3", "%17", "%17", "4", "0x5") MOM_ROR("%4", "%19", "%19", "4", "0x5")
                      MOM_ROR("%0", "%12", "%12", "4", "0xa") MOM_ROR("%1", "%14", "%14", "4", "0xa") MOM_ROR("%2", "%16", "%16", "4", "0xa")
@@ -349,7 +352,7 @@ __device__ __forceinline__ float row_totals(const float (&v)[N], uint64_t bit0, 
                      : "s"(bit0), "s"(sel2), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]),
                        "v"(v[8]), "v"(v[N - 1]));
     } else {
-        asm volatile("s_nop 4\n"
+        asm volatile(MOM_ROW_NOP
                      MOM_ROR("%0", "%11", "%11", "4", "0x5") MOM_ROR("%1", "%13", "%13", "4", "0x5") MOM_ROR("%2", "%15", "%15", "4", "0x5")
                      MOM_ROR("%3", "%17", "%17", "4", "0x5") MOM_ROR("%4", "%19", "%19", "4", "0xf")
                      MOM_ROR("%0", "%12", "%12", "4", "0xa") MOM_ROR("%1", "%14", "%14", "4", "0xa") MOM_ROR("%2", "%16", "%16", "4", "0xa")
@@ -371,6 +374,9 @@ __device__ __forceinline__ int mom_row_slot(int lane)
 }
 // The two halves of the 4 x 4 transposition that sums the rows of four splats (see above): swap_add16(a, b) leaves, in row
 // pairs (0,1) and (2,3), the pair's sum of a (even row) and of b (odd row); swap_add32 does the same with the wave's halves.
+// (In-place asm forms of the two -- swap, add, and the waiting registers updated by read-modify-write statements only -- were
+// tried to lose the two copies per iteration the register allocator makes around them: it made more, 1391 / 1429 vector
+// instructions in the kernel against 1374.)
 __device__ __forceinline__ float swap_add16(float a, float b)
 {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -383,9 +389,11 @@ __device__ __forceinline__ float swap_add32(float a, float b)
 }
 
 // DEPTH: a gradient arrives for the depth image too (dL_dpixel_depths != null; never in training).
-// The record this kernel leaves per Gaussian (gacc, 12 floats) holds RAW sums: slots 0-1 the mean's, without the factors
-// -W/2 and -H/2 of d(pixel)/d(ndc) and the sign; slots 2-4 the conic's, without their -1/2.  The projection backward
-// (raster_backward.hip) applies those constants once per Gaussian instead of this loop once per (pixel, splat) pair.
+// The record this kernel leaves per Gaussian (gacc, 12 floats) holds RAW sums: slots 0-1 sum a dx and sum a dy (a = opacity G
+// dL/dalpha), i.e. the mean's gradient before the splat's conic matrix, the factors -W/2 and -H/2 of d(pixel)/d(ndc) and the sign
+// are applied; slots 2-4 the conic's, without their -1/2.  The projection backward (raster_backward.hip) applies the matrix and
+// those constants once per Gaussian instead of this loop once per (pixel, splat) pair.  The record stays linear in dL/dpixel, so
+// the ranks of a tile-row shard still sum it (mom_raster_backward_render in include/mom4d.h).
 template <bool DEPTH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_MIN, MOM_BWD_WAVES)))   // LDS (31 KB) allows 5 workgroups per CU
 render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
@@ -506,8 +514,13 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             const int j = __builtin_amdgcn_readlane(list[c], k);
             contributor = (uint32_t)(toDo - j - 1);        // position of splat j in the tile's list, counted from 0
             if ((int)contributor >= wave_last) continue;   // wave-uniform: occluded for all 64 pixels
-            const float4 r0 = s_rec[j * 3 + 0];
-            const float4 r1 = s_rec[j * 3 + 1];
+            // the record's LDS address, formed ONCE in a vector register (the compiler otherwise re-materialises it from the
+            // scalar in front of every read: three moves per iteration on a kernel bound by instruction issue)
+            uint32_t rec_off = (uint32_t)j * 48u;
+            asm volatile("" : "+v"(rec_off));
+            const char* rec_j = reinterpret_cast<const char*>(s_rec) + rec_off;
+            const float4 r0 = *reinterpret_cast<const float4*>(rec_j);
+            const float4 r1 = *reinterpret_cast<const float4*>(rec_j + 16);
             float dx, dy;
             const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
             if (!__any(!(power < r0.w))) continue;         // no lane of the wave can reach 1/255 (power_bound)
@@ -522,9 +535,21 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             // Inside the divergent block: what only the contributing lanes may do (their recurrences) and the two factors every
             // gradient carries, w = alpha T and a = opacity G dL/dalpha.  The products with them are formed outside, by all lanes
             // (an instruction costs the same whatever EXEC is), so that three registers need a zero for the other lanes, not nine.
+#ifndef MOM_BWD_NOBRANCH
+#define MOM_BWD_NOBRANCH 1            // 207 against 211 us (same box, alternating); 0 keeps the divergent block for measurement
+#endif
+#if MOM_BWD_NOBRANCH
+            // no divergent block: with alpha and G forced to zero in the lanes that do not contribute, the recurrences below are
+            // identities there (T / (1 - 0), 0 c + 1 accum) and both gradient factors vanish
+            const float alpha_in = alpha, G_in = G;
+            float w, a, g_op;
+            {
+                const float alpha = valid ? alpha_in : 0.f, G = valid ? G_in : 0.f;
+#else
             float w = 0.f, a = 0.f, g_op = 0.f;
             if (valid) {
-                const float4 r2 = s_rec[j * 3 + 2];
+#endif
+                const float4 r2 = *reinterpret_cast<const float4*>(rec_j + 32);
                 // the reference divides (T = T / (1 - alpha), backward.cu:502); the hardware reciprocal is within 1 ulp of that
                 // quotient and costs one instruction instead of ten
                 const float one_m_alpha = 1.f - alpha;
@@ -537,12 +562,13 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 float dL_dalpha = (r2.x - accum0) * dp0;
                 dL_dalpha += (r2.y - accum1) * dp1;
                 dL_dalpha += (r2.z - accum2) * dp2;
-                accum0 = alpha * r2.x + one_m_alpha * accum0;
-                accum1 = alpha * r2.y + one_m_alpha * accum1;
-                accum2 = alpha * r2.z + one_m_alpha * accum2;
+                // (spelled as scale-then-fma so that the update happens in the accumulator's own register: no copy)
+                accum0 = __builtin_fmaf(alpha, r2.x, one_m_alpha * accum0);
+                accum1 = __builtin_fmaf(alpha, r2.y, one_m_alpha * accum1);
+                accum2 = __builtin_fmaf(alpha, r2.z, one_m_alpha * accum2);
                 if (DEPTH) {
                     dL_dalpha += (r0.z - accum_d) * dpd;
-                    accum_d = alpha * r0.z + one_m_alpha * accum_d;
+                    accum_d = __builtin_fmaf(alpha, r0.z, one_m_alpha * accum_d);
                 }
                 dL_dalpha *= T;
                 dL_dalpha += (-T_final * inv_1ma) * bg_dot_dpixel;
@@ -553,9 +579,10 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 a = r1.w * g_op;
             }
             const float g_c0 = w * dp0, g_c1 = w * dp1, g_c2 = w * dp2, g_d = DEPTH ? w * dpd : 0.f;
+            // the mean's gradient is conic (ax, ay): the conic belongs to the splat, not the pixel, so the sums of ax and ay go
+            // into the record and the projection backward applies the matrix once per Gaussian (four instructions less here)
             const float ax = a * dx, ay = a * dy;
-            const float g_mx = ax * r1.x + ay * r1.y;
-            const float g_my = ay * r1.z + ax * r1.y;
+            const float g_mx = ax, g_my = ay;
             const float g_cx = ax * dx, g_cy = ax * dy, g_cw = ay * dy;
             // (Letting the lanes of a splat that reaches only one or two pixels of the strip add their nine values themselves --
             // nine one-lane atomic instructions instead of the reduction and one nine-lane instruction -- was measured: 284 / 298 us
@@ -631,7 +658,6 @@ __global__ void row_reduce_test_kernel(const float* in, float* out)
     const int lane = threadIdx.x;
     const float* base = in + (size_t)blockIdx.x * 4 * N * 64;
     float rows[4];
-    asm volatile("s_nop 4");
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         float v[N];

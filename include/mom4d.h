@@ -177,8 +177,9 @@ int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, vo
 
 /* The two halves of mom_raster_backward, for callers that must exchange between them (tile-row shard):
  * _render runs the compositing backward over this rank's tile rows and leaves, in the geometry scratch at
- * mom_raster_layout().geom_gacc, one record of 12 floats per Gaussian: the sums over the local pixels of
- * dL/d{mean2D.x, mean2D.y, conic.x, conic.y, conic.z, opacity, r, g, b, depth} and two zeros.  The
+ * mom_raster_layout().geom_gacc, one record of 12 floats per Gaussian: the sums over the local pixels of the raw terms of
+ * dL/d{mean2D.x, mean2D.y (before the Gaussian's conic matrix and the pixel-to-NDC factors are applied), conic.x, conic.y, conic.z
+ * (before their -1/2), opacity, r, g, b, depth} and two zeros.  The
  * projection backward is linear in that record, so ranks sum it (an all-reduce of 48 bytes per Gaussian) and
  * then each runs _geometry, which yields identical parameter gradients everywhere. */
 int mom_raster_backward_render(const MomRasterArgs* a, void* geom, void* binning, size_t capacity, void* image,

@@ -56,3 +56,14 @@ def test_compositing_kernels_do_not_spill(kernels):
         assert ks
         for v in ks:
             assert not any(i.startswith("scratch_") for i in v), pat
+
+
+def test_render_bwd_has_no_vector_write_of_exec_and_no_select_on_vcc_in_its_loop(kernels):
+    """csrc/raster_render.hip, row_totals: the asm block of DPP adds begins with the two wait states of the VGPR hazard only; the
+    five-wait-state DPP hazard is for VECTOR writes of EXEC (v_cmpx*), which the kernel must therefore not contain.  And the
+    loop must stay free of v_cndmask_b32_e32 -- the VOP2 form reads VCC and costs 23.5 cycles (tools/probe/valu_rate.hip) --
+    beyond the handful in the prologue (the __shfl_xor butterfly of wave_last)."""
+    for k, v in kernels.items():
+        if "render_bwd_kernel" in k:
+            assert not any(i.startswith("v_cmpx") for i in v), k
+            assert sum(1 for i in v if i == "v_cndmask_b32_e32") <= 10, k
