@@ -166,7 +166,6 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    bool done = !inside;
 
     uint2 range = ranges[tile];
     if (range.y > capacity) range.y = capacity;
@@ -192,9 +191,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+    uint64_t live = __builtin_amdgcn_ballot_w64(inside);      // wave-uniform: the lanes still compositing (= !done, as a mask)
 
     for (int i = 0; i < rounds; i++, toDo -= kRound) {
-        if (__syncthreads_count(done) == 256) break;
+        if (__syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256) break;
 #pragma unroll
         for (int sl = 0; sl < kRound / 256; sl++) {
             const int slot = threadIdx.x + 256 * sl, progress = i * kRound + slot;
@@ -216,25 +216,32 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
 #pragma unroll
         for (int c = 0; c < kRoundChunks; c++) {
-            const int nk = min(64, n_w - 64 * c);
+            const int nk = __builtin_amdgcn_readfirstlane(min(64, n_w - 64 * c));
             for (int k = 0; k < nk; k++) {
-                if (__all(done)) break;
+                // The wave-uniform tests below work on lane MASKS built from ballots of single comparisons, which are the
+                // comparisons' own results and combine in the scalar unit; __all / __any of a combined bool made the compiler
+                // rebuild a mask in the vector unit (v_cndmask + v_cmp) -- six of the forty vector instructions of an iteration
+                // went into that and into re-materialising the record's address (the same finding as in render_bwd below).
+                if (live == 0) break;                       // every pixel of the strip is saturated (or outside the image)
                 const int j = __builtin_amdgcn_readlane(list[c], k);
-                const float4 r0 = s_rec[j * 3 + 0];
-                const float4 r1 = s_rec[j * 3 + 1];
+                uint32_t rec_off = (uint32_t)j * 48u;
+                asm volatile("" : "+v"(rec_off));          // the record's LDS address, formed once
+                const char* rec_j = reinterpret_cast<const char*>(s_rec) + rec_off;
+                const float4 r0 = *reinterpret_cast<const float4*>(rec_j);
+                const float4 r1 = *reinterpret_cast<const float4*>(rec_j + 16);
                 float dx, dy;
                 const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
-                bool valid = !done && !(power < r0.w) && !(power > 0.0f);
-                if (!__any(valid)) continue;                // no lane of the wave can reach 1/255 (power_bound)
+                uint64_t vm = live & __builtin_amdgcn_ballot_w64(!(power < r0.w)) & __builtin_amdgcn_ballot_w64(!(power > 0.0f));
+                if (vm == 0) continue;                      // no lane of the wave can reach 1/255 (power_bound)
                 const float alpha = fminf(0.99f, r1.w * mom_exp(power));
-                valid = valid && !(alpha < 1.0f / 255.0f);
                 const float test_T = T * (1.f - alpha);
-                if (valid && test_T < 0.0001f) {
-                    done = true;
-                    valid = false;
-                }
+                vm &= __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+                const uint64_t sat = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+                live &= ~(vm & sat);                        // the lanes this splat would saturate stop here, without it (forward.cu:340-345)
+                vm &= ~sat;
+                const bool valid = __builtin_amdgcn_inverse_ballot_w64(vm);         // the mask IS the condition: no vector compare
                 if (valid) {
-                    const float4 r2 = s_rec[j * 3 + 2];
+                    const float4 r2 = *reinterpret_cast<const float4*>(rec_j + 32);
                     const float w = alpha * T;
                     C0 += r2.x * w;
                     C1 += r2.y * w;
@@ -529,8 +536,9 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             const bool valid = inside && ((int)contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             // wave-uniform skip.  A ballot of each comparison is the comparison's own lane mask, and the masks combine in the
             // scalar unit; a ballot (or __any) of the combined bool made the compiler rebuild a mask with v_cndmask + v_cmp.
-            if ((m_inside & __builtin_amdgcn_ballot_w64((int)contributor < last_contributor) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
-                 __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f))) == 0) continue;
+            const uint64_t vmask = m_inside & __builtin_amdgcn_ballot_w64((int)contributor < last_contributor) &
+                                   __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+            if (vmask == 0) continue;
 
             // Inside the divergent block: what only the contributing lanes may do (their recurrences) and the two factors every
             // gradient carries, w = alpha T and a = opacity G dL/dalpha.  The products with them are formed outside, by all lanes
@@ -544,7 +552,11 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             const float alpha_in = alpha, G_in = G;
             float w, a, g_op;
             {
-                const float alpha = valid ? alpha_in : 0.f, G = valid ? G_in : 0.f;
+                // (asm: the selects take the lane mask the skip test above already holds in a scalar pair.  The compiler's own form
+                // reads VCC -- 23.5 cycles in tools/probe/valu_rate.hip's stream of nothing but such selects, though in this loop
+                // the two forms measured the same, 204.5 against 205 us)
+                float alpha, G;
+                asm("v_cndmask_b32_e64 %0, 0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4" : "=&v"(alpha), "=v"(G) : "v"(alpha_in), "v"(G_in), "s"(vmask));
 #else
             float w = 0.f, a = 0.f, g_op = 0.f;
             if (valid) {

@@ -23,7 +23,11 @@ b = fs.binning[(-fs.binning.data_ptr()) % 256:].cpu().numpy()
 R = int(fs.nr_host[0])
 pl = b[lay.bin_point_list:lay.bin_point_list + R * 4].view(np.uint32)
 print("R", R)
+ncontrib = img[lay.img_n_contrib:lay.img_n_contrib + W * H * 4].view(np.uint32).reshape(H, W)
 tot = {k: 0 for k in ("inst", "px_valid", "s16x4", "s8x4", "s8x8", "s4x4")}
+# the backward's executed (wave, splat) pairs -- a 16x4 strip with at least one lane that passes every test, occlusion included
+# (position in the list < the pixel's last contributor) -- by the number of such lanes
+lane_hist = np.zeros(65, np.int64)
 rng = np.random.default_rng(0)
 for t in rng.choice(tiles, 200, replace=False):
     a, e = ranges[t]
@@ -42,9 +46,21 @@ for t in rng.choice(tiles, 200, replace=False):
     tot["s8x4"] += int(v.reshape(n, 4, 4, 2, 8).any(axis=(2, 4)).sum())
     tot["s8x8"] += int(v.reshape(n, 2, 8, 2, 8).any(axis=(2, 4)).sum())
     tot["s4x4"] += int(v.reshape(n, 4, 4, 4, 4).any(axis=(2, 4)).sum())
+    inside = ((ty * 16 + np.arange(16))[:, None] < H) & ((tx * 16 + np.arange(16))[None, :] < W)
+    nc = np.zeros((16, 16), np.int64)
+    ys, xs = np.nonzero(inside)
+    nc[ys, xs] = ncontrib[ty * 16 + ys, tx * 16 + xs]
+    vb = v & (np.arange(n)[:, None, None] < nc[None])             # what render_bwd's `valid` is
+    per_strip = vb.reshape(n, 4, 4, 16).sum(axis=(2, 3)).reshape(-1)
+    lane_hist += np.bincount(per_strip, minlength=65)
 print(tot)
 i = tot["inst"]
 print("valid pixels per instance", tot["px_valid"] / i)
 for k, lanes in (("s16x4", 64), ("s8x4", 32), ("s8x8", 64), ("s4x4", 16)):
     print(k, "footprint-pairs per instance %.2f" % (tot[k] / i), "lane-slots per instance %.1f" % (tot[k] / i * lanes),
           "useful %.3f" % (tot["px_valid"] / (tot[k] * lanes)))
+executed = int(lane_hist[1:].sum())
+print("render_bwd: executed (wave, splat) pairs per instance %.2f; valid lanes per executed pair: mean %.1f of 64" %
+      (executed / i, float((lane_hist * np.arange(65)).sum()) / executed))
+edges = [(1, 1), (2, 4), (5, 8), (9, 16), (17, 32), (33, 48), (49, 64)]
+print("  share of executed pairs by valid lanes: " + ", ".join(f"{a}-{b}: {lane_hist[a:b + 1].sum() / executed:.3f}" for a, b in edges))
