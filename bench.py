@@ -132,28 +132,27 @@ def measured_traffic(kernel, cfg):
     return k["traffic_bytes"], {"traffic_source": name, "traffic_collected_on": doc.get("lib_version")}
 
 
-def executed_valu(kernel, cfg):
-    """Vector instructions a launch of `kernel` EXECUTES and the share of the SIMDs' issue cycles they take, from the committed SQ
-    counter summary (profiles/*_sq.json) -- same staleness rule as the traffic."""
+def sq_counters(kernel, cfg):
+    """(entry, note): that kernel's means from the committed SQ / GRBM counter summary (profiles/*_sq.json: SQ_INSTS_VALU per
+    launch, the clock measured in that pass, the issue fraction inside that pass) -- reported as live only while the running
+    library is the build the counters were collected on (same rule as the traffic)."""
     doc, name, fresh = _newest_profile("_sq.json", cfg)
     if doc is None:
-        return None
+        return None, {"sq_source": None}
     k = doc.get("kernels", {}).get(kernel + "_kernel")
-    if not k:
-        return None
-    out = {"wave_insts_per_launch": k.get("SQ_INSTS_VALU"), "issue_frac": k.get("valu_issue_frac"), "source": name,
-           "what": "SQ_INSTS_VALU per launch and 4 x that / SIMD busy cycles, rocprofv3 --pmc pass of the same command"}
-    if not fresh:
-        out["stale"] = True
-        out["collected_on"] = doc.get("lib_version")
-    return out
+    note = {"sq_source": name, "sq_collected_on": doc.get("lib_version")}
+    if not k or not fresh:
+        note["sq_stale"] = True
+        return None, note
+    return k, note
 
 
-def step_bytes(P, R, npix, lambda_dssim=0.0, deform_floats=2_904_970):
-    """algorithmic bytes of one fine-stage step, fp32: B = P*2751 + R*172 + N_pix*84 (+240 with SSIM)
-    + B_def, B_def = live deformation floats * 28 (Adam) + 2 * 11.55 MB (plane-gradient RMW) + 11.55 MB (regulariser read)."""
-    planes = 2_887_680 * 4
-    return P * 2751 + R * 172 + npix * (84 + (240 if lambda_dssim else 0)) + deform_floats * 28 + 3 * planes
+def step_bytes(P, R, npix, lambda_dssim=0.0):
+    return importlib.import_module("iclr2025_3d-mom_amd.profiling").step_bytes(P, R, npix, lambda_dssim)
+
+
+def step_roofline(P, R_binned, R_ref, npix, seconds_per_step, lambda_dssim=0.0):
+    return importlib.import_module("iclr2025_3d-mom_amd.profiling").step_roofline(P, R_binned, R_ref, npix, seconds_per_step, lambda_dssim)
 
 
 def metric_name():
@@ -230,9 +229,17 @@ def render_fps(scene, g, pp, background, delta_scale, passes=2):
     return res
 
 
-def side_leg(cfg, dev, path, steps, warmup, sync_mode="async"):
+def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=False, with_densify=False):
     """One more reading of the metric on a fresh model: `path` fused | autograd on workload `cfg`, `steps` timed steps after
-    `warmup`, with the step-level roofline on the reference's instance count (sampled on eight cameras with keep_all_tiles)."""
+    `warmup`, with the step-level roofline on the instances the steps process and, beside it, on the reference's count (both
+    sampled on eight cameras in exact mode).
+    keep_all_tiles: the timed steps bin every tile of every splat's rectangle like the reference (rasterizer_impl.cu:70-111), so
+    that num_rendered, the tile lists and n_contrib are the reference's bit for bit -- the configuration whose integer indices
+    tests/test_raster_gpu.py compares with the oracle.
+    sync_mode "exact" (autograd path): the drop-in's DEFAULT -- every forward waits for its own instance count, as the
+    reference's cudaMemcpy at rasterizer_impl.cu:282 does; this is what an unchanged train_4DGS.py gets.
+    with_densify: consecutive iteration numbers, so that the trainer's own densify / prune round (every 100 iterations,
+    train_4DGS.py:264-290) falls inside the timed window."""
     import torch
     DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
     scene, g, trainer, op = build_state(cfg, dev, fused=(path == "fused"))
@@ -241,36 +248,46 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async"):
         c.device_tensors(dev)
     sample = cams[::max(1, len(cams) // 8)][:8]
     DGR.set_sync_mode("exact")
-    counts = []
-    try:
+    counts = {True: [], False: []}
+
+    def set_keep(flag):
         if trainer.fused is not None:
-            trainer.fused.keep_all_tiles = True
-        else:
-            DGR.set_keep_all_tiles(True)
-        for i, c in enumerate(sample):
-            if trainer.fused is not None:
-                trainer.fused.exact_next()
-            trainer.step(5001 + i, cams=[c])
-            torch.cuda.synchronize()
-            counts.append(int(trainer.fused.nr_host[0]) if trainer.fused is not None else DGR.last_num_rendered())
-    finally:
-        if trainer.fused is not None:
-            trainer.fused.keep_all_tiles = False
+            trainer.fused.keep_all_tiles = flag
             trainer.fused.exact_next()
         else:
-            DGR.set_keep_all_tiles(False)
-    r_mean = sum(counts) / len(counts)
+            DGR.set_keep_all_tiles(flag)
+
+    try:
+        for keep in (True, False):
+            set_keep(keep)
+            for i, c in enumerate(sample):
+                if trainer.fused is not None:
+                    trainer.fused.exact_next()
+                trainer.step(5001 + i, cams=[c])
+                torch.cuda.synchronize()
+                counts[keep].append(int(trainer.fused.nr_host[0]) if trainer.fused is not None else DGR.last_num_rendered())
+    finally:
+        set_keep(keep_all_tiles)
+    r_ref = sum(counts[True]) / len(counts[True])
+    r_binned = sum(counts[False]) / len(counts[False])
+    r_proc = r_ref if keep_all_tiles else r_binned
+    it0 = 5040 if with_densify else 5011        # with_densify: iteration 5100 falls inside the timed window
+
+    def it(i):
+        return it0 + (i if with_densify else i % 80)
+
+    p_start = int(g.get_xyz.shape[0])
     try:
         if trainer.fused is None and sync_mode == "async":
-            DGR.set_sync_mode("async", capacity_hint=int(max(counts) * 1.6) + 65536)
+            DGR.set_sync_mode("async", capacity_hint=int(max(counts[keep_all_tiles]) * 1.6) + 65536)
         for i in range(warmup):
-            trainer.step(5011 + i % 80, cams=[cams[i % len(cams)]])
+            trainer.step(it(i), cams=[cams[i % len(cams)]])
         trainer.drain()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = None
         for i in range(steps):
-            loss = trainer.step(5011 + (warmup + i) % 80, cams=[cams[(warmup + i) % len(cams)]])
+            loss = trainer.step(it(warmup + i), cams=[cams[(warmup + i) % len(cams)]])
         trainer.drain()
         if hasattr(loss, "tensor"):
             loss = loss.tensor()
@@ -278,14 +295,18 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async"):
         dt = time.perf_counter() - t0
     finally:
         DGR.set_sync_mode("exact")
+        set_keep(False)
     assert torch.isfinite(loss).all(), f"loss is not finite ({cfg['name']}, {path})"
-    b = step_bytes(cfg["P"], r_mean, cfg["W"] * cfg["H"])
     out = {"workload": cfg["name"], "step_path": path, "value": steps / dt, "unit": "steps/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": 1e3 * dt / steps, "instances_R_mean": r_mean, "final_loss": float(loss),
+           "ms_per_step": 1e3 * dt / steps, "instances_R_mean": r_ref, "instances_binned_mean": r_binned,
+           "keep_all_tiles": bool(keep_all_tiles), "final_loss": float(loss),
            "time_resolution": cfg["time_res"], "steps_replayed_after_overflow": int(trainer.replayed),
            "host_sync": "device-gated async (fused step)" if path == "fused" else sync_mode,
-           "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": b, "achieved": b * steps / dt / 1e9, "peak": 8000.0,
-                             "unit": "GB/s", "frac": b * steps / dt / 1e9 / 8000.0}}
+           "roofline_step": step_roofline(cfg["P"], r_proc, r_ref, cfg["W"] * cfg["H"], dt / steps)}
+    if with_densify:
+        out["densify_in_window"] = {"iterations": [it(warmup), it(warmup + steps - 1)], "gaussians_before": p_start,
+                                    "gaussians_after": int(g.get_xyz.shape[0]),
+                                    "what": "the trainer's own round at iteration 5100 (train_4DGS.py:264-290 gates) is inside the timed window"}
     del scene, g, trainer
     import gc
     gc.collect()
@@ -452,19 +473,15 @@ def main():
         dts, loss_s, r_mean = timed(nxt, a.steady_steps)
         nxt += a.steady_steps
         assert torch.isfinite(loss_s).all(), "loss is not finite (steady leg)"
-        b = step_bytes(cfg["P"], r_mean, npix, a.lambda_dssim)
         steady = {"value": a.steady_steps * scale / dts, "unit": "steps/s", "steps": a.steady_steps, "warmup": a.steady_warmup,
                   "ms_per_step": 1e3 * dts / a.steady_steps, "instances_R_mean": r_mean, "instances_binned_mean": binned_mean[0],
-                  "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": b, "achieved": b * a.steady_steps / dts / 1e9,
-                                    "peak": 8000.0, "unit": "GB/s", "frac": b * a.steady_steps / dts / 1e9 / 8000.0,
-                                    "formula": "P*2751 + R*172 + Npix*84 + 116 MB (SURVEY 8d); per GPU"}}
+                  "roofline_step": step_roofline(cfg["P"], binned_mean[0] or r_mean, r_mean, npix, dts / a.steady_steps, a.lambda_dssim)}
     for i in range(a.warmup):
         one(nxt + i)
     nxt += a.warmup
     dt, loss, r_mean = timed(nxt, a.steps, profile_kernel=a.roofline_kernel)
     nxt += a.steps
     assert torch.isfinite(loss).all(), "loss is not finite"
-    b_step = step_bytes(cfg["P"], r_mean, npix, a.lambda_dssim)
     out = {
         "metric": metric_name(), "value": a.steps * scale / dt,
         "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -479,20 +496,17 @@ def main():
                    "ranks_seen": ranks_seen, "host_sync": a.sync_mode, "final_loss": float(loss), "densify_in_window": bool(a.with_densify),
                    "gaussians_at_end": int(g.get_xyz.shape[0]), "steps_replayed_after_overflow": int(trainer.replayed),
                    "inputs": "camera matrices and ground-truth images pre-staged in HBM before the timed region"},
-        "roofline_step": {"bound": "hbm", "algorithmic_bytes_per_step": b_step, "achieved": b_step * a.steps / dt / 1e9,
-                          "peak": 8000.0, "unit": "GB/s", "frac": b_step * a.steps / dt / 1e9 / 8000.0,
-                          "formula": "P*2751 + R*172 + Npix*84 + 116 MB (SURVEY 8d); per GPU"},
+        "roofline_step": step_roofline(cfg["P"], binned_mean[0] or r_mean, r_mean, npix, dt / a.steps, a.lambda_dssim),
     }
     if steady is not None:
         out["steady"] = steady
     if rank == 0:
         traffic, tnote = measured_traffic(a.roofline_kernel, cfg)
-        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], r_mean, npix, traffic=traffic)
+        sq, sqnote = sq_counters(a.roofline_kernel, cfg)
+        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], binned_mean[0] or r_mean, npix, traffic=traffic, R_ref=r_mean, sq=sq)
         if out["roofline"] is not None:
             out["roofline"].update(tnote)
-            ev = executed_valu(a.roofline_kernel, cfg)
-            if ev is not None:
-                out["roofline"]["valu"] = ev
+            out["roofline"].update(sqnote)
         prof.enable(a.roofline_kernel, False)
         if world == 1 and not a.no_extra:
             # the metric's two other readings, on the same scene and model state: the SSIM/L1 loss of the
@@ -514,7 +528,13 @@ def main():
             # (parity-test sizes, not bench lines), so that BASELINE.md's table is filled from this record
             if a.config == "c2" and not a.no_side_legs:
                 out["via_render_api"] = side_leg(cfg, dev, "autograd", 100, 20)
-                out["other_configs"] = {k: side_leg(CONFIGS[k], dev, "fused", 20, 5) for k in ("c1", "c3", "c5")}
+                # the drop-in's default sync mode: what the reference's unchanged train_4DGS.py gets (it cannot select async)
+                out["via_render_api_exact"] = side_leg(cfg, dev, "autograd", 100, 20, sync_mode="exact")
+                # the reference-identical binning (every tile of every rectangle): the mode whose integer indices are bit-exact
+                out["keep_all_tiles"] = side_leg(cfg, dev, "fused", 100, 20, keep_all_tiles=True)
+                out["other_configs"] = {k: side_leg(CONFIGS[k], dev, "fused", 20, 5) for k in ("c1", "c3")}
+                # BASELINE configs[4]: "densify/prune every 100 iters" -- the round at iteration 5100 is inside the window
+                out["other_configs"]["c5"] = side_leg(CONFIGS["c5"], dev, "fused", 120, 10, with_densify=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         sys.stdout.flush()

@@ -1,8 +1,21 @@
 """Roofline bookkeeping for bench.py.
 
-Algorithmic bytes per launch follow SURVEY.md section 8(d) (fp32): P = Gaussians, R = (Gaussian, tile)
-instances, N = pixels.  `achieved` = algorithmic bytes / average launch duration measured with HIP events around
-every launch of that kernel inside the timed region (csrc/profile.hip); `peak` = 8 TB/s HBM3E (MI355X_MICROARCH.md).
+Units: P = Gaussians, R = (Gaussian, tile) instances, N = pixels.  Two instance counts exist and
+every figure says which one it is on:
+    R_ref     the reference's count -- every tile of every splat's rectangle (duplicateWithKeys, rasterizer_impl.cu:70-111) --
+              which SURVEY 8d's algorithmic bytes are defined on, and which a keep_all_tiles launch processes;
+    R_binned  what the default binning keeps (the instances that can reach alpha >= 1/255 in their tile): the units the timed
+              launches actually PROCESS.
+`frac` is always on the processed units; `frac_on_reference_R` is the same time charged with the reference's count.
+
+Bounds:
+  * the compositing kernels (render_fwd, render_bwd) are bound by vector-instruction issue, not by HBM: `bound` = "valu",
+    achieved = wave64 vector instructions per second = SQ_INSTS_VALU per launch (the committed rocprofv3 --pmc pass of the same
+    workload and library build: profiles/*_sq.json) / the live launch duration (HIP events, csrc/profile.hip); peak = 1024 SIMDs x
+    clock / 4 cycles per instruction with the clock MEASURED in that counter pass (GRBM_GUI_ACTIVE / 8 XCDs / launch duration, the
+    guide's effective-clock formula).  The HBM figure rides along as `hbm`.
+  * the MLP kernels: "mfma" against the fp32 MFMA peak (157 TFLOP/s).
+  * everything else: "hbm", algorithmic bytes / duration against 8 TB/s.
 """
 import ctypes as C
 
@@ -10,12 +23,14 @@ from . import _native as N
 
 HBM_PEAK_GBS = 8000.0
 FP32_VALU_PEAK_TFLOPS = 157.0      # MI355X fp32 vector peak (MI355X_MICROARCH.md)
-# SURVEY 8d, "Raster VALU": FLOP per evaluated (pixel, splat) pair, with one exp each; Q = 256 R pairs per launch
-VALU_FLOP_PER_PAIR = {"render_fwd": 20, "render_bwd": 70}
+SIMDS = 1024                       # 256 CUs x 4
+CYCLES_PER_VALU = 4.0              # issue cycles of one wave64 vector instruction on a SIMD (tools/probe/valu_rate.hip: the
+                                   # SQ's own accounting, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, is 4.16-4.19 on these kernels)
 # the deformation MLP is the MFMA-bound part of the path: 34 048 FLOP per Gaussian forward (trunk 64x64, three
 # head hidden layers 64x64, heads 64x{3,3,4}); the backward (dX and dW, both kernels inside one timed scope) is twice that
 FP32_MFMA_PEAK_TFLOPS = 157.0
 MFMA_FLOP_PER_GAUSSIAN = {"mlp_fwd": 34_048, "mlp_bwd": 68_096}
+VALU_BOUND = ("render_fwd", "render_bwd")
 
 SLOTS = {n: i for i, n in enumerate(
     ["preprocess_fwd", "tile_hist", "tile_scan", "tile_scatter", "tile_sort", "render_fwd", "render_bwd", "preprocess_bwd",
@@ -23,7 +38,7 @@ SLOTS = {n: i for i, n in enumerate(
 
 
 def algorithmic_bytes(kernel, P, R, Npix, deform_floats=2_904_970):
-    """Bytes one launch must move if every operand crossed HBM exactly once."""
+    """Bytes one launch must move if every operand crossed HBM exactly once (R: the instances that launch processes)."""
     return {
         # render fwd: id 4 + record 40 (xy 8, conic+opacity 16, rgb 12, depth 4) per instance; 24 B/pixel out
         "render_fwd": R * 44 + Npix * 24,
@@ -32,13 +47,30 @@ def algorithmic_bytes(kernel, P, R, Npix, deform_floats=2_904_970):
         # preprocess fwd: 236 B in (means 12, scales 12, rot 16, opacity 4, SH 192) + 48 B record + 24 B cov3D + 8 B
         "preprocess_fwd": P * (236 + 48 + 24 + 8),
         "preprocess_bwd": P * (307 + 256),
-        # hexplane: 6144 B of plane texels gathered per Gaussian, 12 B in, 256 B out (fwd); + 256 B in and
-        # 6144 B scattered (bwd)
-        "hexplane_fwd": P * (12 + 6144 + 256),
-        "hexplane_bwd": P * (12 + 6144 + 256 + 6144 + 12),
         "adam": (P * 59 + deform_floats) * 28,
         "tile_sort": R * 12,
     }[kernel]
+
+
+def step_bytes(P, R, npix, lambda_dssim=0.0, deform_floats=2_904_970):
+    """algorithmic bytes of one fine-stage step, fp32: B = P*2751 + R*172 + N_pix*84 (+240 with SSIM)
+    + B_def, B_def = live deformation floats * 28 (Adam) + 2 * 11.55 MB (plane-gradient RMW) + 11.55 MB (regulariser read)."""
+    planes = 2_887_680 * 4
+    return P * 2751 + R * 172 + npix * (84 + (240 if lambda_dssim else 0)) + deform_floats * 28 + 3 * planes
+
+
+def step_roofline(P, R_binned, R_ref, npix, seconds_per_step, lambda_dssim=0.0):
+    """The step-level figure: SURVEY 8d's bytes on the instances the step PROCESSED over the step time, against 8 TB/s; the same
+    time charged with the reference's instance count beside it."""
+    b = step_bytes(P, R_binned, npix, lambda_dssim)
+    b_ref = step_bytes(P, R_ref, npix, lambda_dssim)
+    gbs = b / seconds_per_step / 1e9
+    return {"bound": "hbm", "algorithmic_bytes_per_step": b, "instances": R_binned,
+            "instances_are": "processed by the timed steps (the default binning's count)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "frac_on_reference_R": b_ref / seconds_per_step / 1e9 / HBM_PEAK_GBS, "instances_reference": R_ref,
+            "algorithmic_bytes_on_reference_R": b_ref,
+            "formula": "P*2751 + R*172 + Npix*84 (+240 with SSIM) + 116 MB (SURVEY 8d); per GPU"}
 
 
 def enable(kernel, on=True):
@@ -51,7 +83,16 @@ def read(kernel, reset=True):
     return ms.value, cnt.value
 
 
-def roofline(kernel, P, R, Npix, traffic=None):
+def valu_bound(insts_per_launch, clock_ghz, avg_s):
+    """achieved / peak / frac of a kernel bound by vector-instruction issue."""
+    achieved = insts_per_launch / avg_s / 1e9                     # G wave-instructions / s
+    peak = SIMDS * clock_ghz / CYCLES_PER_VALU
+    return achieved, peak
+
+
+def roofline(kernel, P, R_binned, Npix, traffic=None, R_ref=None, sq=None):
+    """The live figure for `kernel` from the HIP-event slot.  sq: that kernel's entry of the committed counter summary
+    (profiles/*_sq.json: SQ_INSTS_VALU, clock_ghz), or None."""
     ms, cnt = read(kernel)
     if cnt == 0:
         return None
@@ -62,9 +103,26 @@ def roofline(kernel, P, R, Npix, traffic=None):
         return {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
                 "algorithmic_flop_per_launch": flop, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
-    b = algorithmic_bytes(kernel, P, R, Npix)
-    achieved = b / avg_s / 1e9
-    out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
-           "algorithmic_bytes_per_launch": b}
-    return out
+    b = algorithmic_bytes(kernel, P, R_binned, Npix)
+    gbs = b / avg_s / 1e9
+    hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": b,
+           "instances": R_binned, "instances_are": "processed by the timed launches (the default binning's count)"}
+    if R_ref is not None:
+        b_ref = algorithmic_bytes(kernel, P, R_ref, Npix)
+        hbm.update({"frac_on_reference_R": b_ref / avg_s / 1e9 / HBM_PEAK_GBS, "instances_reference": R_ref,
+                    "algorithmic_bytes_on_reference_R": b_ref})
+    common = {"kernel": kernel, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt}
+    if kernel in VALU_BOUND:
+        out = {"bound": "valu", **common, "hbm": hbm}
+        if sq and sq.get("SQ_INSTS_VALU") and sq.get("clock_ghz"):
+            achieved, peak = valu_bound(sq["SQ_INSTS_VALU"], sq["clock_ghz"], avg_s)
+            out.update({"achieved": achieved, "peak": peak, "unit": "G wave64 vector instructions/s", "frac": achieved / peak,
+                        "wave_insts_per_launch": sq["SQ_INSTS_VALU"], "clock_ghz_in_counter_pass": sq["clock_ghz"],
+                        "frac_in_counter_pass": sq.get("valu_issue_frac"),
+                        "how": "SQ_INSTS_VALU per launch (committed --pmc pass, same workload and library build) / live launch "
+                               "duration; peak = 1024 SIMDs x measured clock / 4 cycles per instruction"})
+        else:
+            out.update({"achieved": None, "peak": None, "unit": "G wave64 vector instructions/s", "frac": None,
+                        "note": "no counter summary of this library build is committed: the instruction count is unknown"})
+        return out
+    return {"bound": "hbm", **common, **hbm}

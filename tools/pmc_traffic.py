@@ -38,9 +38,17 @@ NAMES = {
 }
 SKIP = 5  # warm-up launches left out of the average
 
-# bench.py config c2 (the workload the metric is quoted on)
+# bench.py config c2 (the workload the metric is quoted on) unless a fourth argument names another bench.py config
 WORKLOAD = {"workload": "200k Gaussians, 60 frames, 960x540, HexPlane on", "gaussians": 200000, "width": 960, "height": 540}
-DEFORM_FLOATS = 2_904_970
+DEFORM_FLOATS = 2_904_970          # live floats of the deformation field at the default time resolution (50)
+
+
+def deform_floats(time_res):
+    """Live (optimised) floats of the deformation field: the c2 figure with the three space-time planes of both levels resized."""
+    base_t, planes = 50, 0
+    for mult in (1, 2):
+        planes += 3 * 32 * 64 * mult * (time_res - base_t)      # (x,t), (y,t), (z,t) planes: 32 channels x 64*mult x T
+    return DEFORM_FLOATS + planes
 
 
 def load(path):
@@ -54,9 +62,16 @@ def load(path):
 
 
 def main():
-    if len(sys.argv) != 4:
+    if len(sys.argv) not in (4, 5):
         sys.exit(__doc__)
     fetch, write, prefix = load(sys.argv[1]), load(sys.argv[2]), sys.argv[3]
+    n_deform = DEFORM_FLOATS
+    if len(sys.argv) == 5:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        c = bench.CONFIGS[sys.argv[4]]
+        WORKLOAD.update({"workload": c["name"], "gaussians": c["P"], "width": c["W"], "height": c["H"]})
+        n_deform = deform_floats(c["time_res"])
     rows, kernels = [], {}
     for sym, short in NAMES.items():
         fv, wv = fetch.get(sym, [])[SKIP:], write.get(sym, [])[SKIP:]
@@ -74,7 +89,7 @@ def main():
                           "WRITE_SIZE_KiB_raw": round(w_kib, 1), "read_bytes": rd, "write_bytes": wr,
                           "traffic_bytes": rd + wr}
 
-    floats = WORKLOAD["gaussians"] * 59 + DEFORM_FLOATS
+    floats = WORKLOAD["gaussians"] * 59 + n_deform
     want_rd, want_wr = floats * 16, floats * 12
     got = kernels.get("adam")
     if not got:
@@ -98,7 +113,7 @@ def main():
         # the library the counters were collected on (mom_version() carries a hash of the kernel sources): bench.py reports the
         # figures of this file only while the running library is that build
         "lib_version": native.lib().mom_version().decode(),
-        "what": "HBM-side traffic per launch from rocprofv3 PMC counters, one MI355X, bench.py config c2",
+        "what": "HBM-side traffic per launch from rocprofv3 PMC counters, one MI355X, bench.py config " + (sys.argv[4] if len(sys.argv) == 5 else "c2"),
         "method": "two separate --pmc passes, per-dispatch values averaged over the launches after the first %d" % SKIP,
         "corrections": {"unit": "counter values are KiB (x1024)", "FETCH_SIZE": "x2 on gfx950", "WRITE_SIZE": "exact"},
         "calibration": {"adam_kernel_read_error": round(err_rd, 4), "adam_kernel_write_error": round(err_wr, 4),
