@@ -716,6 +716,10 @@ extern "C" int mom_deform_forward_activated(const MomDeformMLP* w, int P, const 
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
+int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts, const float* dscales,
+                              const float* drots, float* dfeat, void* scratch, hipStream_t s);      // deform_bwd_b3.hip
+size_t mom_deform_bwd_b3f_scratch_bytes(void);
+
 // dx and the head layers' dW in one kernel; only the trunk's dH (the first [P,64] of `scratch`) goes through memory
 static int deform_backward_fused(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                                  const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream,
@@ -762,7 +766,12 @@ static int deform_backward_fused(const MomDeformMLP* w, int P, const float* feat
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 
-extern "C" size_t mom_deform_backward_scratch_bytes(int P) { return (size_t)4 * (size_t)(P > 0 ? P : 1) * kHid * sizeof(float); }
+// the larger of what the forms need: the two-kernel form's four [P,64] matrices, the one-kernel form's per-workgroup partial sums
+extern "C" size_t mom_deform_backward_scratch_bytes(int P)
+{
+    const size_t a = (size_t)4 * (size_t)(P > 0 ? P : 1) * kHid * sizeof(float), b = mom_deform_bwd_b3f_scratch_bytes();
+    return a > b ? a : b;
+}
 
 extern "C" int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                                    const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream)
@@ -777,9 +786,12 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
     if (P < 0) return MOM_EINVAL;
     if (P == 0) return MOM_OK;
     if (!feat || !a0 || !dpts || !dscales || !drots || !dfeat || !scratch) return MOM_EINVAL;
-    // MOM_MLP_BWD=fused: the one-kernel variant above (opt-in, measured slower; read per call so a test can compare the two)
+    // MOM_MLP_BWD (read per call so that tests can compare the forms): unset or "b3" -- the one-kernel backward on the bf16 pipe
+    // with role-specialised waves (deform_bwd_b3.hip; nothing goes to dw_stream, the scratch is not touched); "split" -- the two
+    // f32 kernels below (dx on `stream`, dW on `dw_stream`); "fused" -- round 3's one-kernel f32 form (measured slower).
     const char* e = getenv("MOM_MLP_BWD");
     if (e && e[0] == 'f') return deform_backward_fused(w, P, feat, a0, dpts, dscales, drots, dfeat, scratch, stream, dw_stream);
+    if (!e || e[0] == 'b') return mom_launch_deform_bwd_b3f(w, P, feat, a0, dpts, dscales, drots, dfeat, scratch, (hipStream_t)stream);
     MlpDev d;
     int rc = fill_dev(w, &d);
     if (rc) return rc;

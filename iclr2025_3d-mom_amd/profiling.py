@@ -12,7 +12,7 @@ Bounds:
   * the compositing kernels (render_fwd, render_bwd) are bound by vector-instruction issue, not by HBM: `bound` = "valu",
     achieved = wave64 vector instructions per second = SQ_INSTS_VALU per launch (the committed rocprofv3 --pmc pass of the same
     workload and library build: profiles/*_sq.json) / the live launch duration (HIP events, csrc/profile.hip); peak = 1024 SIMDs x
-    clock / 4 cycles per instruction with the clock MEASURED in that counter pass (GRBM_GUI_ACTIVE / 8 XCDs / launch duration, the
+    clock / 2 cycles per instruction (the fp32 vector peak's issue rate) with the clock MEASURED in that counter pass (GRBM_GUI_ACTIVE / 8 XCDs / launch duration, the
     guide's effective-clock formula).  The HBM figure rides along as `hbm`.
   * the MLP kernels: "mfma" against the fp32 MFMA peak (157 TFLOP/s).
   * everything else: "hbm", algorithmic bytes / duration against 8 TB/s.
@@ -24,8 +24,11 @@ from . import _native as N
 HBM_PEAK_GBS = 8000.0
 FP32_VALU_PEAK_TFLOPS = 157.0      # MI355X fp32 vector peak (MI355X_MICROARCH.md)
 SIMDS = 1024                       # 256 CUs x 4
-CYCLES_PER_VALU = 4.0              # issue cycles of one wave64 vector instruction on a SIMD (tools/probe/valu_rate.hip: the
-                                   # SQ's own accounting, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, is 4.16-4.19 on these kernels)
+CYCLES_PER_VALU = 2.0              # the SIMD's peak: one wave64 vector instruction per 2 cycles (MI355X_MICROARCH.md, v_fma_f32; it is
+                                   # what makes 1024 SIMDs x 64 lanes x 2 flop at 2.4 GHz the 157 TFLOP/s fp32 vector peak).  What a real
+                                   # mix reaches is lower -- tools/probe/valu_rate.hip prices v_mul / v_add at 2.5 cycles, DPP adds, compares
+                                   # and selects at 4.2, v_exp / v_rcp / v_readlane / permlane swaps at 8.2 -- but a fraction of THIS peak is
+                                   # at most 1 by construction (with 4 cycles, rounds 1-3's figure, render_bwd read 1.05 at c2 and 1.12 at c3)
 # the deformation MLP is the MFMA-bound part of the path: 34 048 FLOP per Gaussian forward (trunk 64x64, three
 # head hidden layers 64x64, heads 64x{3,3,4}); the backward (dX and dW, both kernels inside one timed scope) is twice that
 FP32_MFMA_PEAK_TFLOPS = 157.0
@@ -120,7 +123,7 @@ def roofline(kernel, P, R_binned, Npix, traffic=None, R_ref=None, sq=None):
                         "wave_insts_per_launch": sq["SQ_INSTS_VALU"], "clock_ghz_in_counter_pass": sq["clock_ghz"],
                         "frac_in_counter_pass": sq.get("valu_issue_frac"),
                         "how": "SQ_INSTS_VALU per launch (committed --pmc pass, same workload and library build) / live launch "
-                               "duration; peak = 1024 SIMDs x measured clock / 4 cycles per instruction"})
+                               "duration; peak = 1024 SIMDs x measured clock / 2 cycles per instruction (the issue rate of the 157 TFLOP/s fp32 vector peak)"})
         else:
             out.update({"achieved": None, "peak": None, "unit": "G wave64 vector instructions/s", "frac": None,
                         "note": "no counter summary of this library build is committed: the instruction count is unknown"})

@@ -397,14 +397,16 @@ int mom_deform_forward_activated(const MomDeformMLP* w, int P, const float* feat
                                  float* opacity_act, mom_stream_t stream);
 /* d{pts,scales,rots}: gradients of the three outputs; writes dfeat [P,64]; weight/bias gradients accumulate into w->d*.
  * (The identity paths d xyz += dpts etc. are the caller's.) */
-size_t mom_deform_backward_scratch_bytes(int P);   /* 4 x [P,64] floats: the per-layer pre-activation gradients */
+size_t mom_deform_backward_scratch_bytes(int P);   /* the larger of 4 x [P,64] floats (the two-kernel form's pre-activation gradients) and the
+                                                       one-kernel form's per-workgroup partial sums (17.8 MB) */
 int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                         const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream);
-/* The same with the weight-gradient kernel on a second stream: dfeat (and the thin output layers' gradients) are complete on
- * `stream` as before; the 64x64 layers' weight / bias gradients are complete on `dw_stream`, which the call orders behind the
- * part on `stream` that produces their input.  The caller joins `dw_stream` before reading those gradients or reusing
- * `scratch`.  Lets the matrix-pipe bound weight-gradient kernel overlap the HexPlane backward, which is bound by vector issue
- * and memory latency.  dw_stream == stream: identical to mom_deform_backward. */
+/* The same with a second stream at the callee's disposal.  Default form (one kernel on the bf16 matrix pipe, csrc/deform_bwd_b3.hip:
+ * the pre-activation gradients never leave the CU): everything is complete on `stream`, nothing is sent to `dw_stream`.
+ * Two-kernel form (MOM_MLP_BWD=split in the environment): dfeat and the thin output layers' gradients are complete on `stream`,
+ * the 64x64 layers' weight / bias gradients on `dw_stream`, which the call orders behind the part on `stream` that produces their
+ * input.  Either way the caller joins `dw_stream` before reading the gradients or reusing `scratch`.  dw_stream == stream:
+ * identical to mom_deform_backward. */
 int mom_deform_backward_split(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                               const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream,
                               mom_stream_t dw_stream);

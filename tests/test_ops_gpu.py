@@ -506,6 +506,65 @@ def test_deform_backward_fused_variant_equals_the_two_kernel_backward(monkeypatc
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max()))
 
 
+@pytest.mark.parametrize("P", [50021, 4099, 33, 7, 200_000])
+def test_deform_backward_one_kernel_bf16_equals_the_two_kernel_f32_backward(P, monkeypatch):
+    """The default MLP backward (csrc/deform_bwd_b3.hip: one kernel, role-specialised waves, every product the exact three-way
+    bf16 expansion) against the two f32-MFMA kernels (MOM_MLP_BWD=split) and against torch autograd of the reference's layer
+    sequence (scene/deformation.py:53-65,97-153): d(features) and every weight and bias gradient -- W0, b0, the three heads' W1,
+    b1, W2, b2 -- within 2e-5 of each tensor's scale of the f32 kernels, 1e-4 of autograd (fp32 summation orders); ragged sizes
+    (a last tile of 1, 3 and 7 Gaussians) and config 2's size.  Twice in a row: the kernel's LDS hand-over must leave no state.
+    (Autograd only up to 5 k Gaussians: a hidden unit whose pre-activation is within rounding of zero takes the other side of the
+    ReLU under torch's matmul, which switches that unit's whole contribution on or off -- about one unit in a million.)"""
+    params, mk = _mlp_state(P, 11)
+    feat, xyz, scal, rot, flow = mk(P, 64) * 3, mk(P, 3), mk(P, 3), mk(P, 4), mk(P, 3)
+    dpts, dsc, drot = mk(P, 3), mk(P, 3), mk(P, 4)
+    lib, s = N.lib(), N.current_stream()
+
+    def run(mode):
+        if mode is None:
+            monkeypatch.delenv("MOM_MLP_BWD", raising=False)
+        else:
+            monkeypatch.setenv("MOM_MLP_BWD", mode)
+        grads = [torch.zeros_like(p) for p in params]
+        d = ops.DeformMLPFunction._desc(params, grads)
+        pts, sc_d, rot_d, a0 = (torch.empty(P, k, device="cuda") for k in (3, 3, 4, 64))
+        N.check(lib.mom_deform_forward(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                       flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), a0.data_ptr(), s), "fwd")
+        dfeat = torch.full((P, 64), float("nan"), device="cuda")
+        scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device="cuda")
+        N.check(lib.mom_deform_backward_split(C.byref(d), P, feat.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(),
+                                              drot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s, s), "bwd")
+        torch.cuda.synchronize()
+        return dfeat, grads
+
+    f_ref, g_ref = run("split")
+    for rep in range(2):
+        f_new, g_new = run(None)
+        assert torch.isfinite(f_new).all()
+        fs = max(1.0, float(f_ref.abs().max()))
+        assert float((f_new - f_ref).abs().max()) <= 2e-5 * fs, (rep, float((f_new - f_ref).abs().max()), fs)
+        for i, (a, b) in enumerate(zip(g_ref, g_new)):
+            sc = max(1.0, float(a.abs().max()))
+            assert float(b.abs().max()) > 0 or float(a.abs().max()) == 0, i
+            assert float((a - b).abs().max()) <= 2e-5 * sc, (rep, i, float((a - b).abs().max()), sc)
+    if P > 5000:
+        return
+    # torch autograd of the same layers
+    tp = [p.detach().clone().requires_grad_(True) for p in params]
+    x = feat.detach().clone().requires_grad_(True)
+    a0t = torch.relu(x @ tp[0].t() + tp[1])
+    loss = 0
+    for k, dout in enumerate((dpts, dsc, drot)):
+        W1, b1, W2, b2 = tp[2 + 4 * k: 6 + 4 * k]
+        o = torch.relu(a0t @ W1.t() + b1) @ W2.t() + b2
+        loss = loss + (o * dout).sum()
+    loss.backward()
+    assert float((f_new - x.grad).abs().max()) <= 1e-4 * max(1.0, float(x.grad.abs().max()))
+    for i, (t_, b) in enumerate(zip(tp, g_new)):
+        sc = max(1.0, float(t_.grad.abs().max()))
+        assert float((t_.grad - b).abs().max()) <= 1e-4 * sc, (i, float((t_.grad - b).abs().max()), sc)
+
+
 def test_adam_step_taken_in_two_parts_equals_one_step():
     """FusedAdam.step_partial(some) on a second stream followed by step() (the rest) -- how the fused training step overlaps the
     appearance parameters' update with the deformation backward -- against one step(): bit-identical parameters, moments and

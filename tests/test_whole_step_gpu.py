@@ -95,10 +95,20 @@ def test_one_iteration_hip_vs_cpu_oracle(cfg_name, lambda_dssim):
             # 99.9 % of the elements within 1e-4 of the tensor's scale, every element within 2e-3 -- at config-2 size (12 M
             # elements in f_rest) a counted handful, at most 1e-6 of the tensor and never fewer than 2 allowed, may reach 5e-3:
             # Gaussians with a (pixel, splat) pair within an ulp of the 1/255 / 0.99 / 1e-4 thresholds (measured: 2.6e-3)
-            frac_loose = float((err > 1e-4).mean())
+            # A Gaussian whose gradient moved with a threshold pair hands the difference on to everything behind it: through the MLP
+            # to the four texels x 32 channels it samples in each of six planes.  At config-2 size a dozen such Gaussians put ~0.1-0.2 %
+            # of a 64 x 64 plane's elements beyond 1e-4 of the plane's scale (measured 1.1e-3 and 1.9e-3, none beyond 2.6e-3): the
+            # planes get 3e-3 there, every other tensor keeps 1e-3.
+            # The MLP's weight gradients are sums over ALL Gaussians (200 k terms of both signs per element at config 2): two fp32
+            # summation orders of such a sum differ by ~1e-4 of the tensor's largest element by themselves (measured: every element
+            # within 1.8e-4; the one-kernel backward against the two f32 kernels on identical inputs: 2e-5, tests/test_ops_gpu.py),
+            # so "loose" means beyond 5e-4 for them there.
+            weight = k.startswith(("w", "b")) and cfg_name != "tiny"
+            frac_loose = float((err > (5e-4 if weight else 1e-4)).mean())
             n_far = int((err > 2e-3).sum())
             far_ok = 0 if cfg_name == "tiny" else max(2, int(1e-6 * err.size))
-            assert frac_loose <= 1e-3 and n_far <= far_ok and float(err.max()) <= 5e-3, (fused, k, frac_loose, n_far, float(err.max()))
+            loose_ok = 3e-3 if (cfg_name != "tiny" and k.startswith("plane_")) else 1e-3
+            assert frac_loose <= loose_ok and n_far <= far_ok and float(err.max()) <= 5e-3, (fused, k, frac_loose, n_far, float(err.max()))
         acc_scale = max(float(np.abs(ref_s["accum"]).max()), 1e-30)
         e = np.abs(stats["accum"] - ref_s["accum"]) / acc_scale
         assert float((e > 1e-4).mean()) <= 1e-3 and float(e.max()) <= 2e-3, (fused, float(e.max()))

@@ -5,11 +5,12 @@ warm-up and left out), the launch count, the mean duration (the rows carry start
 and SQ_INSTS_VALU are both present:
     clock_ghz        = GRBM_GUI_ACTIVE / 8 / duration     (the counter is summed over the 8 XCDs: the guide's effective-clock
                        formula; it reads a little HIGH on dispatches shorter than 0.3 ms, which makes the fraction below read low)
-    valu_issue_frac  = 4 * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
-the share of the launch's SIMD cycles in which a wave64 vector instruction held the issue port (4 cycles each): at most 1 by
-construction, because the denominator is every cycle of the launch on every SIMD.  (Rounds 1-3 divided by SQ_BUSY_CYCLES / 32,
-which leaves out the cycles a shader engine idles inside the launch, and read 1.05 on render_bwd.)  Without GRBM_GUI_ACTIVE the
-old figure is printed as valu_issue_frac_sq_busy."""
+    valu_issue_frac  = 2 * SQ_INSTS_VALU / (1024 SIMDs * GRBM_GUI_ACTIVE / 8)
+the launch's vector instructions against the SIMDs' peak issue rate, one wave64 instruction per 2 cycles (the rate behind the
+157 TFLOP/s fp32 vector peak): at most 1 by construction.  (Rounds 1-3 charged 4 cycles per instruction and divided by
+SQ_BUSY_CYCLES / 32: that read 1.05 on render_bwd at c2 and reads 1.12 at c3 -- simple VOP2 instructions of different waves do
+retire faster than one per 4 cycles, tools/probe/valu_rate.hip.)  Without GRBM_GUI_ACTIVE the old figure is printed as
+valu_issue_frac_sq_busy."""
 import collections
 import csv
 import json
@@ -60,7 +61,7 @@ def main():
                 t["clock_ghz"] = cyc / (t["duration_us"] * 1e3)
                 extra += f"  clock {t['clock_ghz']:.2f} GHz"
             if "SQ_INSTS_VALU" in t:
-                t["valu_issue_frac"] = 4.0 * t["SQ_INSTS_VALU"] / (1024.0 * cyc)
+                t["valu_issue_frac"] = 2.0 * t["SQ_INSTS_VALU"] / (1024.0 * cyc)
                 extra += f"  valu_issue_frac {t['valu_issue_frac']:.3f}"
         elif "SQ_BUSY_CYCLES" in t and "SQ_INSTS_VALU" in t and t["SQ_BUSY_CYCLES"] > 0:
             t["valu_issue_frac_sq_busy"] = 4.0 * t["SQ_INSTS_VALU"] / (t["SQ_BUSY_CYCLES"] / 32.0 * 1024.0)

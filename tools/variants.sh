@@ -8,7 +8,7 @@ mkdir -p ../lib/var
 base=$(basename $src .hip)
 extra=""
 extra="-fno-slp-vectorize"
-case $base in raster_preprocess|knn) extra="$extra -ffp-contract=off";; raster_render) extra="$extra -mllvm -amdgpu-sched-strategy=max-ilp";; esac
+case $base in raster_preprocess|knn) extra="$extra -ffp-contract=off";; raster_render) extra="$extra -mllvm -amdgpu-sched-strategy=max-ilp";; deform_bwd_b3) extra="$extra -mllvm -amdgpu-mfma-vgpr-form";; esac
 for spec in "$@"; do
   name=${spec%%=*}; flags=${spec#*=}
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 $extra $flags -c $base.hip -o ../lib/var/$name.o || exit 1
