@@ -137,23 +137,33 @@ __device__ __forceinline__ void flush_dw(float* __restrict__ part /* this layer'
         if (h == 0) part[kHid * kHid + 32 * mt + col] = b;
     }
 }
-// dst[i] += sum over the workgroups' partials (the gradients are ACCUMULATED into, mom4d.h).  blockIdx.y takes every 16th partial
-// (one thread per element walking all 256 was a chain of 64 dependent round trips: 30 us) and adds its sum with one atomic.
-constexpr int kReduceY = 16;
-__global__ void __launch_bounds__(256) deform_bwd_reduce_kernel(MlpDev m, const float* __restrict__ parts, int nparts)
+// dst[i] += sum over the workgroups' partials (the gradients are ACCUMULATED into, mom4d.h).  A block takes 64 consecutive
+// elements; its 1024 threads are 16 groups of 64, group q sums the partials q, q + 16, ... (every load instruction of a wave reads
+// 256 contiguous bytes), the groups meet in LDS, and one thread per element adds the total.  No atomics: one thread per element
+// walking all 256 partials took 30 us (a chain of dependent round trips), sixteen or sixty-four atomics per element 28 / 43 us.
+constexpr int kReduceGroups = 16;
+__global__ void __launch_bounds__(64 * kReduceGroups) deform_bwd_reduce_kernel(MlpDev m, const float* __restrict__ parts, int nparts)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= kPartFloats) return;
+    __shared__ float s_sum[kReduceGroups][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + e;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int w = blockIdx.y;
-    for (; w + 3 * kReduceY < nparts; w += 4 * kReduceY) {
-        s0 += parts[(size_t)w * kPartFloats + i];
-        s1 += parts[(size_t)(w + kReduceY) * kPartFloats + i];
-        s2 += parts[(size_t)(w + 2 * kReduceY) * kPartFloats + i];
-        s3 += parts[(size_t)(w + 3 * kReduceY) * kPartFloats + i];
+    if (i < kPartFloats) {
+        int w = q;
+        for (; w + 3 * kReduceGroups < nparts; w += 4 * kReduceGroups) {
+            s0 += parts[(size_t)w * kPartFloats + i];
+            s1 += parts[(size_t)(w + kReduceGroups) * kPartFloats + i];
+            s2 += parts[(size_t)(w + 2 * kReduceGroups) * kPartFloats + i];
+            s3 += parts[(size_t)(w + 3 * kReduceGroups) * kPartFloats + i];
+        }
+        for (; w < nparts; w += kReduceGroups) s0 += parts[(size_t)w * kPartFloats + i];
     }
-    for (; w < nparts; w += kReduceY) s0 += parts[(size_t)w * kPartFloats + i];
-    const float s = (s0 + s1) + (s2 + s3);
+    s_sum[q][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q != 0 || i >= kPartFloats) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kReduceGroups; k++) s += s_sum[k][e];
     if (s == 0.f) return;
     float* dst;
     if (i < 4 * kPartLayer) {
@@ -172,7 +182,7 @@ __global__ void __launch_bounds__(256) deform_bwd_reduce_kernel(MlpDev m, const 
             dst = m.db2[k] + (j - 4 * kHid);
         }
     }
-    atomicAdd(dst, s);
+    *dst += s;
 }
 
 __device__ __forceinline__ int ld_acquire(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -501,6 +511,6 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
     hipLaunchKernelGGL(deform_bwd_b3f_kernel, dim3(blocks), dim3(256), kLdsBytes, s, d, P, tiles, feat, a0, dpts, dscales, drots, dfeat,
                        (float*)scratch);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
-    hipLaunchKernelGGL(deform_bwd_reduce_kernel, dim3((kPartFloats + 255) / 256, kReduceY), dim3(256), 0, s, d, (const float*)scratch, blocks);
+    hipLaunchKernelGGL(deform_bwd_reduce_kernel, dim3((kPartFloats + 63) / 64), dim3(64 * kReduceGroups), 0, s, d, (const float*)scratch, blocks);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -81,9 +81,12 @@ static inline size_t image_view(char* base, int W, int H, ImageView* v)
 }
 static inline size_t bin_view(char* base, size_t cap, BinView* v)
 {
+    // point_list FIRST: it is all the backward reads of this buffer, and at offset 0 its position does not depend on the capacity
+    // the forward was given -- the drop-in's exact mode hands the backward the true instance count as `capacity` while the buffer
+    // was laid out for a larger one (diff_gaussian_rasterization/_C.py)
     size_t off = 0;
-    size_t o_k = off; off = mom_align_up(off + cap * 8);
     size_t o_p = off; off = mom_align_up(off + cap * 4);
+    size_t o_k = off; off = mom_align_up(off + cap * 8);
     if (v) {
         v->keys = (uint64_t*)(base + o_k);
         v->point_list = (uint32_t*)(base + o_p);

@@ -139,6 +139,44 @@ def _args(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D
     return a, keep
 
 
+def exact_render(lib, a, geom, img, out_color, out_depth, nr_host, P, W, H, dev, stream, regeometry):
+    """Second half of an exact-mode forward, behind mom_raster_forward_geometry on `stream`: returns (the TRUE instance count,
+    the binning buffer).  The reference waits for the count here and then sizes the buffer (rasterizer_impl.cu:282-285); waiting
+    first leaves the GPU idle for as long as the host needs to come back and enqueue the compositing.  So the compositing is
+    enqueued FIRST, into a buffer sized from the counts of earlier exact-mode forwards, and the host then waits only for the
+    geometry stage (an event between the two launches): the count is there, the GPU is already sorting and compositing.  If the
+    count exceeds the guess -- the first frame, a sudden jump -- the stream is drained and the frame's rasterizer stages run again
+    (regeometry(): the geometry stage, whose bucket cursors the truncated scatter has consumed; then the compositing with the exact
+    size), before anything else has been enqueued: what the caller gets back is complete either way, and num_rendered is the
+    frame's own count.  The buffer is merely larger than the reference's would be."""
+    guess = _state.get("exact_cap", 0)
+    ev = None
+    if guess:
+        ev = torch.cuda.Event()
+        ev.record()
+        binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, guess),), dtype=torch.uint8, device=dev)
+        N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), guess, img.data_ptr(),
+                                              out_color.data_ptr(), out_depth.data_ptr(), None, stream), "mom_raster_forward_render")
+        ev.synchronize()
+    else:
+        torch.cuda.current_stream().synchronize()
+    count = int(nr_host[0])
+    if count > guess:
+        if guess:
+            torch.cuda.current_stream().synchronize()      # the truncated pass is out of the way before its buffers are reused
+            regeometry()
+        guess = count
+        binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, guess),), dtype=torch.uint8, device=dev)
+        N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), guess, img.data_ptr(),
+                                              out_color.data_ptr(), out_depth.data_ptr(), None, stream), "mom_raster_forward_render")
+    # next frame's guess: a quarter above the largest count seen, in steps (so that the allocator sees the same size again)
+    want = ((int(count * 1.25) + 65535) // 65536) * 65536
+    if want > _state.get("exact_cap", 0) or _state.get("exact_cap", 0) > 4 * want:
+        _state["exact_cap"] = want
+    _state["exact_last_capacity"] = guess
+    return count, binning
+
+
 def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                         projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
                         debug):
@@ -169,10 +207,15 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
     # async with nothing to size from (no hint, no earlier frame): this one forward waits for its count, like exact mode
     blind = _state["mode"] == "async" and _state["cap_hint"] == 0 and _state["last_R"] is None
     if _state["mode"] == "exact" or blind:
-        torch.cuda.current_stream().synchronize()
-        cap = int(nr_host[0])
+        def regeometry():
+            N.check(lib.mom_raster_forward_geometry(C.byref(a), geom.data_ptr(), img.data_ptr(), radii.data_ptr(), nr_dev.data_ptr(),
+                                                    nr_host.data_ptr(), stream), "mom_raster_forward_geometry")
+        cap, binning = exact_render(lib, a, geom, img, out_color, out_depth, nr_host, P, W, H, dev, stream, regeometry)
         if blind:
             _state["cap_hint"] = int(cap * 1.5) + 4096
+        _state["last_R"] = nr_host
+        del keep
+        return cap, out_color, out_depth, radii, geom, binning, img
     else:
         flag = overflow_flag(dev)
         _check_overflow(_FLAG_LAG)

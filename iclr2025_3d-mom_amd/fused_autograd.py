@@ -138,10 +138,17 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
     # async with nothing to size from (no hint, no earlier frame): this one forward waits for its count, like exact mode
     blind = state["mode"] == "async" and state["cap_hint"] == 0 and state["last_R"] is None
     if state["mode"] == "exact" or blind:
-        torch.cuda.current_stream().synchronize()
-        cap, flag = int(nr_host[0]), None
+        # the drop-in's default: the frame's own count decides, but the compositing is enqueued before the host waits for it
+        # (RC.exact_render)
+        def regeometry():
+            N.check(lib.mom_raster_forward_geometry(C.byref(a), st.geom.data_ptr(), st.img.data_ptr(), st.radii.data_ptr(),
+                                                    nr_dev.data_ptr(), nr_host.data_ptr(), s), "raster_geometry")
+        count, st.binning = RC.exact_render(lib, a, st.geom, st.img, st.color, st.depth, nr_host, P, W, H, dev, s, regeometry)
+        cap, flag = state["exact_last_capacity"], None
         if blind:
-            state["cap_hint"] = int(cap * 1.5) + 4096
+            state["cap_hint"] = int(count * 1.5) + 4096
+        state["last_R"] = nr_host
+        st.cap = cap
     else:
         flag = RC.overflow_flag(dev)
         RC._check_overflow(RC._FLAG_LAG)
@@ -149,12 +156,11 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
         if prev is not None:
             state["cap_hint"] = max(state["cap_hint"], int(int(prev[0]) * 1.5) + 4096)
         cap = max(state["cap_hint"], 4096)
-    state["last_R"] = nr_host
-    st.cap = cap
-    st.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
-    N.check(lib.mom_raster_forward_render(C.byref(a), st.geom.data_ptr(), st.binning.data_ptr(), cap, st.img.data_ptr(),
-                                          st.color.data_ptr(), st.depth.data_ptr(), None if flag is None else flag.data_ptr(), s),
-            "raster_render")
+        state["last_R"] = nr_host
+        st.cap = cap
+        st.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
+        N.check(lib.mom_raster_forward_render(C.byref(a), st.geom.data_ptr(), st.binning.data_ptr(), cap, st.img.data_ptr(),
+                                              st.color.data_ptr(), st.depth.data_ptr(), flag.data_ptr(), s), "raster_render")
     if flag is not None:
         status_host = RC.pinned_word()
         status_host.copy_(flag, non_blocking=True)

@@ -507,7 +507,11 @@ def _dense(t):
 
 def _same_layout(a, b):
     """Same shape and same strides on every dimension that has more than one element."""
-    return a.shape == b.shape and all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+    if a.shape != b.shape:
+        return False
+    if a.stride() == b.stride():          # the common case, one tuple comparison (this runs 24 times per iteration of the API path)
+        return True
+    return all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
 
 
 class FusedAdam(torch.optim.Optimizer):

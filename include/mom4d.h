@@ -169,7 +169,8 @@ typedef struct MomRasterGrads {
 /* Backward (Rasterizer::backward, rasterizer_impl.cu:343-444): render backward
  * (backward.cu:415-590), cov2D backward (:144-274), preprocess backward (:346-412).
  * dL_dout_color [3,H,W]; dL_dout_depth [1,H,W] or null (treated as zeros).
- * `capacity` is the value given to mom_raster_forward_render.  dL_dscales /
+ * `capacity` is the value given to mom_raster_forward_render, or any smaller value that is still >= the forward's num_rendered
+ * (the tile lists sit at the start of the binning buffer whatever it was sized for).  dL_dscales /
  * dL_drotations are written only when scales/rotations are present. */
 int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, void* binning, size_t capacity,
                         void* image, const float* dL_dout_color, const float* dL_dout_depth,
@@ -197,8 +198,8 @@ int mom_mark_visible(int P, const float* means3D, const float* viewmatrix, const
  * image: ranges[tiles][2] u32, n_contrib[H*W] u32, final_T[H*W] f32, tile_counts[tiles] u32
  * (the per-tile histogram, bucket cursors and a small header also live here so that the
  * binning buffer can be sized AFTER the instance count is known).
- * binning: keys[capacity] u64 (depth_bits<<32|idx, bucketed by tile),
- * point_list[capacity] u32. */
+ * binning: point_list[capacity] u32 at offset 0 (all the backward reads of this buffer: a backward may therefore be given
+ * any capacity between the true instance count and the forward's), then keys[capacity] u64 (depth_bits<<32|idx, bucketed by tile). */
 typedef struct MomRasterLayout {
     size_t geom_rec, geom_cov3D, geom_clamped, geom_gacc;
     size_t img_ranges, img_n_contrib, img_final_T, img_tile_counts;

@@ -32,7 +32,7 @@ def test_sizing_functions_need_no_gpu():
     lay = N.MomRasterLayout()
     import ctypes as C
     assert lib.mom_raster_layout(1000, 64, 64, 5000, C.byref(lay)) == 0
-    assert lay.geom_cov3D >= 1000 * 48 and lay.bin_point_list >= 5000 * 8
+    assert lay.geom_cov3D >= 1000 * 48 and lay.bin_point_list == 0 and lay.bin_keys >= 5000 * 4      # point_list first: see mom4d.h
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

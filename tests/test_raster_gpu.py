@@ -184,6 +184,26 @@ def test_forward_parity(seed, P, W, H, kw, keep_all_tiles):
     _cmp_forward(hip_forward(s, keep_all_tiles=keep_all_tiles), _oracle(s), P)
 
 
+def test_exact_mode_with_a_guess_that_is_too_small_renders_the_frame_again():
+    """diff_gaussian_rasterization._C.exact_render enqueues the compositing into a buffer sized from earlier frames BEFORE it
+    waits for this frame's instance count; when the count exceeds the guess it must run the frame's rasterizer stages again with
+    the exact size (the truncated scatter has consumed the bucket cursors).  Forced here: a guess of 4096 instances for a frame
+    of ~10^5; the result -- count, lists, images -- is the oracle's, and the next frame's guess has grown."""
+    from hip_helpers import RC, hip_forward
+    ro.set_threads(16)
+    s = random_gaussians(20000, seed=4, W=320, H=180, scale=(-5.0, -3.0))
+    st = _oracle(s)
+    assert st.num_rendered > 3 * 4096
+    for keep_all in (True, False):
+        RC._state["exact_cap"] = 4096
+        fw = hip_forward(s, keep_all_tiles=keep_all)
+        _cmp_forward(fw, st, 20000)
+        assert RC._state["exact_cap"] >= fw["R"] > 4096
+        again = hip_forward(s, keep_all_tiles=keep_all)          # now inside the guess: same result, no second pass needed
+        np.testing.assert_array_equal(again["point_list"], fw["point_list"])
+        np.testing.assert_array_equal(again["color"], fw["color"])
+
+
 def test_forward_parity_lower_sh_degree_and_scale_modifier():
     from hip_helpers import hip_forward
     s = random_gaussians(1500, seed=7, W=96, H=80)
