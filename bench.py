@@ -288,6 +288,7 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
         loss = None
         for i in range(steps):
             loss = trainer.step(it(warmup + i), cams=[cams[(warmup + i) % len(cams)]])
+        t_enq = time.perf_counter() - t0           # the host's share: every launch of the window is enqueued (exact mode: its waits included)
         trainer.drain()
         if hasattr(loss, "tensor"):
             loss = loss.tensor()
@@ -298,7 +299,10 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
         set_keep(False)
     assert torch.isfinite(loss).all(), f"loss is not finite ({cfg['name']}, {path})"
     out = {"workload": cfg["name"], "step_path": path, "value": steps / dt, "unit": "steps/s", "steps": steps, "warmup": warmup,
-           "ms_per_step": 1e3 * dt / steps, "instances_R_mean": r_ref, "instances_binned_mean": r_binned,
+           "ms_per_step": 1e3 * dt / steps, "host_enqueue_ms_per_step": 1e3 * t_enq / steps,
+           "host_enqueue_is": "wall time of the Python loop that enqueues the window's steps, before the final drain: close to "
+                              "ms_per_step means the host sets the pace (or, in exact mode, waits for the GPU every step)",
+           "instances_R_mean": r_ref, "instances_binned_mean": r_binned,
            "keep_all_tiles": bool(keep_all_tiles), "final_loss": float(loss),
            "time_resolution": cfg["time_res"], "steps_replayed_after_overflow": int(trainer.replayed),
            "host_sync": "device-gated async (fused step)" if path == "fused" else sync_mode,

@@ -21,10 +21,10 @@ class Camera(nn.Module):
             print(e)
             print(f"[Warning] Custom device {data_device} failed, fallback to default cuda device")
             self.data_device = torch.device("cuda")
-        self.original_image = image.clamp(0.0, 1.0)[:3, :, :]      # stays on the host like the reference (:39-40)
-        self.image_width, self.image_height = self.original_image.shape[2], self.original_image.shape[1]
+        self._image_host = image.clamp(0.0, 1.0)[:3, :, :]         # the master copy stays on the host like the reference's (:39-40)
+        self.image_width, self.image_height = self._image_host.shape[2], self._image_host.shape[1]
         if gt_alpha_mask is not None:
-            self.original_image = self.original_image * gt_alpha_mask
+            self._image_host = self._image_host * gt_alpha_mask
         self.depth, self.mask, self.frame_num = depth, mask, frame_num
         self.zfar, self.znear, self.trans, self.scale = 100.0, 0.01, trans, scale
         self.world_view_transform = torch.tensor(getWorld2View2(R, T, trans, scale)).transpose(0, 1)
@@ -33,6 +33,24 @@ class Camera(nn.Module):
         self.camera_center = self.world_view_transform.inverse()[3, :3]
         self._dev_cache = None
         self._gt_dev = None
+
+    # `original_image` is what the reference's loop uploads every iteration (`viewpoint_cam.original_image.cuda()`,
+    # train_4DGS.py:194: 6 MB over PCIe behind a pageable-memory staging copy at 960x540).  With a GPU present the attribute hands
+    # out the device-resident copy of the bounded cache below, so that the script's own .cuda() is a no-op; .cpu(), indexing,
+    # save_image and arithmetic work on it as on the host tensor.  GT_ON_DEVICE = False restores the host tensor.
+    GT_ON_DEVICE = True
+
+    @property
+    def original_image(self):
+        if Camera.GT_ON_DEVICE and self.data_device.type == "cuda" and torch.cuda.is_available():
+            return self.device_tensors(self.data_device if self.data_device.index is not None
+                                       else torch.device("cuda", torch.cuda.current_device()))[3]
+        return self._image_host
+
+    @original_image.setter
+    def original_image(self, image):
+        self._image_host = image.detach().to("cpu") if image.device.type != "cpu" else image
+        self._drop_gt()
 
     # Ground-truth images resident on the device, over all cameras: bounded (least recently used first out), because a real
     # multi-view video is tens of GB while the three matrices of a camera are 140 bytes.  The reference uploads the image of
@@ -52,7 +70,7 @@ class Camera(nn.Module):
             self._drop_gt()
         cls = Camera
         if self._gt_dev is None:
-            img = self.original_image.to(device).contiguous()
+            img = self._image_host.to(device).contiguous()
             self._gt_dev = img
             if img.device.type != "cpu":
                 nbytes = img.numel() * img.element_size()

@@ -47,11 +47,11 @@ def write_stage1_outputs(input_dir, scene):
             "pcd_points": pts.T.copy(), "pcd_colors": np.asarray(scene.point_cloud.colors, np.float32),
             "pcd_masks": np.ones((pts.shape[0], 3), np.float32), "frames": []}
     for cam in views:
-        data["frames"].append({"image": _to_pil(cam.original_image), "transform_matrix": _c2w_opengl(cam).tolist(), "mask": ones,
+        data["frames"].append({"image": _to_pil(cam._image_host), "transform_matrix": _c2w_opengl(cam).tolist(), "mask": ones,
                                "final_hint_start_x": [], "final_hint_start_y": [], "final_hint_end_x": [], "final_hint_end_y": [],
                                "T2C_flow": [], "our_flow": []})
     for f, cam in enumerate(scene._video):
-        _to_pil(cam.original_image).save(os.path.join(mom, "video", f"{f:05d}.png"))
+        _to_pil(cam._image_host).save(os.path.join(mom, "video", f"{f:05d}.png"))
     path = os.path.join(mom, "train_data.pth")
     torch.save(data, path)
     torch.save(scene.scene_flow.clone(), os.path.join(mom, "scene_flow.pth"))

@@ -109,7 +109,7 @@ class SyntheticScene:
             R, t = self.side_trajectory()
             F = len(self._video)
             self._side = [Camera(colmap_id=i, R=R[i].astype(np.float64), T=t[i].astype(np.float64), FoVx=self.FovX, FoVy=self.FovY,
-                                 image=self._video[i % F].original_image, gt_alpha_mask=None, image_name=f"side{i}", uid=i,
+                                 image=self._video[i % F]._image_host, gt_alpha_mask=None, image_name=f"side{i}", uid=i,
                                  data_device=self._video[0].data_device, time=((i % F) / (F - 1) if F > 1 else 0.0),
                                  frame_num=i % F) for i in range(59)]
         return self._side

@@ -46,3 +46,25 @@ def test_fine_sampler_keeps_one_permutation_per_frame():
     fresh = [x for x in s.sample_list if x % 5 == 1]                          # frame 1's own indices appear once each at least
     assert set(fresh) >= {p * 5 + 1 for p in range(6)}
     assert all(0 <= x < 30 for x in s.sample_list) and list(iter(s)) == s.sample_list
+
+
+@pytest.mark.gpu
+def test_the_scripts_own_upload_of_the_ground_truth_image_is_a_no_op():
+    """train_4DGS.py:194 does `gt_image = viewpoint_cam.original_image.cuda()` every iteration.  With a GPU present the attribute
+    hands out the device-resident copy (bounded cache, scene/cameras.py), so that call moves nothing; the host copy stays the
+    master (checkpoints, the stage-1 writer), and GT_ON_DEVICE = False gives the reference's host tensor back."""
+    import numpy as np
+    C = importlib.import_module(PKG + ".scene.cameras")
+    img = torch.rand(3, 24, 32)
+    cam = C.Camera(colmap_id=0, R=np.eye(3), T=np.zeros(3), FoVx=0.9, FoVy=0.6, image=img, gt_alpha_mask=None, image_name="x", uid=0)
+    a = cam.original_image
+    assert a.is_cuda and a.cuda().data_ptr() == a.data_ptr() == cam.original_image.data_ptr()
+    assert torch.equal(a.cpu(), img.clamp(0, 1)) and tuple(a.shape) == (3, 24, 32)
+    assert cam.device_tensors(a.device)[3].data_ptr() == a.data_ptr()
+    C.Camera.GT_ON_DEVICE = False
+    try:
+        assert not cam.original_image.is_cuda and torch.equal(cam.original_image, img.clamp(0, 1))
+    finally:
+        C.Camera.GT_ON_DEVICE = True
+    cam.original_image = torch.zeros(3, 24, 32, device="cuda")          # assignment replaces the master copy
+    assert float(cam.original_image.abs().max()) == 0.0 and not cam._image_host.is_cuda
