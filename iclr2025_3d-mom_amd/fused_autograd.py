@@ -183,7 +183,7 @@ def _field_grads(st, f, direct=True):
     field = st.field
     # through-the-graph mode (direct False): never touch a .grad, never hand out the cached buffer
     held = [p.grad if direct else None for p in st.planes]
-    in_place = [g is not None and ops._same_layout(g, p) and ops._dense(g) for g, p in zip(held, st.planes)]
+    in_place = ops.in_place_flags(held, st.planes)
     key = (tuple(p.data_ptr() for p in st.planes), tuple(p.data_ptr() for p in st.mlp), tuple(field.aabb_host()),
            tuple(g.data_ptr() if ip else 0 for g, ip in zip(held, in_place)))
     c = getattr(field, "_fa_grads", None)

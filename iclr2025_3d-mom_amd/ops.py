@@ -446,7 +446,7 @@ class PlaneRegFunction(torch.autograd.Function):
         # the device (float(g) was a host synchronisation in every iteration).
         direct = PlaneRegFunction.DIRECT_GRADS and direct_grads_ok(planes, ctx.needs_input_grad[2:])
         held = [p.grad if direct else None for p in planes]
-        in_place = [h is not None and _same_layout(h, p) and _dense(h) for h, p in zip(held, planes)]
+        in_place = in_place_flags(held, planes)
         key = (tuple(p.data_ptr() for p in planes), tuple(w_smooth), tuple(w_l1),
                tuple(h.data_ptr() if ip else 0 for h, ip in zip(held, in_place)))
         c = PlaneRegFunction._cache
@@ -512,6 +512,29 @@ def _same_layout(a, b):
     if a.stride() == b.stride():          # the common case, one tuple comparison (this runs 24 times per iteration of the API path)
         return True
     return all(sa == sb for sa, sb, n in zip(a.stride(), b.stride(), a.shape) if n > 1)
+
+
+_IN_PLACE_MEMO = {}
+
+
+def in_place_flags(held, planes):
+    """[h is a gradient tensor the kernels can add into in place: same layout as its plane, dense] for every plane.  The answer
+    depends on the two tensors' storage, shape and strides only, and the loop hands in the SAME buffers iteration after iteration
+    (the gradient buffers are cached), so it is remembered per (gradient pointer, plane pointer): twelve pairs of pointer reads
+    instead of twelve shape-and-stride walks, twice per iteration of the API path."""
+    out = []
+    for h, p in zip(held, planes):
+        if h is None:
+            out.append(False)
+            continue
+        k = (h.data_ptr(), p.data_ptr(), h.shape, h.stride())
+        v = _IN_PLACE_MEMO.get(k)
+        if v is None:
+            if len(_IN_PLACE_MEMO) > 4096:
+                _IN_PLACE_MEMO.clear()
+            v = _IN_PLACE_MEMO[k] = bool(_same_layout(h, p) and _dense(h))
+        out.append(v)
+    return out
 
 
 class FusedAdam(torch.optim.Optimizer):
