@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     __shared__ uint32_t s_bin[kOrderBins + 1];
+    __shared__ uint32_t s_big;             // tiles of at least kRenderSortCap instances: the head of the order
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     for (int i = threadIdx.x; i <= kOrderBins; i += 1024) s_bin[i] = 0;
@@ -185,6 +186,12 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
         const uint32_t excl = incl - (c0 + c1);
         s_bin[2 * lane] = excl;
         s_bin[2 * lane + 1] = excl + c0;
+        // the classes are 32 instances wide and kRenderSortCap is a multiple of 32: every tile the binning's own sort launch has to
+        // take (more keys than the compositing forward sorts itself) sits in front of the first class below kRenderSortCap / 32
+        static_assert(kRenderSortCap % 32 == 0 && kRenderSortCap / 32 < kOrderBins, "class boundary");
+        constexpr int kFirstSmall = kOrderBins - kRenderSortCap / 32;          // first class whose tiles all have < kRenderSortCap keys
+        if (2 * lane == kFirstSmall) s_big = excl;
+        if (2 * lane + 1 == kFirstSmall) s_big = excl + c0;
     }
     __syncthreads();
     for (int t = t0 + threadIdx.x; t < t0 + nt; t += 1024) tile_order[atomicAdd(&s_bin[bin_of(tile_counts[t])], 1u)] = (uint32_t)t;
@@ -192,6 +199,7 @@ __global__ void __launch_bounds__(1024) tile_scan_kernel(int tiles, const uint32
         hdr[0] = s_carry;
         hdr[3] = (uint32_t)t0;              // the range the order covers: a later launch over other rows ignores the order
         hdr[4] = (uint32_t)nt;
+        hdr[5] = s_big;                     // how many entries at the head of the order can exceed kRenderSortCap keys
         *num_rendered_dev = s_carry;
         // device-accessible pinned host memory: the count reaches the host without a copy command behind this kernel
         if (num_rendered_host) __hip_atomic_store(num_rendered_host, s_carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -252,28 +260,36 @@ __global__ void __launch_bounds__(256) tile_scatter_kernel(int P, int chunks, in
 // CAP: keys this instantiation sorts in LDS; it handles the tiles with LO < n <= CAP (n > kSortLdsCap: in global memory) and
 // leaves the others to the sibling launch.  A single kernel sized for the worst case reserved 64 KB of LDS for every tile
 // and fitted two workgroups per CU, while the average tile at 960x540 has ~650 keys.
+// head_count (may be null): a device word holding how many entries at the head of tile_order can qualify (tile_scan, hdr[5]); the
+// launch is then a small fixed grid whose workgroups stride over that head, instead of one workgroup per tile of which nearly
+// all look at their tile's count and leave (2040 workgroups for a handful of large tiles: 11 us at 960x540).
 template <int LO, int CAP>
 __global__ void __launch_bounds__(256) tile_sort_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_order,
-                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, uint32_t capacity)
+                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ point_list, uint32_t capacity,
+                                                       const uint32_t* __restrict__ head_count, int nt)
 {
     __shared__ uint64_t s_keys[CAP];
-    const uint2 r = ranges[tile_order[blockIdx.x]];         // the launch's tiles, heaviest first (tile_scan)
-    uint32_t end = r.y < capacity ? r.y : capacity;
-    if (r.x >= end) return;
-    const int n = (int)(end - r.x);
-    if (n <= LO || (n > CAP && CAP < kSortLdsCap)) return;          // the sibling launch's tile
-    uint64_t* gk = keys + r.x;
-    if (n <= CAP) {
-        for (int i = threadIdx.x; i < n; i += 256) s_keys[i] = gk[i];
-        __syncthreads();
-        if (n > 1) bitonic_sort<true>(s_keys, n, 256, threadIdx.x);
-        for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)s_keys[i];
-    } else {
-        // oversized bucket: same network directly on the (L2-resident) global bucket
-        __syncthreads();
-        bitonic_sort<false>(gk, n, 256, threadIdx.x);
-        __threadfence_block();
-        for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)gk[i];
+    const int limit = head_count ? min((int)*head_count, nt) : nt;
+    for (int slot = blockIdx.x; slot < limit; slot += gridDim.x) {
+        const uint2 r = ranges[tile_order[slot]];            // the launch's tiles, heaviest first (tile_scan)
+        uint32_t end = r.y < capacity ? r.y : capacity;
+        if (r.x >= end) continue;
+        const int n = (int)(end - r.x);
+        if (n <= LO || (n > CAP && CAP < kSortLdsCap)) continue;    // the sibling launch's tile
+        uint64_t* gk = keys + r.x;
+        __syncthreads();                                    // the previous tile's keys have left s_keys
+        if (n <= CAP) {
+            for (int i = threadIdx.x; i < n; i += 256) s_keys[i] = gk[i];
+            __syncthreads();
+            if (n > 1) bitonic_sort<true>(s_keys, n, 256, threadIdx.x);
+            for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)s_keys[i];
+        } else {
+            // oversized bucket: same network directly on the (L2-resident) global bucket
+            __syncthreads();
+            bitonic_sort<false>(gk, n, 256, threadIdx.x);
+            __threadfence_block();
+            for (int i = threadIdx.x; i < n; i += 256) point_list[r.x + i] = (uint32_t)gk[i];
+        }
     }
 }
 
@@ -348,14 +364,14 @@ int mom_launch_binning_sort(const MomRasterArgs* a, const GeomView& g, const Bin
     if (render_sorts_small) {
         // tiles of up to kRenderSortCap keys are sorted by the compositing forward itself (raster_render.hip), in the LDS it stages
         // its splats in afterwards: one launch and one pass over the keys less; this launch takes the rest
-        hipLaunchKernelGGL((tile_sort_kernel<kRenderSortCap, kSortLdsCap>), dim3(nt), dim3(256), 0, s, im.ranges, im.tile_order, b.keys,
-                           b.point_list, cap);
+        hipLaunchKernelGGL((tile_sort_kernel<kRenderSortCap, kSortLdsCap>), dim3(nt < 128 ? nt : 128), dim3(256), 0, s, im.ranges,
+                           im.tile_order, b.keys, b.point_list, cap, im.hdr + 5, nt);
         return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
     }
     hipLaunchKernelGGL((tile_sort_kernel<0, kSortSmallCap>), dim3(nt), dim3(256), 0, s, im.ranges, im.tile_order, b.keys, b.point_list,
-                       cap);
+                       cap, (const uint32_t*)nullptr, nt);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     hipLaunchKernelGGL((tile_sort_kernel<kSortSmallCap, kSortLdsCap>), dim3(nt), dim3(256), 0, s, im.ranges, im.tile_order, b.keys,
-                       b.point_list, cap);
+                       b.point_list, cap, (const uint32_t*)nullptr, nt);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

@@ -611,12 +611,17 @@ class FusedAdam(torch.optim.Optimizer):
             plan["arrs"][cfg][i].grad = g.data_ptr()
         torch._foreach_add_(plan["steps"], 1)
         arrs = plan["arrs"]
-        for (group, b1, b2, cfg, i), st_step in zip(plan["entries"], plan["steps"]):
-            step = float(st_step)
+        # the step counters are host tensors the state surgery and rewind() may have touched: read them all in one go, and form
+        # the two bias corrections once per distinct (betas, step) -- one or two values, not one per tensor
+        step_vals = torch.stack(plan["steps"]).tolist()
+        bias = {}
+        for (group, b1, b2, cfg, i), step in zip(plan["entries"], step_vals):
+            bc = bias.get((b1, b2, step))
+            if bc is None:
+                bc = bias[(b1, b2, step)] = (1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step))
             t = arrs[cfg][i]
             t.lr = float(group["lr"])
-            t.bias_correction1 = 1.0 - b1 ** step
-            t.bias_correction2_sqrt = math.sqrt(1.0 - b2 ** step)
+            t.bias_correction1, t.bias_correction2_sqrt = bc
         for (b1, b2, eps), arr in arrs.items():
             N.check(N.lib().mom_adam_step(arr, len(arr), b1, b2, eps,
                                           None if self.skip_flag is None else self.skip_flag.data_ptr(), N.current_stream()),
