@@ -492,7 +492,7 @@ deform_bwd_b3f_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
 size_t mom_deform_bwd_b3f_scratch_bytes(void) { return (size_t)256 * kPartFloats * sizeof(float); }
 
 int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts, const float* dscales,
-                              const float* drots, float* dfeat, void* scratch, hipStream_t s)
+                              const float* drots, float* dfeat, void* scratch, hipStream_t s, hipStream_t dw_stream)
 {
     MlpDev d;
     int rc = fill_dev(w, &d);
@@ -513,6 +513,19 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
     hipLaunchKernelGGL(deform_bwd_b3f_kernel, dim3(blocks), dim3(256), kLdsBytes, s, d, P, tiles, feat, a0, dpts, dscales, drots, dfeat,
                        (float*)scratch);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
-    hipLaunchKernelGGL(deform_bwd_reduce_kernel, dim3((kPartFloats + 63) / 64), dim3(64 * kReduceGroups), 0, s, d, (const float*)scratch, blocks);
+    // The sum over the workgroups' partials is all that is left of "the weight gradients are complete on dw_stream": it goes to the
+    // caller's second stream, behind an event.  On `stream` it sat between the MLP backward and the HexPlane backward and, in the
+    // training step, shared HBM with the early Adam launch: 46 us on the critical path for a kernel that takes 6 alone.
+    static int reduce_on_main = -1;      // MOM_B3F_REDUCE_MAIN=1: keep the reduction on `stream` (measurement)
+    if (reduce_on_main < 0) { const char* e = getenv("MOM_B3F_REDUCE_MAIN"); reduce_on_main = (e && e[0] == '1') ? 1 : 0; }
+    if (reduce_on_main) dw_stream = s;
+    if (dw_stream != s) {
+        static hipEvent_t main_done = nullptr;
+        if (!main_done && hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
+        if (hipEventRecord(main_done, s) != hipSuccess) return MOM_ELAUNCH;
+        if (hipStreamWaitEvent(dw_stream, main_done, 0) != hipSuccess) return MOM_ELAUNCH;
+    }
+    hipLaunchKernelGGL(deform_bwd_reduce_kernel, dim3((kPartFloats + 63) / 64), dim3(64 * kReduceGroups), 0, dw_stream, d, (const float*)scratch,
+                       blocks);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }

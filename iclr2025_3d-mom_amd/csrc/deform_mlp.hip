@@ -717,7 +717,7 @@ extern "C" int mom_deform_forward_activated(const MomDeformMLP* w, int P, const 
 }
 
 int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts, const float* dscales,
-                              const float* drots, float* dfeat, void* scratch, hipStream_t s);      // deform_bwd_b3.hip
+                              const float* drots, float* dfeat, void* scratch, hipStream_t s, hipStream_t dw_stream);      // deform_bwd_b3.hip
 size_t mom_deform_bwd_b3f_scratch_bytes(void);
 
 // dx and the head layers' dW in one kernel; only the trunk's dH (the first [P,64] of `scratch`) goes through memory
@@ -787,11 +787,13 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
     if (P == 0) return MOM_OK;
     if (!feat || !a0 || !dpts || !dscales || !drots || !dfeat || !scratch) return MOM_EINVAL;
     // MOM_MLP_BWD (read per call so that tests can compare the forms): unset or "b3" -- the one-kernel backward on the bf16 pipe
-    // with role-specialised waves (deform_bwd_b3.hip; nothing goes to dw_stream, the scratch is not touched); "split" -- the two
+    // with role-specialised waves (deform_bwd_b3.hip; dfeat is complete on `stream`, the small reduction that completes the weight
+    // gradients runs on dw_stream); "split" -- the two
     // f32 kernels below (dx on `stream`, dW on `dw_stream`); "fused" -- round 3's one-kernel f32 form (measured slower).
     const char* e = getenv("MOM_MLP_BWD");
     if (e && e[0] == 'f') return deform_backward_fused(w, P, feat, a0, dpts, dscales, drots, dfeat, scratch, stream, dw_stream);
-    if (!e || e[0] == 'b') return mom_launch_deform_bwd_b3f(w, P, feat, a0, dpts, dscales, drots, dfeat, scratch, (hipStream_t)stream);
+    if (!e || e[0] == 'b')
+        return mom_launch_deform_bwd_b3f(w, P, feat, a0, dpts, dscales, drots, dfeat, scratch, (hipStream_t)stream, (hipStream_t)dw_stream);
     MlpDev d;
     int rc = fill_dev(w, &d);
     if (rc) return rc;

@@ -403,7 +403,8 @@ size_t mom_deform_backward_scratch_bytes(int P);   /* the larger of 4 x [P,64] f
 int mom_deform_backward(const MomDeformMLP* w, int P, const float* feat, const float* a0, const float* dpts,
                         const float* dscales, const float* drots, float* dfeat, void* scratch, mom_stream_t stream);
 /* The same with a second stream at the callee's disposal.  Default form (one kernel on the bf16 matrix pipe, csrc/deform_bwd_b3.hip:
- * the pre-activation gradients never leave the CU): everything is complete on `stream`, nothing is sent to `dw_stream`.
+ * the pre-activation gradients never leave the CU): dfeat is complete on `stream`; the weight / bias gradients are complete on
+ * `dw_stream` (the sum over the workgroups' partial sums runs there, ordered behind the kernel on `stream`).
  * Two-kernel form (MOM_MLP_BWD=split in the environment): dfeat and the thin output layers' gradients are complete on `stream`,
  * the 64x64 layers' weight / bias gradients on `dw_stream`, which the call orders behind the part on `stream` that produces their
  * input.  Either way the caller joins `dw_stream` before reading the gradients or reusing `scratch`.  dw_stream == stream:
