@@ -30,3 +30,5 @@ python3 tools/pmc_traffic.py $out/FETCH_SIZE_counter_collection.csv $out/WRITE_S
 python3 tools/pmc_sq.py $out/sq_counter_collection.csv --json $out/${pre}_sq.json --workload "$name" | head -14
 if [ "$cfg" = "c2" ]; then python3 tools/pmc_mfma.py $out/sq_counter_collection.csv $out/sq_kernel_trace.csv $out/$pre 2>&1 | tail -6; fi
 tail -c 2500 $out/bench_default.json
+# the raw per-dispatch counter tables are tens of MB per config; only the summaries travel back
+rm -f $out/*_counter_collection.csv $out/sq_kernel_trace.csv
