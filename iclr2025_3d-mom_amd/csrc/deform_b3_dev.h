@@ -44,6 +44,11 @@ struct Frag3 {
 __device__ __forceinline__ Frag3 split8(const float (&v)[8])
 {
     Frag3 f;
+#ifdef B3F_NO_SPLIT        // timing ablation: the operands' raw bits as every piece (wrong numbers, the split's instructions gone)
+#pragma unroll
+    for (int p = 0; p < 3; p++) f.p[p] = make_uint4(__float_as_uint(v[0]) ^ __float_as_uint(v[4]), __float_as_uint(v[1]) ^ __float_as_uint(v[5]), __float_as_uint(v[2]) ^ __float_as_uint(v[6]), __float_as_uint(v[3]) ^ __float_as_uint(v[7]));
+    return f;
+#endif
     uint32_t q[4][3];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -74,6 +79,11 @@ __device__ __forceinline__ void split_tile(const f32x16 (&t)[2], Frag3 (&B)[4])
 }
 __device__ __forceinline__ f32x16 mfma16(uint4 a, uint4 b, f32x16 c)
 {
+#ifdef B3F_NO_MFMA         // timing ablation: the operands are kept alive, no matrix instruction is issued
+    asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w));
+    c[0] += __uint_as_float(a.x);
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 

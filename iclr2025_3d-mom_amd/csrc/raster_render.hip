@@ -101,6 +101,12 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
 #ifndef MOM_FWD_WAVES
 #define MOM_FWD_WAVES 8
 #endif
+#ifndef MOM_FWD_PREFETCH
+#define MOM_FWD_PREFETCH 1
+#endif
+#ifndef MOM_BWD_CUT
+#define MOM_BWD_CUT 1
+#endif
 #ifndef MOM_BWD_WAVES
 #define MOM_BWD_WAVES 5
 #endif
@@ -177,6 +183,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     // binning sorted every tile).  The sorted indices go to point_list -- the backward walks it too -- and are read back from
     // there by this workgroup (same CU: its stores are visible to its loads after the barrier).
     static_assert(kRenderSortCap * 8 <= kRound * 3 * 16, "the sort aliases the splat staging area");
+    bool have_first = false;                                  // a tile sorted here: the first round's index comes out of LDS
+    uint32_t first_id = 0;
     if (sort_keys && toDo > 0 && toDo <= kRenderSortCap) {
         uint64_t* sk = reinterpret_cast<uint64_t*>(s_rec);
         const uint64_t* __restrict__ gk = sort_keys + range.x;
@@ -184,6 +192,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
         __syncthreads();
         if (toDo > 1) bitonic_sort<true>(sk, toDo, 256, (int)threadIdx.x);
         for (int i = threadIdx.x; i < toDo; i += 256) point_list[range.x + i] = (uint32_t)sk[i];
+        have_first = true;
+        if ((int)threadIdx.x < toDo) first_id = (uint32_t)sk[threadIdx.x];     // (the keys alias s_rec: read before round 0 stages into it)
         __threadfence_block();
         __syncthreads();
     }
@@ -193,8 +203,44 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint64_t live = __builtin_amdgcn_ballot_w64(inside);      // wave-uniform: the lanes still compositing (= !done, as a mask)
 
+#if MOM_FWD_PREFETCH
+    // A round's records are asked for one round ahead: the index and the three record loads that depend on it are two memory round
+    // trips, and a tile's eight workgroups-per-CU neighbours are all there is to cover them (at the headline size every tile is
+    // resident from the start of the launch: nothing new is scheduled onto a SIMD that waits).  The values wait in registers
+    // through the compositing of the round before and go to LDS once every wave has left that round.
+    static_assert(kRound == 256, "one staged splat per thread");
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+    bool pv = false;
+    auto fetch = [&](int round) {
+        const uint32_t at = range.x + (uint32_t)(round * kRound) + threadIdx.x;
+        pv = round < rounds && at < range.y;
+        if (pv) {
+            const size_t id = (round == 0 && have_first) ? first_id : point_list[at];
+            p0 = rec[3 * id + 0];
+            p1 = rec[3 * id + 1];
+            p2 = rec[3 * id + 2];
+        }
+    };
+    fetch(0);
+#endif
     for (int i = 0; i < rounds; i++, toDo -= kRound) {
         if (__syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256) break;
+#if MOM_FWD_PREFETCH
+        {
+            uint32_t reach = 0;
+            if (pv) {
+                float4 q0 = p0;
+                q0.w = power_bound(p1.w);
+                reach = strip_reach_mask(q0, p1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
+                s_rec[threadIdx.x * 3 + 0] = q0;
+                s_rec[threadIdx.x * 3 + 1] = p1;
+                s_rec[threadIdx.x * 3 + 2] = p2;
+            }
+            s_mask[threadIdx.x] = (uint8_t)reach;
+        }
+        __syncthreads();
+        fetch(i + 1);
+#else
 #pragma unroll
         for (int sl = 0; sl < kRound / 256; sl++) {
             const int slot = threadIdx.x + 256 * sl, progress = i * kRound + slot;
@@ -212,6 +258,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
             s_mask[slot] = (uint8_t)reach;                  // slots past the end of the list: unreachable
         }
         __syncthreads();
+#endif
         int list[kRoundChunks];
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
 #pragma unroll
@@ -429,7 +476,9 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     if (range.y > capacity) range.y = capacity;
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
+#if !MOM_BWD_CUT
     const int rounds = (toDo + kRoundB - 1) / kRoundB;
+#endif
 
     const int pix = inside ? py * W + px : 0;
     const size_t HW = (size_t)H * W;
@@ -489,14 +538,35 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+#if MOM_BWD_CUT
+    // ... and the splats behind the last contributor of the whole TILE are not even staged: the list ends there for this launch
+    // (positions are counted from the front, so cutting the tail moves none of them).  A tile the forward left early -- every
+    // pixel saturated -- otherwise stages, tests and skips the rest of its list round after round.
+    {
+        int* s_last = reinterpret_cast<int*>(s_id);
+        if (lane == 0) s_last[wv] = wave_last;
+        __syncthreads();
+        const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
+        __syncthreads();                                   // s_id is written again by the first round's staging
+        if (tile_last < toDo) {
+            toDo = tile_last;
+            range.y = range.x + (uint32_t)tile_last;
+            contributor = (uint32_t)toDo;
+        }
+    }
+    const int rounds = (toDo + kRoundB - 1) / kRoundB;
+#endif
 
+    // (Asking for the next round's records a round ahead, as render_fwd does, does not pay here: 26 more live registers spill at
+    // five waves per SIMD -- 201.8 against 195.3 us; with 256-splat rounds 211; the indices alone 196.6.)
     for (int i = 0; i < rounds; i++, toDo -= kRoundB) {
         drain();                     // s_id is about to be overwritten: what waits goes out now
         __syncthreads();
 #pragma unroll
         for (int sl = 0; sl < kRoundB / 256; sl++) {
-            const int slot = threadIdx.x + 256 * sl, progress = i * kRoundB + slot;
+            const int slot = threadIdx.x + 256 * sl;
             uint32_t reach = 0;
+            const int progress = i * kRoundB + slot;
             if (range.x + progress < range.y) {
                 const uint32_t id = point_list[range.y - progress - 1];
                 s_id[slot] = id;

@@ -23,6 +23,16 @@ for _ in range(3):
     N.check(lib.mom_deform_backward_split(C.byref(d), P, feat.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(), drot.data_ptr(),
                                           dfeat.data_ptr(), scratch.data_ptr(), s, s), "bwd")
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    N.check(lib.mom_deform_backward_split(C.byref(d), P, feat.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(), drot.data_ptr(),
+                                          dfeat.data_ptr(), scratch.data_ptr(), s, s), "bwd")
+e1.record()
+torch.cuda.synchronize()
+print("kernel + reduce, alone: %.1f us per launch" % (e0.elapsed_time(e1) * 1e3 / 20))
+if not os.environ.get("MOM4D_LIB", "").endswith("stamps.so"):
+    sys.exit(0)
 part_floats = 4 * (64 * 64 + 64) + 3 * (4 * 64 + 4)
 off = 256 * part_floats * 4
 dbg = scratch[off:off + 256 * 4 * 8 * 8].cpu().numpy().view(np.uint64).reshape(256, 4, 8).astype(np.float64)
