@@ -132,6 +132,9 @@ def measured_traffic(kernel, cfg):
     return k["traffic_bytes"], {"traffic_source": name, "traffic_collected_on": doc.get("lib_version")}
 
 
+PROFILE_PERIOD = 7
+
+
 def sq_counters(kernel, cfg):
     """(entry, note): that kernel's means from the committed SQ / GRBM counter summary (profiles/*_sq.json: SQ_INSTS_VALU per
     launch, the clock measured in that pass, the issue fraction inside that pass) -- reported as live only while the running
@@ -439,7 +442,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         if profile_kernel and rank == 0:
-            prof.enable(profile_kernel)      # two hipEventRecord per step around the dominant kernel only
+            # HIP events around the dominant kernel only, on every 7th step of the region (7 is coprime to the 60 / 120 / 240 cameras
+            # the steps cycle through, so the sample covers them evenly): an event pair costs the stream ~13 us of bubbles
+            # (tools/gap_stats.py), 1.3 % of the headline step if every launch carried one
+            prof.enable(profile_kernel, period=PROFILE_PERIOD if steps >= 10 * PROFILE_PERIOD else 1)
         t0 = time.perf_counter()
         loss = None
         for i in range(steps):

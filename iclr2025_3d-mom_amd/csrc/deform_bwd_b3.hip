@@ -202,6 +202,10 @@ __device__ __forceinline__ void wait_ge(const int* p, int v)
 #else
 #define B3F_STAMP(i) do { } while (0)
 #endif
+// (The wave takes its SIMD's whole register file, so nothing co-runs with this kernel: the early Adam launch on the second stream
+// waits for its workgroups to leave.  Capped at 480 registers -- amdgpu_num_vgpr(240) -- one Adam wave fits beside it on every
+// SIMD and the HexPlane backward no longer shares HBM with Adam (189 -> 170 us at config 2, 3400 -> 2420 at config 5), but this
+// kernel then takes 222 instead of 173-191 us, raised wave priority or not: 1066 -> 1038 steps/s at config 2, equal at config 5.)
 __global__ void __launch_bounds__(256, 1)
 deform_bwd_b3f_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ a0g,
                       const float* __restrict__ dpts, const float* __restrict__ dscales, const float* __restrict__ drots,

@@ -52,6 +52,17 @@ def algorithmic_bytes(kernel, P, R, Npix, deform_floats=2_904_970):
         "preprocess_bwd": P * (307 + 256),
         "adam": (P * 59 + deform_floats) * 28,
         "tile_sort": R * 12,
+        # binning: the histogram reads the 40-byte rectangle record per Gaussian; the scan 20 B per tile; the scatter writes one
+        # 8-byte key per instance
+        "tile_hist": P * 40,
+        "tile_scan": (Npix // 256) * 20,
+        "tile_scatter": P * 40 + R * 8,
+        # HexPlane: forward 4620 B gathered + 640 B written per Gaussian; backward (gather + scatter in one
+        # scope) 6412 + 768 B per Gaussian in the gather, 768 B in the scatter, and the plane gradients' read-modify-write
+        "hexplane_fwd": P * (4620 + 640),
+        "hexplane_bwd": P * (6412 + 768 + 768) + 2 * 2_887_680 * 4,
+        "l1_loss": Npix * 36,
+        "plane_reg": 3 * 2_887_680 * 4,
     }[kernel]
 
 
@@ -76,8 +87,9 @@ def step_roofline(P, R_binned, R_ref, npix, seconds_per_step, lambda_dssim=0.0):
             "formula": "P*2751 + R*172 + Npix*84 (+240 with SSIM) + 116 MB (SURVEY 8d); per GPU"}
 
 
-def enable(kernel, on=True):
-    N.check(N.lib().mom_profile_enable(SLOTS[kernel], 1 if on else 0), "mom_profile_enable")
+def enable(kernel, on=True, period=1):
+    """period > 1: time every period-th launch (an event pair costs the stream ~13 us of bubbles, tools/gap_stats.py)."""
+    N.check(N.lib().mom_profile_enable(SLOTS[kernel], (max(1, int(period)) if on else 0)), "mom_profile_enable")
 
 
 def read(kernel, reset=True):
@@ -104,7 +116,7 @@ def roofline(kernel, P, R_binned, Npix, traffic=None, R_ref=None, sq=None):
         flop = float(P) * MFMA_FLOP_PER_GAUSSIAN[kernel]
         tf = flop / avg_s / 1e12
         return {"bound": "mfma", "kernel": kernel, "achieved": tf, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
+                "frac": tf / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt, "launches_are": "the launches timed with HIP events (a sample of the region's launches when bench.py sets a period)",
                 "algorithmic_flop_per_launch": flop, "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
     b = algorithmic_bytes(kernel, P, R_binned, Npix)
     gbs = b / avg_s / 1e9
@@ -114,7 +126,8 @@ def roofline(kernel, P, R_binned, Npix, traffic=None, R_ref=None, sq=None):
         b_ref = algorithmic_bytes(kernel, P, R_ref, Npix)
         hbm.update({"frac_on_reference_R": b_ref / avg_s / 1e9 / HBM_PEAK_GBS, "instances_reference": R_ref,
                     "algorithmic_bytes_on_reference_R": b_ref})
-    common = {"kernel": kernel, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt}
+    common = {"kernel": kernel, "traffic": traffic, "avg_launch_us": avg_s * 1e6, "launches": cnt,
+              "launches_are": "the launches timed with HIP events (a sample of the region's launches when bench.py sets a period)"}
     if kernel in VALU_BOUND:
         out = {"bound": "valu", **common, "hbm": hbm}
         if sq and sq.get("SQ_INSTS_VALU") and sq.get("clock_ghz"):

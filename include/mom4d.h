@@ -437,8 +437,9 @@ int mom_image_to_rgb8(int C, int H, int W, const float* img, uint8_t* out, mom_s
 const char* mom_version(void);
 
 /* Per-kernel HIP-event timing (bench.py's live roofline figure).  Slots: see mom_profile_name(0..15).
- * While a slot is enabled every launch of that kernel is bracketed by two hipEventRecord on the launch stream;
- * mom_profile_read synchronises those events and returns the accumulated time and launch count. */
+ * While a slot is enabled launches of that kernel are bracketed by two hipEventRecord on the launch stream: every launch with
+ * on = 1, every on-th launch with on > 1 (an event pair costs the stream ~13 us of bubbles; a sampled mean costs 1/on of that).
+ * mom_profile_read synchronises those events and returns the accumulated time and the number of launches TIMED. */
 #define MOM_PROF_SLOTS 16
 int mom_profile_enable(int slot, int on);
 int mom_profile_read(int slot, double* total_ms, long long* count, int reset);

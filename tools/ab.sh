@@ -4,7 +4,7 @@
 v=$1; k=${2:-render_bwd}; cfg=${3:-c2}
 for i in 1 2 3; do
   for lib in var/$v.so libmom4d.so; do
-    MOM4D_LIB=iclr2025_3d-mom_amd/lib/$lib MOM4D_LIB_LAX=1 python bench.py --config $cfg --no-cpu-baseline --no-extra --steps 300 --warmup 50 --roofline-kernel $k 2>/dev/null | python -c "
+    MOM4D_LIB=iclr2025_3d-mom_amd/lib/$lib MOM4D_LIB_LAX=1 python bench.py --config $cfg --no-cpu-baseline --no-extra --steps ${STEPS:-300} --warmup ${WARM:-50} --roofline-kernel $k 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 r=d.get('roofline') or {}
