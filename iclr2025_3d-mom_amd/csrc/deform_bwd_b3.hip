@@ -505,7 +505,17 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
     for (int i = 0; i < 3; i++)
         if (!d.dW1[i] || !d.db1[i] || !d.dW2[i] || !d.db2[i]) return MOM_EINVAL;
     const int tiles = (P + 31) / 32;
-    const int blocks = tiles < 256 ? tiles : 256;         // persistent: one workgroup of four role waves per CU
+    // Persistent: one workgroup of four role waves per CU, and each wave takes its SIMD's whole register file -- nothing co-runs on
+    // a CU this kernel holds.  A caller with a second stream (the training step: the appearance parameters' Adam launch is waiting
+    // there) gets 224 workgroups, 28 per XCD: the 32 CUs left over let that HBM-bound launch run UNDER this kernel (2.5 TB/s is all
+    // it needs) instead of beside the HexPlane backward afterwards, whose gather it slowed from 83 to 116 us.  Measured, steps/s at
+    // 256 / 240 / 232 / 224 / 216 / 208 workgroups: config 2 1047 / 1040 / 1035 / 1061 / 1057 / 1054, config 3 285 / 282 / 280 /
+    // 291 / 289 / 287, config 5 91.1 / - / - / 93.1 (a workgroup's tile count steps from 25 to 27 at 240 and to 28 at 224: 240 pays
+    // for too few free CUs).  MOM_B3F_BLOCKS overrides.
+    static int forced_blocks = -1;
+    if (forced_blocks < 0) { const char* e = getenv("MOM_B3F_BLOCKS"); forced_blocks = (e && atoi(e) > 0 && atoi(e) <= 256) ? atoi(e) : 0; }
+    const int max_blocks = forced_blocks ? forced_blocks : (dw_stream != s ? 224 : 256);
+    const int blocks = tiles < max_blocks ? tiles : max_blocks;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
