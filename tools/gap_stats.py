@@ -32,3 +32,10 @@ n = len(starts) - 1
 print(f"steps {n}: wall {wall / n / 1e3:.1f} us, some kernel running {busy / n / 1e3:.1f} us, idle {(wall - busy) / n / 1e3:.1f} us")
 for (a, b), t in gaps.most_common(30):
     print(f"  {t / n / 1e3:6.2f} us/step  ({gapn[(a, b)] / n:.2f} x {t / gapn[(a, b)] / 1e3:5.2f} us)  {a} -> {b}")
+# per-kernel average duration inside the analysed steps
+dur = collections.Counter(); cnt = collections.Counter()
+for s_, e_, name in rows[starts[0]:starts[-1]]:
+    dur[name] += e_ - s_; cnt[name] += 1
+print("kernel: launches per step x average us")
+for name, t in dur.most_common(24):
+    print(f"  {name:34s} {cnt[name] / n:5.2f} x {t / cnt[name] / 1e3:7.1f}")
