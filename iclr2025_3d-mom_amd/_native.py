@@ -281,5 +281,13 @@ def ptr(t):
 
 
 def current_stream():
-    import torch
-    return torch.cuda.current_stream().cuda_stream
+    """The current HIP stream's handle.  (torch.cuda.current_stream() builds a Stream object after four layers of device-index
+    resolution: 10 us a call, and a training step asks a dozen times.)"""
+    global _TC
+    if _TC is None:
+        import torch
+        _TC = torch._C
+    return _TC._cuda_getCurrentRawStream(_TC._cuda_getDevice())
+
+
+_TC = None

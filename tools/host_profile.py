@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--top", type=int, default=30)
+    ap.add_argument("--by-cum", action="store_true", help="sort by cumulative time")
+    ap.add_argument("--async-mode", action="store_true", help="autograd path in the async sync mode (bench.py via_render_api)")
     ap.add_argument("--autograd", action="store_true", help="the render() + loss.backward() path instead of the fused step")
     a = ap.parse_args()
     import torch
@@ -31,6 +33,12 @@ def main():
     cams = trainer.cams
     for c in cams:
         c.device_tensors(torch.device("cuda", 0))      # as bench.py: inputs resident before timing
+
+    if a.autograd and a.async_mode:
+        import importlib
+        DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
+        DGR.set_sync_mode("async", capacity_hint=2_000_000)
+        import gc; gc.collect(); gc.freeze()
 
     def one(i):
         return trainer.step(5001 + (i % 90), cams=[cams[i % len(cams)]])
@@ -48,7 +56,7 @@ def main():
     st.strip_dirs()
     total = sum(v[2] for v in st.stats.values())
     print(f"profiled {a.steps} steps, {total / a.steps * 1e3:.3f} ms/step of host time under the profiler")
-    rows = sorted(st.stats.items(), key=lambda kv: -kv[1][2])[:a.top]
+    rows = sorted(st.stats.items(), key=lambda kv: -kv[1][3 if a.by_cum else 2])[:a.top]
     print(f"{'tottime ms/step':>16s} {'cumtime ms/step':>16s} {'calls/step':>11s}  function")
     for (fn, line, name), (cc, nc, tt, ct, _) in rows:
         print(f"{tt / a.steps * 1e3:16.4f} {ct / a.steps * 1e3:16.4f} {nc / a.steps:11.1f}  {fn}:{line}({name})")
