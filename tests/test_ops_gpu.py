@@ -537,7 +537,34 @@ def test_deform_backward_one_kernel_bf16_equals_the_two_kernel_f32_backward(P, m
         torch.cuda.synchronize()
         return dfeat, grads
 
+    side = torch.cuda.Stream()
+
+    def run_two_streams():
+        """As the training step calls it: a second stream for the weight gradients.  The kernel then takes 224 workgroups (the
+        rest of the chip is the second stream's) and its partial sums are reduced on that stream; the caller joins before reading."""
+        monkeypatch.delenv("MOM_MLP_BWD", raising=False)
+        grads = [torch.zeros_like(p) for p in params]
+        d = ops.DeformMLPFunction._desc(params, grads)
+        pts, sc_d, rot_d, a0 = (torch.empty(P, k, device="cuda") for k in (3, 3, 4, 64))
+        N.check(lib.mom_deform_forward(C.byref(d), P, feat.data_ptr(), xyz.data_ptr(), scal.data_ptr(), rot.data_ptr(),
+                                       flow.data_ptr(), 0.7, pts.data_ptr(), sc_d.data_ptr(), rot_d.data_ptr(), a0.data_ptr(), s), "fwd")
+        dfeat = torch.full((P, 64), float("nan"), device="cuda")
+        scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device="cuda")
+        side.wait_stream(torch.cuda.current_stream())
+        N.check(lib.mom_deform_backward_split(C.byref(d), P, feat.data_ptr(), a0.data_ptr(), dpts.data_ptr(), dsc.data_ptr(),
+                                              drot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s, side.cuda_stream), "bwd")
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return dfeat, grads
+
     f_ref, g_ref = run("split")
+    f_one, g_one = run(None)
+    f_two, g_two = run_two_streams()
+    # the workgroup count changes which tiles a workgroup sums, i.e. the order of the fp32 additions of the weight gradients; dfeat
+    # is per Gaussian and must not move at all
+    assert torch.equal(f_one, f_two)
+    for i, (a, b) in enumerate(zip(g_one, g_two)):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(a.abs().max())), i
     for rep in range(2):
         f_new, g_new = run(None)
         assert torch.isfinite(f_new).all()
