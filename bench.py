@@ -167,7 +167,7 @@ def metric_name():
         return "4DGS train-steps/sec @200k Gaussians, 960\u00d7540, 60 frames; render FPS"
 
 
-def render_fps(scene, g, pp, background, delta_scale, passes=2):
+def render_fps(scene, g, pp, background, delta_scale, passes=8):
     """Second half of the metric: no-grad gaussian_renderer.render() over the reference's 59-pose `side` trajectory
     (render_4DGS.py:88 -> render_set), three ways: `value` = pure (images left on the device: the reference loop without its PNG
     writer); `as_scripted` = the whole of render_set with every frame written as a PNG, through render.py's asynchronous writer;
@@ -184,29 +184,48 @@ def render_fps(scene, g, pp, background, delta_scale, passes=2):
         c.device_tensors(dev)
     cfg_hw = (int(cams[0].image_height), int(cams[0].image_width))
     DGR.set_sync_mode("async")          # size the binning buffer from earlier frames; overflowed frames are rendered again below
+
+    def pure(streams):
+        """`passes` x the trajectory through render(), images left on the device; streams > 1: consecutive frames on alternating
+        streams (gaussian_renderer.set_render_streams, fused_render.FusedRenderPool) -- the mode render.py's render_set uses."""
+        R.set_render_streams(streams)
+        try:
+            with torch.no_grad():
+                for c in (cams * 2)[:12 * streams]:
+                    R.render(c, g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)
+                fr = g._fused_render_pool if streams > 1 else g._fused_render
+                fr.overflowed()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(passes):
+                    for c in cams:
+                        out = R.render(c, g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)["render"]
+                bad = fr.overflowed()                       # waits for every frame's flag
+                R.set_render_streams(1)
+                for _ in bad:                               # an overflowed frame counts only once it has been rendered completely
+                    DGR.set_sync_mode("exact")
+                    out = R.render(cams[0], g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)["render"]
+                    DGR.set_sync_mode("async")
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            assert torch.isfinite(out).all()
+            return passes * len(cams), dt, len(bad)
+        finally:
+            R.set_render_streams(1)
+
     try:
-        with torch.no_grad():
-            for c in cams[:8]:
-                R.render(c, g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)
-            fr = g._fused_render
-            fr.overflowed()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(passes):
-                for c in cams:
-                    out = R.render(c, g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)["render"]
-            bad = fr.overflowed()                       # waits for every frame's flag
-            for _ in bad:                               # an overflowed frame counts only once it has been rendered completely
-                DGR.set_sync_mode("exact")
-                out = R.render(cams[0], g, pp, background, stage="fine", cam_type=scene.dataset_type, delta_scale=delta_scale)["render"]
-                DGR.set_sync_mode("async")
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        assert torch.isfinite(out).all()
-        n = passes * len(cams)
-        res = {"value": n / dt, "unit": "frames/s", "frames": n, "ms_per_frame": 1e3 * dt / n, "frames_rendered_again": len(bad),
+        n1, dt1, bad1 = pure(1)
+        n, dt, bad = pure(own.RENDER_STREAMS)
+        res = {"value": n / dt, "unit": "frames/s", "frames": n, "ms_per_frame": 1e3 * dt / n, "frames_rendered_again": bad,
+               "streams": own.RENDER_STREAMS,
                "trajectory": "side, 59 poses (test_trajectory/side_{R,t}_list, last pose dropped)",
-               "mode": "no-grad render(), deformation on, images kept on the device (no PNG writer)"}
+               "mode": "no-grad render(), deformation on, images kept on the device (no PNG writer); consecutive frames on "
+                       f"{own.RENDER_STREAMS} alternating streams (gaussian_renderer.set_render_streams: the mode render.py's "
+                       "render_set runs in), every frame complete before the clock stops",
+               "one_stream": {"value": n1 / dt1, "unit": "frames/s", "frames": n1, "ms_per_frame": 1e3 * dt1 / n1,
+                              "frames_rendered_again": bad1,
+                              "what": "render()'s default: every frame on the caller's current stream, as an unchanged "
+                                      "render_4DGS.py drives it"}}
         tmp = tempfile.mkdtemp(prefix="mom_bench_render_")
         try:
             # one writer for the whole script, as render_sets() would keep it over its four trajectories: pinned ring and encoder

@@ -65,7 +65,8 @@ class FusedRender:
             self.cap_floor = max(getattr(self, "cap_floor", 0), 2 * self.cap)
         return bad
 
-    def render(self, cam, bg, delta_scale, scaling_modifier=1.0, debug=False):
+    def render(self, cam, bg, delta_scale, scaling_modifier=1.0, debug=False, order=False):
+        """order: the field's processing order if the caller already has it (FusedRenderPool takes it on the caller's stream)."""
         g, lib, s = self.g, self.lib, N.current_stream()
         dev = g._xyz.device
         P = g._xyz.shape[0]
@@ -76,7 +77,8 @@ class FusedRender:
         field = dn.grid
         xyz, scal, rot, opac = g._xyz.detach(), g._scaling.detach(), g._rotation.detach(), g._opacity.detach()
         flow = g._scene_flow if g._scene_flow.is_contiguous() else g._scene_flow.contiguous()
-        order = field._processing_order(xyz)
+        if order is False:
+            order = field._processing_order(xyz)
         planes = [p for lv in field.grids for p in lv]
         mlp = dn._fused_params()
         dkey = (tuple(p.data_ptr() for p in planes + mlp), tuple(field.aabb_host()))
@@ -137,3 +139,87 @@ class FusedRender:
             ev.record()
             self.pending.append((self.serial, slot, ev))
         return color, depth, radii
+
+
+class FusedRenderPool:
+    """Consecutive frames on n alternating streams (gaussian_renderer.set_render_streams(n), n > 1).
+
+    A frame's deformation field, projection and binning are short kernels bound by latency (three waves per SIMD for 20 us at a
+    time); its compositing kernel is bound by vector issue and fills the chip.  One stream runs them strictly one after the other:
+    276 us per frame at config 2.  Frames are independent, so the next frame's front half can run while this frame composites, if
+    it is on another stream with its own scratch: 3715 -> 5290 frames/s with two streams, 5720 with three (tools/probe/
+    fps_two_streams.py).  Every slot is a FusedRender of its own (geometry / image / binning state, capacity bookkeeping, overflow
+    ring); the model's tensors are shared and only read.
+
+    What the caller must know: a frame is produced on ITS SLOT'S stream and render() does not make the caller's stream wait for it
+    (that wait would chain every frame behind the one before).  render() returns the stream and an event (`"stream"`, `"ready"`
+    in gaussian_renderer.render()'s dict): consume the frame inside `with torch.cuda.stream(out["stream"])`, or after
+    `torch.cuda.current_stream().wait_event(out["ready"])` (+ `tensor.record_stream(...)` if it is kept past its next use on the
+    slot's stream), or after a device synchronisation.  That is why the mode is opt-in: the reference's own loop reads the image
+    with `.cpu()` right away (render_4DGS.py:64), which only waits for the current stream."""
+
+    def __init__(self, gaussians, n):
+        self.g = gaussians
+        self.n = int(n)
+        self.slots = [FusedRender(gaussians) for _ in range(self.n)]
+        self.streams = [torch.cuda.Stream(device=gaussians._xyz.device) for _ in range(self.n)]
+        self.count = 0               # frames rendered so far (the next frame's global index)
+        self._where = {}             # (slot, the slot's serial after the frame) -> global frame index
+        self.bad = []
+
+    @property
+    def collect(self):
+        return self.slots[0].collect
+
+    @collect.setter
+    def collect(self, v):
+        for sl in self.slots:
+            sl.collect = v
+            if v:
+                sl.bad = []
+
+    def render(self, cam, bg, delta_scale, scaling_modifier=1.0, debug=False):
+        g = self.g
+        k = self.count % self.n
+        sl, st = self.slots[k], self.streams[k]
+        dev = g._xyz.device
+        # whatever is created lazily and cached for later frames is created on the CALLER's stream, which the slot's stream then
+        # waits for: the camera's device copies, the field's processing order (rebuilt every 64 calls)
+        cam.device_tensors(dev)
+        order = g._deformation.deformation_net.grid._processing_order(g._xyz.detach())
+        # ... but only if that stream has anything pending: a marker on it per frame puts traffic on its hardware queue, which one of
+        # the slots' streams may share (four hardware queues per device: after a training run -- two streams -- a three-slot pool
+        # fell from 5700 to 4400 frames/s through such a collision)
+        cur = torch.cuda.current_stream(dev)
+        if not cur.query():
+            st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            color, depth, radii = sl.render(cam, bg, delta_scale, scaling_modifier, debug, order=order)
+            visible = radii > 0
+            ev = torch.cuda.Event()
+            ev.record(st)
+        self._where[(k, sl.serial)] = self.count
+        if len(self._where) > 4096:
+            for key in list(self._where)[:2048]:
+                del self._where[key]
+        self.count += 1
+        return color, depth, radii, visible, st, ev
+
+    def zero_points(self):
+        """The `viewspace_points` of a no-grad frame: zeros of the model's shape (gaussian_renderer/__init__.py:36 of the
+        reference makes them per call; nobody writes them without a backward).  One tensor per model size, made once: a fill kernel
+        per frame on the caller's stream is the kind of traffic render() above avoids."""
+        z = getattr(self, "_zeros", None)
+        if z is None or z.shape != self.g._xyz.shape or z.device != self.g._xyz.device:
+            z = self._zeros = torch.zeros_like(self.g._xyz)
+        return z
+
+    def overflowed(self, lag=0):
+        """Global indices (FusedRenderPool.count at the time of the render() that produced them) of the async-mode frames whose
+        binning buffer overflowed: FusedRender.overflowed() of every slot, plus what the slots collected meanwhile."""
+        out = []
+        for k, sl in enumerate(self.slots):
+            serials = list(sl.bad) + sl.overflowed(lag)
+            sl.bad = []
+            out += [self._where[(k, s)] for s in serials if (k, s) in self._where]
+        return sorted(out)

