@@ -489,6 +489,279 @@ deform_bwd_b3f_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
     }
 }
 
+
+// ===========================================================================================================================
+// Variant "b3g" (MOM_MLP_BWD=b3g): EIGHT role waves per workgroup, two per SIMD.  The one-wave-per-SIMD kernel above exposes
+// nearly all of its MFMA time (ablation: 41 of 43 us) and every LDS / memory round trip, because a wave cannot issue its vector
+// instructions under its own dependent MFMAs.  Here every role is cut in two along its data flow, and the two halves -- waves w
+// and w + 4, which the hardware places on the same SIMD -- work on consecutive tiles at the same time:
+//   head k, wave A (k):      a1 = relu(W1_k a0 + b1_k) [W1_k fragments in registers], dW2_k / db2_k, dH1_k; stages dH1_k^T for B
+//   head k, wave B (k + 4):  dA0_k = W1_k^T dH1_k [fragments from LDS] -> added into the trunk's slot; dW1_k += dH1_k^T a0, db1_k
+//   trunk,  wave A (3):      dH0 = relu'(a0) (sum of the heads' dA0); stages dH0^T for B; dfeat = W0^T dH0 [fragments in registers]
+//   trunk,  wave B (7):      dW0 += dH0^T feat, db0
+// A role half fits 256 registers (no wave holds more than one fragment set AND one 64 x 64 weight-gradient tile), and LDS holds one
+// staging area per hand-over instead of one per wave: 148 KB.  Hand-overs are single-buffered: the producer works a tile ahead in
+// registers and waits for the consumer's release only before it stages.  The heads' dA0 meet in one slot in a fixed order (below).
+constexpr int kG_OffFrag = 0;                                   // W1_k^T fragments, k = 0..2
+constexpr int kG_OffSA = kG_OffFrag + 3 * kFragU4 * 16;         // [3 heads][64][kXS] a1^T: private to the head's A wave
+constexpr int kG_OffSH = kG_OffSA + 3 * 64 * kXS * 4;           // [3 heads][64][kXS] dH1^T: A -> B
+constexpr int kG_OffST = kG_OffSH + 3 * 64 * kXS * 4;           // [64][kXS] dH0^T: trunk A -> trunk B
+constexpr int kG_OffXch = kG_OffST + 64 * kXS * 4;              // [32 values][64 lanes] floats: the sum of the heads' dA0
+constexpr int kG_OffDout = kG_OffXch + 32 * 64 * 4;             // [3 heads][32][4] floats
+constexpr int kG_OffW2 = kG_OffDout + 3 * 32 * 4 * 4;           // [3][4][64] floats (rows >= nout zero)
+constexpr int kG_OffB1 = kG_OffW2 + 3 * 4 * 64 * 4;             // [3][64] floats
+constexpr int kG_OffFlag = kG_OffB1 + 3 * 64 * 4;               // pubA[3] relB[3] pubB[3] relT pubTA relTB
+constexpr int kG_LdsBytes = kG_OffFlag + 64;
+static_assert(kG_LdsBytes <= 160 * 1024, "the eight-wave MLP backward must fit a CU's LDS");
+enum { kF_PubA = 0, kF_RelB = 3, kF_PubB = 6, kF_RelT = 9, kF_PubTA = 10, kF_RelTB = 11 };
+
+// dW += dH^T X for one tile: A from the staged dH^T, B from the rows requested at the top of the tile; db += row sums of dH
+__device__ __forceinline__ void dw_phase(const float* __restrict__ sH, const XRows& xr, f32x16 (&dW)[2][2], float (&db)[2], int col, int h)
+{
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+        Frag3 A[2], B[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) A[mt] = dw_a_frag(sH, mt, ks, col, h, db[mt]);
+#pragma unroll
+        for (int nt = 0; nt < 2; nt++) B[nt] = split8(xr.v[nt][ks]);
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) dW[mt][nt] = mfma6(A[mt], B[nt], dW[mt][nt]);
+    }
+}
+
+__global__ void __launch_bounds__(512, 1)
+deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ a0g,
+                      const float* __restrict__ dpts, const float* __restrict__ dscales, const float* __restrict__ drots,
+                      float* __restrict__ dfeat, float* __restrict__ parts)
+{
+    float* __restrict__ part = parts + (size_t)blockIdx.x * kPartFloats;
+    extern __shared__ char lds_raw[];
+    uint4* fragT = reinterpret_cast<uint4*>(lds_raw + kG_OffFrag);
+    float* xch = reinterpret_cast<float*>(lds_raw + kG_OffXch);
+    float* sW2 = reinterpret_cast<float*>(lds_raw + kG_OffW2);
+    float* sB1 = reinterpret_cast<float*>(lds_raw + kG_OffB1);
+    int* flags = reinterpret_cast<int*>(lds_raw + kG_OffFlag);
+    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int pair = wv & 3, half = wv >> 2;               // waves w and w + 4 share a SIMD
+
+    // ---- prologue, all eight waves
+    for (int slot = threadIdx.x; slot < 3 * 2 * 4 * 64; slot += 512) {
+        const int k = slot >> 9, mt = (slot >> 8) & 1, s = (slot >> 6) & 3, ln = slot & 63;
+        const int mrow = 32 * mt + (ln & 31), k0 = 16 * s + 4 * (ln >> 5);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = m.W1[k][(k0 + (j & 3) + 8 * (j >> 2)) * kHid + mrow];
+        const Frag3 f = split8(v);
+#pragma unroll
+        for (int p = 0; p < 3; p++) fragT[k * kFragU4 + ((p * 2 + mt) * 4 + s) * 64 + ln] = f.p[p];
+    }
+    for (int i = threadIdx.x; i < 3 * 4 * kHid; i += 512) {
+        const int head = i >> 8, n = (i >> 6) & 3;
+        const int nout = head == 2 ? 4 : 3;
+        sW2[i] = n < nout ? m.W2[head][n * kHid + (i & 63)] : 0.f;
+    }
+    if (threadIdx.x < 3 * kHid) sB1[threadIdx.x] = m.b1[threadIdx.x >> 6][threadIdx.x & 63];
+    if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+    __syncthreads();
+
+    const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
+
+    if (pair < 3 && half == 0) {
+        // =================================================================================== head k, wave A
+        const int k = pair, nout = k == 2 ? 4 : 3;
+        const float* __restrict__ dsrc = k == 0 ? dpts : (k == 1 ? dscales : drots);
+        float* sA = reinterpret_cast<float*>(lds_raw + kG_OffSA) + k * 64 * kXS;
+        float* sH = reinterpret_cast<float*>(lds_raw + kG_OffSH) + k * 64 * kXS;
+        float* sD = reinterpret_cast<float*>(lds_raw + kG_OffDout) + k * 32 * 4;
+        const float* __restrict__ W2l = sW2 + k * 4 * kHid;
+        Frag3 wf[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const float* row = m.W1[k] + (32 * mt + col) * kHid + 16 * s + 4 * h;
+                const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                wf[mt][s] = split8(v);
+            }
+        float dW2[4] = {0.f, 0.f, 0.f, 0.f}, db2[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x16 a0n[2];
+        if (t_begin < t_end) load_feat(a0g, t_begin * 32 + col, t_begin * 32 + col < P, h, a0n);
+        for (int t = t_begin; t < t_end; t++) {
+            const int g = t * 32 + col;
+            const bool ok = g < P;
+            float dout[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) dout[q] = (ok && q < nout) ? dsrc[nout * g + q] : 0.f;
+            f32x16 a1[2];
+            {
+                Frag3 Ba0[4];
+                split_tile<false>(a0n, Ba0);
+                init_bias(sB1 + k * kHid, a1, h);
+                layer_regs(wf, Ba0, a1);
+            }
+            if (t + 1 < t_end) load_feat(a0g, (t + 1) * 32 + col, (t + 1) * 32 + col < P, h, a0n);
+            relu_tile(a1);
+            __builtin_amdgcn_wave_barrier();
+            stage36(sA, a1, col, h);                         // a1^T: read back by this wave only (dW2 below)
+            if (h == 0) *reinterpret_cast<float4*>(sD + 4 * col) = make_float4(dout[0], dout[1], dout[2], dout[3]);
+            __builtin_amdgcn_wave_barrier();
+            // dH1 = relu'(h1) * W2^T dout, in place of a1
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float4 wa = *reinterpret_cast<const float4*>(W2l + 0 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float4 wb = *reinterpret_cast<const float4*>(W2l + 1 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float4 wc = *reinterpret_cast<const float4*>(W2l + 2 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float4 wd = *reinterpret_cast<const float4*>(W2l + 3 * kHid + 32 * mt + 8 * q + 4 * h);
+                    const float v0 = wa.x * dout[0] + wb.x * dout[1] + wc.x * dout[2] + wd.x * dout[3];
+                    const float v1 = wa.y * dout[0] + wb.y * dout[1] + wc.y * dout[2] + wd.y * dout[3];
+                    const float v2 = wa.z * dout[0] + wb.z * dout[1] + wc.z * dout[2] + wd.z * dout[3];
+                    const float v3 = wa.w * dout[0] + wb.w * dout[1] + wc.w * dout[2] + wd.w * dout[3];
+                    a1[mt][4 * q + 0] = a1[mt][4 * q + 0] > 0.f ? v0 : 0.f;
+                    a1[mt][4 * q + 1] = a1[mt][4 * q + 1] > 0.f ? v1 : 0.f;
+                    a1[mt][4 * q + 2] = a1[mt][4 * q + 2] > 0.f ? v2 : 0.f;
+                    a1[mt][4 * q + 3] = a1[mt][4 * q + 3] > 0.f ? v3 : 0.f;
+                }
+            wait_ge(flags + kF_RelB + k, t - t_begin);       // wave B has finished with the previous tile's dH1^T
+            stage36(sH, a1, col, h);
+            st_release(flags + kF_PubA + k, t - t_begin + 1);
+            {   // output layer: dW2[n][f] += sum_g dout[n][g] a1[f][g]   (lane = f);  db2[n] += dout[n][this lane's Gaussian]
+#pragma unroll
+                for (int q = 0; q < 4; q++) db2[q] += dout[q];
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
+#pragma unroll
+                for (int g4 = 0; g4 < 32; g4 += 4) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(sA + lane * kXS + g4);
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float4 d = *reinterpret_cast<const float4*>(sD + 4 * (g4 + u));
+                        w0 += d.x * vv[u]; w1 += d.y * vv[u]; w2 += d.z * vv[u]; w3 += d.w * vv[u];
+                    }
+                }
+                dW2[0] += w0; dW2[1] += w1; dW2[2] += w2; dW2[3] += w3;
+            }
+        }
+        float* thin = part + 4 * kPartLayer + k * kPartThin;
+#pragma unroll
+        for (int n = 0; n < 4; n++) thin[n * kHid + lane] = dW2[n];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            float b = db2[q];
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) b += __shfl_xor(b, d);
+            if (lane == 0) thin[4 * kHid + q] = b;
+        }
+    } else if (pair < 3) {
+        // =================================================================================== head k, wave B
+        const int k = pair;
+        const float* sH = reinterpret_cast<const float*>(lds_raw + kG_OffSH) + k * 64 * kXS;
+        const uint4* __restrict__ wT = fragT + k * kFragU4;
+        f32x16 dW[2][2];
+        float db[2] = {0.f, 0.f};
+        zero_tile(dW[0]);
+        zero_tile(dW[1]);
+        for (int t = t_begin; t < t_end; t++) {
+            XRows xr;
+            x_request(a0g, t, P, col, h, xr);               // a0 in the weight gradient's layout, used at the end of the tile
+            wait_ge(flags + kF_PubA + k, t - t_begin + 1);
+            f32x16 dA0[2];
+            zero_tile(dA0);
+            {
+                // the B operand of W1_k^T dH1: K-step s holds the features 16 s + 4 h + (j & 3) + 8 (j >> 2), j = 0..7 -- read from the
+                // staged transposed copy, eight dwords per K-step
+                Frag3 Bd[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = sH[(16 * s + 4 * h + (j & 3) + 8 * (j >> 2)) * kXS + col];
+                    Bd[s] = split8(v);
+                }
+                layer_lds(wT, Bd, dA0, lane);
+            }
+            // The three heads' dA0 meet in ONE slot, in a fixed order: head 0 writes (once the trunk has read the previous tile's sum),
+            // head 1 adds to it, head 2 adds to that -- (d0 + d1) + d2, the one-wave kernel's order, bit for bit.  (Three slots do not
+            // fit beside the staging areas; ds_add_f32 from the three waves at once cost 160 us per launch: LDS float atomics.)
+            if (k == 0) {
+                wait_ge(flags + kF_RelT, t - t_begin);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) xch[(mt * 16 + r) * 64 + lane] = dA0[mt][r];
+            } else {
+                wait_ge(flags + kF_PubB + k - 1, t - t_begin + 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) xch[(mt * 16 + r) * 64 + lane] += dA0[mt][r];
+            }
+            st_release(flags + kF_PubB + k, t - t_begin + 1);
+            dw_phase(sH, xr, dW, db, col, h);
+            st_release(flags + kF_RelB + k, t - t_begin + 1);
+        }
+        flush_dw(part + (1 + k) * kPartLayer, dW, db, col, h);
+    } else if (half == 0) {
+        // =================================================================================== trunk, wave A
+        float* sT = reinterpret_cast<float*>(lds_raw + kG_OffST);
+        Frag3 wf[2][4];
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = m.W0[(16 * s + 4 * h + (j & 3) + 8 * (j >> 2)) * kHid + 32 * mt + col];
+                wf[mt][s] = split8(v);
+            }
+        f32x16 a0n[2];
+        if (t_begin < t_end) load_feat(a0g, t_begin * 32 + col, t_begin * 32 + col < P, h, a0n);
+        for (int t = t_begin; t < t_end; t++) {
+            const int g = t * 32 + col;
+            const bool ok = g < P;
+            wait_ge(flags + kF_PubB + 2, t - t_begin + 1);   // head 2 adds last
+            f32x16 dH0[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) dH0[mt][r] = a0n[mt][r] > 0.f ? xch[(mt * 16 + r) * 64 + lane] : 0.f;
+            st_release(flags + kF_RelT, t - t_begin + 1);    // head 0 may write the next tile's
+            if (t + 1 < t_end) load_feat(a0g, (t + 1) * 32 + col, (t + 1) * 32 + col < P, h, a0n);
+            wait_ge(flags + kF_RelTB, t - t_begin);          // wave B has finished with the previous tile's dH0^T
+            stage36(sT, dH0, col, h);
+            st_release(flags + kF_PubTA, t - t_begin + 1);
+            {
+                Frag3 Bd[4];
+                split_tile<false>(dH0, Bd);
+                f32x16 df[2];
+                zero_tile(df);
+                layer_regs(wf, Bd, df);                     // dfeat = W0^T dH0
+                store_feat(dfeat, g, ok, h, df);
+            }
+        }
+    } else {
+        // =================================================================================== trunk, wave B
+        const float* sT = reinterpret_cast<const float*>(lds_raw + kG_OffST);
+        f32x16 dW[2][2];
+        float db[2] = {0.f, 0.f};
+        zero_tile(dW[0]);
+        zero_tile(dW[1]);
+        for (int t = t_begin; t < t_end; t++) {
+            XRows xr;
+            x_request(feat, t, P, col, h, xr);
+            wait_ge(flags + kF_PubTA, t - t_begin + 1);
+            dw_phase(sT, xr, dW, db, col, h);
+            st_release(flags + kF_RelTB, t - t_begin + 1);
+        }
+        flush_dw(part, dW, db, col, h);
+    }
+}
+
 }  // namespace
 
 // The entry point deform_mlp.hip's mom_deform_backward_split dispatches to by default (MOM_MLP_BWD unset or "b3").  (It takes the
@@ -523,7 +796,19 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
             return MOM_ELAUNCH;
         attr_set = true;
     }
+    static int eight = -1;               // MOM_B3_EIGHT=1: the eight-wave variant (deform_bwd_b3g_kernel)
+    if (eight < 0) {
+        const char* e = getenv("MOM_B3_EIGHT");
+        eight = (e && e[0] == '1') ? 1 : 0;
+        if (eight && hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         kG_LdsBytes) != hipSuccess)
+            return MOM_ELAUNCH;
+    }
     MomProfScope ps(MOM_P_MLP_BWD, s);
+    if (eight)
+        hipLaunchKernelGGL(deform_bwd_b3g_kernel, dim3(blocks), dim3(512), kG_LdsBytes, s, d, P, tiles, feat, a0, dpts, dscales, drots, dfeat,
+                           (float*)scratch);
+    else
     hipLaunchKernelGGL(deform_bwd_b3f_kernel, dim3(blocks), dim3(256), kLdsBytes, s, d, P, tiles, feat, a0, dpts, dscales, drots, dfeat,
                        (float*)scratch);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
