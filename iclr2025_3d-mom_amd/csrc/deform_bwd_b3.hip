@@ -11,7 +11,8 @@
 //   round 3's one-kernel f32 form: no dH traffic, but all 640 v_mfma_f32_32x32x2_f32 of a tile on one wave's critical path,
 //                              and that instruction blocks the SIMD's vector ALU: 266 us against 183;
 //   here:  the fp32-exact three-way bf16 split of deform_field.hip's forward (six v_mfma_f32_32x32x16_bf16 per product block,
-//          0.375 of the f32 matrix cycles, vector ALU free meanwhile) and FOUR ROLES, one wave per SIMD:
+//          0.375 of the f32 matrix cycles, vector ALU free meanwhile) and FOUR ROLES.  Two kernels: deform_bwd_b3f_kernel -- one wave per
+//          role and SIMD, described here -- and, the default, deform_bwd_b3g_kernel further down, which cuts every role in two:
 //            waves 0-2, "head k":  a1 = relu(W1_k a0 + b1_k) recomputed, dW2_k / db2_k, dH1_k = relu'(.) W2_k^T dout_k,
 //                                  dA0_k = W1_k^T dH1_k handed to the trunk wave through LDS, dW1_k += dH1_k^T a0, db1_k;
 //            wave 3, "trunk":      dH0 = relu'(a0) (dA0_0 + dA0_1 + dA0_2), dfeat = W0^T dH0, dW0 += dH0^T feat, db0.
@@ -194,7 +195,10 @@ __device__ __forceinline__ void wait_ge(const int* p, int v)
 #ifdef B3F_NO_SYNC
     return;
 #endif
-    while (__builtin_amdgcn_readfirstlane(ld_acquire(p)) < v) __builtin_amdgcn_s_sleep(2);
+#ifndef B3_SLEEP
+#define B3_SLEEP 2
+#endif
+    while (__builtin_amdgcn_readfirstlane(ld_acquire(p)) < v) __builtin_amdgcn_s_sleep(B3_SLEEP);
 }
 
 #ifdef B3F_STAMPS
@@ -491,7 +495,7 @@ deform_bwd_b3f_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
 
 
 // ===========================================================================================================================
-// Variant "b3g" (MOM_MLP_BWD=b3g): EIGHT role waves per workgroup, two per SIMD.  The one-wave-per-SIMD kernel above exposes
+// The default kernel (MOM_B3_EIGHT=0 selects the four-wave one above): EIGHT role waves per workgroup, two per SIMD.  The one-wave-per-SIMD kernel above exposes
 // nearly all of its MFMA time (ablation: 41 of 43 us) and every LDS / memory round trip, because a wave cannot issue its vector
 // instructions under its own dependent MFMAs.  Here every role is cut in two along its data flow, and the two halves -- waves w
 // and w + 4, which the hardware places on the same SIMD -- work on consecutive tiles at the same time:
@@ -502,6 +506,10 @@ deform_bwd_b3f_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
 // A role half fits 256 registers (no wave holds more than one fragment set AND one 64 x 64 weight-gradient tile), and LDS holds one
 // staging area per hand-over instead of one per wave: 148 KB.  Hand-overs are single-buffered: the producer works a tile ahead in
 // registers and waits for the consumer's release only before it stages.  The heads' dA0 meet in one slot in a fixed order (below).
+// Where the cut goes was measured (-DB3G_STAMPS: cycles alive / polling per role wave): as above, the head's wave A is active 78 % of
+// a tile and its wave B 88 %, the trunk's waves 40 %: 150-158 us.  dW2_k formed by the trunk's wave B instead: wave A drops to 53 %,
+// the kernel stays at 158 (wave B's chain is the bound).  dA0_k formed by wave A from the registers dH1 is in (no scalar re-read by B):
+// wave A 80 %, wave B 49 %, 170 us -- the longer chain is what counts, not the SIMD's total.
 constexpr int kG_OffFrag = 0;                                   // W1_k^T fragments, k = 0..2
 constexpr int kG_OffSA = kG_OffFrag + 3 * kFragU4 * 16;         // [3 heads][64][kXS] a1^T: private to the head's A wave
 constexpr int kG_OffSH = kG_OffSA + 3 * 64 * kXS * 4;           // [3 heads][64][kXS] dH1^T: A -> B
@@ -532,6 +540,11 @@ __device__ __forceinline__ void dw_phase(const float* __restrict__ sH, const XRo
     }
 }
 
+#ifdef B3G_STAMPS      // per role wave: cycles alive and cycles spent polling a hand-over flag (tools/probe/b3f_stamps.py)
+#define G_WAIT(p, v) do { const unsigned long long w0_ = __builtin_amdgcn_s_memtime(); wait_ge(p, v); waited_ += __builtin_amdgcn_s_memtime() - w0_; } while (0)
+#else
+#define G_WAIT(p, v) wait_ge(p, v)
+#endif
 __global__ void __launch_bounds__(512, 1)
 deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ a0g,
                       const float* __restrict__ dpts, const float* __restrict__ dscales, const float* __restrict__ drots,
@@ -568,6 +581,10 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
     __syncthreads();
 
     const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
+#ifdef B3G_STAMPS
+    unsigned long long waited_ = 0;
+    const unsigned long long start_ = __builtin_amdgcn_s_memtime();
+#endif
 
     if (pair < 3 && half == 0) {
         // =================================================================================== head k, wave A
@@ -627,7 +644,7 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
                     a1[mt][4 * q + 2] = a1[mt][4 * q + 2] > 0.f ? v2 : 0.f;
                     a1[mt][4 * q + 3] = a1[mt][4 * q + 3] > 0.f ? v3 : 0.f;
                 }
-            wait_ge(flags + kF_RelB + k, t - t_begin);       // wave B has finished with the previous tile's dH1^T
+            G_WAIT(flags + kF_RelB + k, t - t_begin);       // wave B has finished with the previous tile's dH1^T
             stage36(sH, a1, col, h);
             st_release(flags + kF_PubA + k, t - t_begin + 1);
             {   // output layer: dW2[n][f] += sum_g dout[n][g] a1[f][g]   (lane = f);  db2[n] += dout[n][this lane's Gaussian]
@@ -669,7 +686,7 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
         for (int t = t_begin; t < t_end; t++) {
             XRows xr;
             x_request(a0g, t, P, col, h, xr);               // a0 in the weight gradient's layout, used at the end of the tile
-            wait_ge(flags + kF_PubA + k, t - t_begin + 1);
+            G_WAIT(flags + kF_PubA + k, t - t_begin + 1);
             f32x16 dA0[2];
             zero_tile(dA0);
             {
@@ -689,13 +706,13 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
             // head 1 adds to it, head 2 adds to that -- (d0 + d1) + d2, the one-wave kernel's order, bit for bit.  (Three slots do not
             // fit beside the staging areas; ds_add_f32 from the three waves at once cost 160 us per launch: LDS float atomics.)
             if (k == 0) {
-                wait_ge(flags + kF_RelT, t - t_begin);
+                G_WAIT(flags + kF_RelT, t - t_begin);
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) xch[(mt * 16 + r) * 64 + lane] = dA0[mt][r];
             } else {
-                wait_ge(flags + kF_PubB + k - 1, t - t_begin + 1);
+                G_WAIT(flags + kF_PubB + k - 1, t - t_begin + 1);
 #pragma unroll
                 for (int mt = 0; mt < 2; mt++)
 #pragma unroll
@@ -724,7 +741,7 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
         for (int t = t_begin; t < t_end; t++) {
             const int g = t * 32 + col;
             const bool ok = g < P;
-            wait_ge(flags + kF_PubB + 2, t - t_begin + 1);   // head 2 adds last
+            G_WAIT(flags + kF_PubB + 2, t - t_begin + 1);   // head 2 adds last
             f32x16 dH0[2];
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
@@ -732,7 +749,7 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
                 for (int r = 0; r < 16; r++) dH0[mt][r] = a0n[mt][r] > 0.f ? xch[(mt * 16 + r) * 64 + lane] : 0.f;
             st_release(flags + kF_RelT, t - t_begin + 1);    // head 0 may write the next tile's
             if (t + 1 < t_end) load_feat(a0g, (t + 1) * 32 + col, (t + 1) * 32 + col < P, h, a0n);
-            wait_ge(flags + kF_RelTB, t - t_begin);          // wave B has finished with the previous tile's dH0^T
+            G_WAIT(flags + kF_RelTB, t - t_begin);          // wave B has finished with the previous tile's dH0^T
             stage36(sT, dH0, col, h);
             st_release(flags + kF_PubTA, t - t_begin + 1);
             {
@@ -754,12 +771,19 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
         for (int t = t_begin; t < t_end; t++) {
             XRows xr;
             x_request(feat, t, P, col, h, xr);
-            wait_ge(flags + kF_PubTA, t - t_begin + 1);
+            G_WAIT(flags + kF_PubTA, t - t_begin + 1);
             dw_phase(sT, xr, dW, db, col, h);
             st_release(flags + kF_RelTB, t - t_begin + 1);
         }
         flush_dw(part, dW, db, col, h);
     }
+#ifdef B3G_STAMPS
+    if (lane == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(parts + (size_t)256 * kPartFloats) + ((size_t)blockIdx.x * 8 + wv) * 2;
+        dbg[0] = __builtin_amdgcn_s_memtime() - start_;
+        dbg[1] = waited_;
+    }
+#endif
 }
 
 }  // namespace
@@ -796,10 +820,10 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
             return MOM_ELAUNCH;
         attr_set = true;
     }
-    static int eight = -1;               // MOM_B3_EIGHT=1: the eight-wave variant (deform_bwd_b3g_kernel)
+    static int eight = -1;               // the eight-wave kernel (deform_bwd_b3g_kernel) by default; MOM_B3_EIGHT=0: the four-wave one
     if (eight < 0) {
         const char* e = getenv("MOM_B3_EIGHT");
-        eight = (e && e[0] == '1') ? 1 : 0;
+        eight = (e && e[0] == '0') ? 0 : 1;
         if (eight && hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          kG_LdsBytes) != hipSuccess)
             return MOM_ELAUNCH;

@@ -31,6 +31,16 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 print("kernel + reduce, alone: %.1f us per launch" % (e0.elapsed_time(e1) * 1e3 / 20))
+if os.environ.get("MOM4D_LIB", "").endswith("gstamps.so"):
+    # the eight-wave variant (-DB3G_STAMPS): per role wave, cycles alive and cycles spent polling a hand-over flag
+    part_floats = 4 * (64 * 64 + 64) + 3 * (4 * 64 + 4)
+    off = 256 * part_floats * 4
+    dbg = scratch[off:off + 256 * 8 * 2 * 8].cpu().numpy().view(np.uint64).reshape(256, 8, 2).astype(np.float64)
+    tiles = (P + 31) // 32 / 256
+    for w, name in enumerate(["head0 A", "head1 A", "head2 A", "trunk A", "head0 B", "head1 B", "head2 B", "trunk B"]):
+        tot, wait = np.median(dbg[:, w, 0]) / tiles, np.median(dbg[:, w, 1]) / tiles
+        print(f"{name}: {tot:.0f} cycles per tile, of which {wait:.0f} polling ({100 * wait / tot:.0f} %)")
+    sys.exit(0)
 if not os.environ.get("MOM4D_LIB", "").endswith("stamps.so"):
     sys.exit(0)
 part_floats = 4 * (64 * 64 + 64) + 3 * (4 * 64 + 4)
