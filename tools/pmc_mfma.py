@@ -24,7 +24,7 @@ import sys
 SIMDS = 256 * 4
 P = 200_000
 # dx: three recomputed head layers + three W1^T + W0^T = seven 64x64 layers per Gaussian (the thin output layers run on the VALU)
-FLOP = {"deform_bwd_b3f_kernel": 0, "deform_fwd_kernel": 34_048 * P, "deform_field_fwd_kernel": 34_048 * P, "deform_field_fwd_b3_kernel": 0, "deform_bwd_dx_kernel": 7 * 2 * 64 * 64 * P, "deform_bwd_dw_kernel": 4 * 2 * 64 * 64 * P}
+FLOP = {"deform_bwd_b3f_kernel": 0, "deform_bwd_b3g_kernel": 0, "deform_fwd_kernel": 34_048 * P, "deform_field_fwd_kernel": 34_048 * P, "deform_field_fwd_b3_kernel": 0, "deform_bwd_dx_kernel": 7 * 2 * 64 * 64 * P, "deform_bwd_dw_kernel": 4 * 2 * 64 * 64 * P}
 
 
 def main():
@@ -41,7 +41,7 @@ def main():
         if m:
             dur[m.group(1)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     out = {}
-    for k in ("deform_fwd_kernel", "deform_field_fwd_kernel", "deform_field_fwd_b3_kernel", "deform_bwd_b3f_kernel", "deform_bwd_dx_kernel",
+    for k in ("deform_fwd_kernel", "deform_field_fwd_kernel", "deform_field_fwd_b3_kernel", "deform_bwd_b3f_kernel", "deform_bwd_b3g_kernel", "deform_bwd_dx_kernel",
               "deform_bwd_dw_kernel"):
         if k not in cnt:
             continue
@@ -66,13 +66,13 @@ def main():
             rec["expected_busy_cycles_at_32_per_mfma"] = 32.0 * rec["bf16_mfma_per_launch"]
             rec["equivalent_f32_TFLOPs"] = round(34_048 * P / d_ns / 1e3, 1)
             rec["note"] = "HexPlane gather and MLP in one kernel: the duration covers both; the matrix pipe is the bf16 one"
-        if k == "deform_bwd_b3f_kernel":
+        if k in ("deform_bwd_b3f_kernel", "deform_bwd_b3g_kernel"):
             # per tile of 32 Gaussians: three head waves x 144 + the trunk wave's 96 v_mfma_f32_32x32x16_bf16 (six piece products per
             # f32 product; eleven 64x64 layer products per Gaussian: three recomputed, three W1^T, W0^T, four weight gradients)
             rec["bf16_mfma_per_launch"] = (3 * 144 + 96) * ((P + 31) // 32)
             rec["expected_busy_cycles_at_32_per_mfma"] = 32.0 * rec["bf16_mfma_per_launch"]
             rec["equivalent_f32_TFLOPs"] = round(11 * 2 * 64 * 64 * P / d_ns / 1e3, 1)
-            rec["note"] = "one wave per SIMD, four roles per workgroup; the head SIMDs carry 144 of a tile's MFMAs each, the trunk SIMD 96"
+            rec["note"] = ("one wave per SIMD, four roles per workgroup" if k.endswith("b3f_kernel") else "two waves per SIMD, every role cut in two") + "; the head SIMDs carry 144 of a tile's MFMAs each, the trunk SIMD 96"
         if FLOP[k]:
             rec["expected_busy_cycles_from_flop"] = 64.0 * FLOP[k] / 4096.0
             rec["achieved_TFLOPs"] = round(FLOP[k] / d_ns / 1e3, 1)

@@ -35,7 +35,7 @@ NAMES = {
     "deform_fwd_kernel": "mlp_fwd", "deform_bwd_dx_kernel": "mlp_bwd_dx", "deform_bwd_dw_kernel": "mlp_bwd_dw",
     "plane_reg_kernel": "plane_reg", "deform_field_fwd_b3_kernel": "deform_field_fwd", "deform_field_fwd_kernel": "deform_field_fwd_f32",
     "hexplane_lines_kernel": "hexplane_lines", "tile_hist_kernel": "tile_hist", "tile_scatter_kernel": "tile_scatter",
-    "deform_bwd_b3f_kernel": "mlp_bwd", "deform_bwd_reduce_kernel": "mlp_bwd_reduce", "act_bwd_kernel": "act_bwd",
+    "deform_bwd_b3f_kernel": "mlp_bwd", "deform_bwd_b3g_kernel": "mlp_bwd", "deform_bwd_reduce_kernel": "mlp_bwd_reduce", "act_bwd_kernel": "act_bwd",
     "densify_stats_kernel": "densify_stats", "tile_scan_kernel": "tile_scan",
 }
 SKIP = 5  # warm-up launches left out of the average
