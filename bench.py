@@ -307,6 +307,12 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
             DGR.set_sync_mode("async", capacity_hint=int(max(counts[keep_all_tiles]) * 1.6) + 65536)
         for i in range(warmup):
             trainer.step(it(i), cams=[cams[i % len(cams)]])
+        if with_densify:
+            # one-time library initialisation out of the window: densify_and_split's torch.bmm is this process's first GEMM (rocBLAS
+            # loads its kernels: ~0.2 s, once per process), torch.normal its first random draw
+            z = torch.zeros(4, 3, 3, device=dev)
+            torch.bmm(z, z)
+            torch.normal(mean=torch.zeros(4, 3, device=dev), std=torch.ones(4, 3, device=dev))
         trainer.drain()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
