@@ -6,7 +6,14 @@
 
 namespace {
 
-constexpr int kSmallRect = 8;          // splats touching <= 8 tiles are enumerated by their own lane
+// Splats touching at most this many tiles are enumerated by their own lane; larger ones by the whole wave, one tile per lane, which
+// costs a broadcast of the splat (fifteen v_readlane) and a wave-wide pass per splat.  With the threshold at 8 (rounds 1-3) a third
+// of the visible splats took the wave-wide path and it was 80 % of tile_hist's vector instructions; measured at config 2,
+// threshold -> tile_hist: 4 -> 37 us, 8 -> 32, 12 -> 23, 16 -> 21, 24 -> 20, 32 -> 20, 48 -> 21, 64 -> 25 (config 3: 74 -> 46 at 24).
+#ifndef MOM_SMALL_RECT
+#define MOM_SMALL_RECT 24
+#endif
+constexpr int kSmallRect = MOM_SMALL_RECT;
 constexpr int kMaxLdsTiles = 16384;    // 64 KiB LDS histogram
 
 

@@ -26,6 +26,8 @@ def snapshot(g):
 
 def main():
     mode, prefix = sys.argv[1], sys.argv[2]
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("MOM_RANK_STACKS_AFTER", "120")), exit=False)      # a hung rank says where
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
