@@ -132,8 +132,6 @@ def measured_traffic(kernel, cfg):
     return k["traffic_bytes"], {"traffic_source": name, "traffic_collected_on": doc.get("lib_version")}
 
 
-PROFILE_PERIOD = 7
-
 
 def sq_counters(kernel, cfg):
     """(entry, note): that kernel's means from the committed SQ / GRBM counter summary (profiles/*_sq.json: SQ_INSTS_VALU per
@@ -165,6 +163,44 @@ def metric_name():
             return json.load(fh)["metric"]
     except (OSError, KeyError, ValueError):
         return "4DGS train-steps/sec @200k Gaussians, 960\u00d7540, 60 frames; render FPS"
+
+
+def pairs_evaluated(fs):
+    """SURVEY 8(d)'s Q for the frame the fused step `fs` rendered last (call after a synchronisation): evaluated pixel-Gaussian pairs
+    = sum over tiles of 256 x (list entries the tile's block walks before it exits).
+      q_fwd     the forward: its block exits at the start of the 256-entry round in which every pixel is done (forward.cu:305-312;
+                render_fwd keeps that round structure and stores the count per tile: MomRasterLayout.img_tile_walked);
+      q_bwd     the backward as THIS library runs it: a tile's list ends at its last contributor (max n_contrib over the tile);
+      q_bwd_no_exit  256 x the instances: the reference's backward has no block exit and walks every entry (backward.cu:497-505);
+      alpha_pairs    sum over pixels of n_contrib: the pairs that lie in front of their pixel's last contributor, i.e. the ones
+                the backward's per-thread test (backward.cu:519-520) lets through to the exponent.
+    With keep_all_tiles the lists are the reference's, so q_fwd and q_bwd_no_exit are the reference's own Q."""
+    import ctypes as C
+    import torch
+    N = importlib.import_module("iclr2025_3d-mom_amd._native")
+    P = fs.P
+    W, H = fs._wh
+    lay = N.MomRasterLayout()
+    N.lib().mom_raster_layout(P, W, H, 0, C.byref(lay))
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    base = fs.img[(-fs.img.data_ptr()) % 256:]
+    walked = base[lay.img_tile_walked:lay.img_tile_walked + gx * gy * 4].view(torch.int32)
+    nc = base[lay.img_n_contrib:lay.img_n_contrib + W * H * 4].view(torch.int32).view(H, W)
+    pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int32, device=nc.device)
+    pad[:H, :W] = nc
+    last = pad.view(gy, 16, gx, 16).amax(dim=(1, 3))
+    return {"q_fwd": 256 * int(walked.long().sum()), "q_bwd": 256 * int(last.long().sum()),
+            "q_bwd_no_exit": 256 * int(fs.nr_host[0]), "alpha_pairs": int(nc.long().sum())}
+
+
+Q_IS = ("SURVEY 8d: evaluated pixel-Gaussian pairs = sum over tiles of 256 x (list entries walked before the tile's block exits), mean "
+        "over the sampled cameras.  q_fwd: the forward (exit when every pixel is done, rounds of 256, forward.cu:305-312); q_bwd: this "
+        "library's backward (the list ends at the tile's last contributor); q_bwd_no_exit: 256 x instances (the reference's backward "
+        "walks every entry); alpha_pairs: sum of n_contrib over the pixels.  *_ref: on the reference's lists (keep_all_tiles)")
+
+
+def mean_q(rows):
+    return {k: sum(r[k] for r in rows) / len(rows) for k in rows[0]} if rows else None
 
 
 def render_fps(scene, g, pp, background, delta_scale, passes=8):
@@ -274,6 +310,7 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
     sample = cams[::max(1, len(cams) // 8)][:8]
     DGR.set_sync_mode("exact")
     counts = {True: [], False: []}
+    qs = {True: [], False: []}
 
     def set_keep(flag):
         if trainer.fused is not None:
@@ -291,17 +328,29 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
                 trainer.step(5001 + i, cams=[c])
                 torch.cuda.synchronize()
                 counts[keep].append(int(trainer.fused.nr_host[0]) if trainer.fused is not None else DGR.last_num_rendered())
+                if trainer.fused is not None:
+                    qs[keep].append(pairs_evaluated(trainer.fused))
     finally:
         set_keep(keep_all_tiles)
     r_ref = sum(counts[True]) / len(counts[True])
     r_binned = sum(counts[False]) / len(counts[False])
     r_proc = r_ref if keep_all_tiles else r_binned
-    it0 = 5040 if with_densify else 5011        # with_densify: iteration 5100 falls inside the timed window
+    # with_densify: BASELINE configs[4]'s "densify/prune every 100 iters" -- the cadence of the reference's argparse default
+    # (arguments/__init__.py:146 of the reference; the dnerf_default overlay the scripts load prunes every 8000, which default_args
+    # mirrors and which made this leg's round a no-op in round 4).  The window walks consecutive iteration numbers around 5100: `pre`
+    # steps, the boundary iteration itself (drain + statistics -> prune -> compaction of every parameter and of Adam's state), `post`
+    # steps on the compacted model.  The statistics the round acts on are the ones the steps themselves accumulated (max_radii2D
+    # of the cameras seen since the model was built; the trained-like scene has splats above the 20-pixel screen-size limit).
+    if with_densify:
+        op.pruning_interval = 100
+    pre = (steps - 1) // 2 if with_densify else 0
+    it0 = 5100 - pre - warmup if with_densify else 5011
 
     def it(i):
         return it0 + (i if with_densify else i % 80)
 
     p_start = int(g.get_xyz.shape[0])
+    segs = None
     try:
         if trainer.fused is None and sync_mode == "async":
             DGR.set_sync_mode("async", capacity_hint=int(max(counts[keep_all_tiles]) * 1.6) + 65536)
@@ -317,7 +366,14 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         loss = None
+        marks = []
         for i in range(steps):
+            if with_densify and i in (pre, pre + 1):
+                # the segments' edges: the boundary iteration drains by itself (Trainer._boundary), the synchronisations here add
+                # nothing to it; the one after it is the price of reporting the boundary's own milliseconds
+                trainer.drain()
+                torch.cuda.synchronize()
+                marks.append((time.perf_counter(), int(g.get_xyz.shape[0])))
             loss = trainer.step(it(warmup + i), cams=[cams[(warmup + i) % len(cams)]])
         t_enq = time.perf_counter() - t0           # the host's share: every launch of the window is enqueued (exact mode: its waits included)
         trainer.drain()
@@ -325,6 +381,12 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
             loss = loss.tensor()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        if with_densify:
+            (ta, na), (tb, nb) = marks
+            post = steps - pre - 1
+            segs = {"before": {"steps": pre, "gaussians": na, "steps_per_s": pre / (ta - t0)},
+                    "boundary": {"iteration": it(warmup + pre), "ms": 1e3 * (tb - ta), "gaussians_before": na, "gaussians_after": nb},
+                    "after": {"steps": post, "gaussians": nb, "steps_per_s": post / (t0 + dt - tb)}}
     finally:
         DGR.set_sync_mode("exact")
         set_keep(False)
@@ -339,10 +401,18 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
            "host_sync": "device-gated async (fused step)" if path == "fused" else sync_mode,
            "python_gc": "gc.freeze() after setup (Trainer(gc_freeze=True)), as in the headline leg",
            "roofline_step": step_roofline(cfg["P"], r_proc, r_ref, cfg["W"] * cfg["H"], dt / steps)}
+    if qs[True]:
+        out["pairs_Q"] = {"processed": mean_q(qs[keep_all_tiles]), "reference_lists": mean_q(qs[True]), "what": Q_IS}
     if with_densify:
+        p_end = int(g.get_xyz.shape[0])
         out["densify_in_window"] = {"iterations": [it(warmup), it(warmup + steps - 1)], "gaussians_before": p_start,
-                                    "gaussians_after": int(g.get_xyz.shape[0]),
-                                    "what": "the trainer's own round at iteration 5100 (train_4DGS.py:264-290 gates) is inside the timed window"}
+                                    "gaussians_after": p_end, "pruning_interval": int(op.pruning_interval),
+                                    "segments": segs,
+                                    "what": "the trainer's own round at iteration 5100 (train_4DGS.py:264-290 gates, pruning_interval "
+                                            "100 = BASELINE configs[4]) is inside the timed window: `value` covers before + boundary + "
+                                            "after; 4 M >= 360 000 closes the reference's densify gate (train_4DGS.py:275), so the round "
+                                            "prunes (opacity / screen-size / world-size masks, gaussian_model.py:681-692 of the reference)"}
+        assert p_end != p_start, f"the densify/prune round at iteration 5100 left the model at {p_start} Gaussians: the leg measured a no-op"
     del scene, g, trainer
     import gc
     gc.collect()
@@ -409,7 +479,10 @@ def main():
     # rank -- the only way to exercise it on a box with a single GPU.
     force_dist = world == 1 and os.environ.get("MOM_FORCE_DIST") == "1" and "RANK" in os.environ
     if world > 1 or force_dist:
-        dist.init_process_group("nccl")
+        import datetime
+        # a collective that cannot complete (a rank died, took another branch) aborts the job after this long instead of hanging it:
+        # torch's watchdog tears the communicator down and the rank exits non-zero, which makes launch.spawn_ranks stop the others
+        dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=float(os.environ.get("MOM_PG_TIMEOUT_S", "300"))))
     dev = torch.device("cuda", local)
     DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
     scene, g, trainer, op = build_state(cfg, dev, fused=(a.path == "fused"), lambda_dssim=a.lambda_dssim, gc_freeze=True)
@@ -451,6 +524,7 @@ def main():
     # algorithmic bytes are defined on; the default binning drops the instances that cannot contribute, and that smaller
     # count is reported beside it (instances_binned).  So: two passes, the first with keep_all_tiles.
     r_of_cam, binned_of_cam = {}, {}
+    q_of_cam = {True: {}, False: {}}
     if trainer.fused is not None:
         for keep_all, table in ((True, r_of_cam), (False, binned_of_cam)):
             trainer.fused.keep_all_tiles = keep_all
@@ -459,6 +533,8 @@ def main():
                 one(i)
                 torch.cuda.synchronize()
                 table[id(cam_of(i))] = int(trainer.fused.nr_host[0])
+                if a.shard == "camera":          # (a tile-row shard's image state covers the rank's rows only)
+                    q_of_cam[keep_all][id(cam_of(i))] = pairs_evaluated(trainer.fused)
         trainer.fused.exact_next()
     prof = importlib.import_module("iclr2025_3d-mom_amd.profiling")
 
@@ -471,10 +547,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         if profile_kernel and rank == 0:
-            # HIP events around the dominant kernel only, on every 7th step of the region (7 is coprime to the 60 / 120 / 240 cameras
-            # the steps cycle through, so the sample covers them evenly): an event pair costs the stream ~13 us of bubbles
-            # (tools/gap_stats.py), 1.3 % of the headline step if every launch carried one
-            prof.enable(profile_kernel, period=PROFILE_PERIOD if steps >= 10 * PROFILE_PERIOD else 1)
+            # HIP events around every launch of the dominant kernel: only the roofline leg below asks for them (an event pair costs
+            # the stream ~13 us of bubbles, tools/gap_stats.py; the headline region carries none, whatever --steps is)
+            prof.enable(profile_kernel, period=1)
         t0 = time.perf_counter()
         loss = None
         for i in range(steps):
@@ -496,9 +571,13 @@ def main():
         bs = [binned_of_cam.get(id(cam_of(first + i))) for i in range(steps)]
         bs = [b for b in bs if b is not None]
         binned_mean[0] = sum(bs) / len(bs) if bs else None
+        for keep_all in (True, False):
+            rows = [q_of_cam[keep_all].get(id(cam_of(first + i))) for i in range(steps)]
+            q_mean[keep_all] = mean_q([r for r in rows if r is not None])
         return dt, loss, (sum(rs) / len(rs) if rs else float(R))
 
     binned_mean = [None]
+    q_mean = {True: None, False: None}
 
     scale = world if a.shard == "camera" else 1
     nxt = 1 + len(cams)
@@ -518,9 +597,18 @@ def main():
     for i in range(a.warmup):
         one(nxt + i)
     nxt += a.warmup
-    dt, loss, r_mean = timed(nxt, a.steps, profile_kernel=a.roofline_kernel)
+    dt, loss, r_mean = timed(nxt, a.steps)
     nxt += a.steps
     assert torch.isfinite(loss).all(), "loss is not finite"
+    headline_binned, headline_q = binned_mean[0], dict(q_mean)
+    # the live roofline's launch durations: a leg of its own, straight after the headline region (same device state), every launch of
+    # the kernel bracketed by HIP events on its launch stream -- one full cycle over the cameras, so the sample is the workload's mix
+    n_roof = len(cams)
+    dt_roof, loss_r, r_mean_roof = timed(nxt, n_roof, profile_kernel=a.roofline_kernel)
+    nxt += n_roof
+    roof_binned = binned_mean[0]
+    assert torch.isfinite(loss_r).all(), "loss is not finite (roofline leg)"
+    binned_mean[0] = headline_binned
     out = {
         "metric": metric_name(), "value": a.steps * scale / dt,
         "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -530,6 +618,7 @@ def main():
                    "instances_R_is": "the reference's count (every tile of every splat's rectangle), mean over the cameras of the timed steps",
                    "instances_binned": binned_mean[0],
                    "instances_binned_is": "what the default binning keeps: instances that can reach alpha >= 1/255 in their tile",
+                   "pairs_Q": {"processed": headline_q[False], "reference_lists": headline_q[True], "what": Q_IS},
                    "sh_degree": 3, "step_path": a.path, "batch_size": 1,
                    "lambda_dssim": a.lambda_dssim, "parallelism": (f"camera-batch x{world}" if a.shard == "camera" else f"tile-row x{world}") if world > 1 else "single",
                    "ranks_seen": ranks_seen, "host_sync": a.sync_mode, "final_loss": float(loss), "densify_in_window": bool(a.with_densify),
@@ -542,10 +631,26 @@ def main():
     if rank == 0:
         traffic, tnote = measured_traffic(a.roofline_kernel, cfg)
         sq, sqnote = sq_counters(a.roofline_kernel, cfg)
-        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], binned_mean[0] or r_mean, npix, traffic=traffic, R_ref=r_mean, sq=sq)
+        out["roofline"] = prof.roofline(a.roofline_kernel, cfg["P"], roof_binned or r_mean_roof, npix, traffic=traffic, R_ref=r_mean_roof, sq=sq)
         if out["roofline"] is not None:
-            out["roofline"].update(tnote)
-            out["roofline"].update(sqnote)
+            rl = out["roofline"]
+            rl.update(tnote)
+            rl.update(sqnote)
+            rl["measured_in"] = (f"a leg of its own after the headline region: {n_roof} steps (one cycle over the cameras), HIP events "
+                                 f"around every {a.roofline_kernel} launch ({n_roof / dt_roof:.1f} steps/s with the events' bubbles); "
+                                 "the headline region carries no events")
+            # SURVEY 8d's secondary ceiling of the raster loops: FLOP on the evaluated pairs against the fp32 vector peak
+            qk = {"render_bwd": ("q_bwd", 70.0), "render_fwd": ("q_fwd", 20.0)}.get(a.roofline_kernel)
+            qrow = mean_q([q_of_cam[False][id(cam_of(nxt - n_roof + i))] for i in range(n_roof) if id(cam_of(nxt - n_roof + i)) in q_of_cam[False]])
+            if qk and qrow:
+                sec = rl["avg_launch_us"] * 1e-6
+                flop = qk[1] * qrow[qk[0]]
+                rl["pairs_Q"] = qrow
+                rl["useful_flop_frac"] = flop / sec / 1e12 / prof.FP32_VALU_PEAK_TFLOPS
+                rl["useful_flop_is"] = (f"{qk[1]:.0f} FLOP x Q ({qk[0]}: the pairs this kernel's tiles walk) / launch duration / "
+                                        f"{prof.FP32_VALU_PEAK_TFLOPS:.0f} TFLOP/s (SURVEY 8d); most walked pairs fail the alpha test and do no "
+                                        "arithmetic beyond it, so this prices the walk, not useful lanes")
+                rl["alpha_pair_flop_frac"] = qk[1] * qrow["alpha_pairs"] / sec / 1e12 / prof.FP32_VALU_PEAK_TFLOPS
         prof.enable(a.roofline_kernel, False)
         if world == 1 and not a.no_extra:
             # the metric's two other readings, on the same scene and model state: the SSIM/L1 loss of the
@@ -573,7 +678,7 @@ def main():
                 out["keep_all_tiles"] = side_leg(cfg, dev, "fused", 100, 20, keep_all_tiles=True)
                 out["other_configs"] = {k: side_leg(CONFIGS[k], dev, "fused", 20, 5) for k in ("c1", "c3")}
                 # BASELINE configs[4]: "densify/prune every 100 iters" -- the round at iteration 5100 is inside the window
-                out["other_configs"]["c5"] = side_leg(CONFIGS["c5"], dev, "fused", 120, 10, with_densify=True)
+                out["other_configs"]["c5"] = side_leg(CONFIGS["c5"], dev, "fused", 121, 10, with_densify=True)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         sys.stdout.flush()

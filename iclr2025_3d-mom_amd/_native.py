@@ -21,7 +21,7 @@ class MomError(RuntimeError):
     pass
 
 
-ABI_VERSION = 4          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
+ABI_VERSION = 5          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
 
 
 class MomRasterArgs(C.Structure):
@@ -52,7 +52,7 @@ class MomRasterGrads(C.Structure):
 class MomRasterLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in ("geom_rec", "geom_cov3D", "geom_clamped", "geom_gacc", "img_ranges",
                                           "img_n_contrib", "img_final_T", "img_tile_counts", "bin_keys",
-                                          "bin_point_list")]
+                                          "bin_point_list", "img_tile_walked")]
 
 
 class MomHexPlane(C.Structure):
@@ -92,20 +92,28 @@ def _sig(lib):
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     if os.environ.get("MOM4D_LIB_LAX") == "1":
         # A/B tooling only (tools/kbench.py with MOM4D_LIB naming an OLDER build of the library): bind what that build has
+        # (a variant built from the CURRENT header -- tools/variants.sh -- or an older build: symbols the older one lacks raise on
+        # call, and its ABI check is skipped when it predates mom_abi_version)
+        class _Missing:
+            restype = argtypes = None
+
+            def __init__(self, name):
+                self.name = name
+
+            def __call__(self, *a):
+                raise MomError(f"{self.name} is not in {LIB_PATH}")
+
         class _Lax:
             def __init__(self, real):
                 object.__setattr__(self, "_real", real)
+                object.__setattr__(self, "_missing", {})
 
             def __getattr__(self, name):
                 try:
                     return getattr(self._real, name)
                 except AttributeError:
-                    class _Missing:
-                        restype = argtypes = None
-
-                        def __call__(self, *a):
-                            raise MomError(f"{name} is not in {LIB_PATH}")
-                    return _Missing()
+                    # one stub per name: the restype / argtypes assigned below must stick to what later lookups return
+                    return self._missing.setdefault(name, _Missing(name))
         lib = _Lax(lib)
     else:
         for name in EXPORTS:
@@ -263,7 +271,12 @@ def lib():
         # torch's streams fails (seen as "HIP launch/runtime failure" in smoke() when build() had loaded the library first)
         import torch  # noqa: F401
         l = _sig(C.CDLL(LIB_PATH))
-        check_abi(l)
+        lax_old = os.environ.get("MOM4D_LIB_LAX") == "1" and not hasattr(l._real, "mom_abi_version")
+        if lax_old:
+            import warnings
+            warnings.warn(f"{LIB_PATH}: no mom_abi_version (a build older than ABI 4) bound in lax mode; struct layouts are NOT checked")
+        else:
+            check_abi(l)
         _lib = l
     return _lib
 

@@ -34,6 +34,7 @@
 // instructions per pair of values.  Measured 185 against 182 us: no gain, so the masks stay, the same arithmetic as the forward.)
 #include "deform_b3_dev.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -786,6 +787,11 @@ deform_bwd_b3g_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat
 #endif
 }
 
+constexpr int kMaxDevices = 64;
+struct PerDevice { bool attr_set = false; };
+PerDevice per_device[kMaxDevices];
+std::mutex per_device_mutex;
+
 }  // namespace
 
 // The entry point deform_mlp.hip's mom_deform_backward_split dispatches to by default (MOM_MLP_BWD unset or "b3").  (It takes the
@@ -813,20 +819,23 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
     if (forced_blocks < 0) { const char* e = getenv("MOM_B3F_BLOCKS"); forced_blocks = (e && atoi(e) > 0 && atoi(e) <= 256) ? atoi(e) : 0; }
     const int max_blocks = forced_blocks ? forced_blocks : (dw_stream != s ? 224 : 256);
     const int blocks = tiles < max_blocks ? tiles : max_blocks;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLdsBytes) != hipSuccess)
-            return MOM_ELAUNCH;
-        attr_set = true;
-    }
-    static int eight = -1;               // the eight-wave kernel (deform_bwd_b3g_kernel) by default; MOM_B3_EIGHT=0: the four-wave one
-    if (eight < 0) {
-        const char* e = getenv("MOM_B3_EIGHT");
-        eight = (e && e[0] == '0') ? 0 : 1;
-        if (eight && hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         kG_LdsBytes) != hipSuccess)
-            return MOM_ELAUNCH;
+    // the eight-wave kernel (deform_bwd_b3g_kernel) by default; MOM_B3_EIGHT=0: the four-wave one
+    static const int eight = [] { const char* e = getenv("MOM_B3_EIGHT"); return (e && e[0] == '0') ? 0 : 1; }();
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= kMaxDevices) return MOM_ELAUNCH;
+    PerDevice& pd = per_device[dev_id];
+    {
+        // per-device lazy state (the dynamic-LDS attribute is per device; the hand-over event belongs to the device it was created
+        // on): a process may drive several devices, from several threads.  A failed attribute call is retried by the next launch.
+        std::lock_guard<std::mutex> lock(per_device_mutex);
+        if (!pd.attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kLdsBytes) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kG_LdsBytes) != hipSuccess)
+                return MOM_ELAUNCH;
+            pd.attr_set = true;
+        }
     }
     MomProfScope ps(MOM_P_MLP_BWD, s);
     if (eight)
@@ -843,10 +852,13 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
     if (reduce_on_main < 0) { const char* e = getenv("MOM_B3F_REDUCE_MAIN"); reduce_on_main = (e && e[0] == '1') ? 1 : 0; }
     if (reduce_on_main) dw_stream = s;
     if (dw_stream != s) {
-        static hipEvent_t main_done = nullptr;
-        if (!main_done && hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
-        if (hipEventRecord(main_done, s) != hipSuccess) return MOM_ELAUNCH;
-        if (hipStreamWaitEvent(dw_stream, main_done, 0) != hipSuccess) return MOM_ELAUNCH;
+        // one event per call: record + wait capture the state at the record, and hipEventDestroy of a recorded event is deferred
+        // until it has completed, so nothing is shared between the calls of different threads or streams
+        hipEvent_t main_done = nullptr;
+        if (hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
+        const bool ok = hipEventRecord(main_done, s) == hipSuccess && hipStreamWaitEvent(dw_stream, main_done, 0) == hipSuccess;
+        (void)hipEventDestroy(main_done);
+        if (!ok) return MOM_ELAUNCH;
     }
     hipLaunchKernelGGL(deform_bwd_reduce_kernel, dim3((kPartFloats + 63) / 64), dim3(64 * kReduceGroups), 0, dw_stream, d, (const float*)scratch,
                        blocks);

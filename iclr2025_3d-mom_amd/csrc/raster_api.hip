@@ -87,6 +87,7 @@ int mom_raster_layout(int P, int W, int H, size_t capacity, MomRasterLayout* out
     out->bin_keys = (size_t)((char*)b.keys - z);
     out->bin_point_list = (size_t)((char*)b.point_list - z);
     out->img_tile_counts = (size_t)((char*)im.tile_counts - z);
+    out->img_tile_walked = (size_t)((char*)im.tile_cursor - z);
     return MOM_OK;
 }
 

@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FW
 render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read AND, for the tiles sorted here, written: no restrict */, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-                  uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys)
+                  uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys, uint32_t* __restrict__ tile_walked)
 {
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
@@ -178,6 +178,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
     const int rounds = (toDo + kRound - 1) / kRound;
+    const int list_len = toDo;
+    int walked_rounds = rounds;                               // rounds of the list this workgroup walks before every pixel is done
 
     // The tile's depth sort, for tiles whose keys fit the LDS the rounds below stage their splats in (sort_keys == null: the
     // binning sorted every tile).  The sorted indices go to point_list -- the backward walks it too -- and are read back from
@@ -224,7 +226,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     fetch(0);
 #endif
     for (int i = 0; i < rounds; i++, toDo -= kRound) {
-        if (__syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256) break;
+        if (__syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256) { walked_rounds = i; break; }
 #if MOM_FWD_PREFETCH
         {
             uint32_t reach = 0;
@@ -300,6 +302,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
             }
         }
     }
+    // "entries processed before block exit" (SURVEY 8d's Q = 256 x the sum of this over the tiles): the list is walked in rounds of
+    // 256 like the reference's (forward.cu:305-327), and a round is entered unless every pixel of the tile is done.  One plain
+    // store per tile into the scatter's cursor array, which nothing reads after the binning.
+    if (threadIdx.x == 0) tile_walked[tile] = (uint32_t)min(list_len, walked_rounds * kRound);
     if (inside) {
         const int pix = py * W + px;
         if (final_T) final_T[pix] = T;                      // null in forward-only rendering: nothing will read them
@@ -701,7 +707,7 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     if (!l1.grad || !l1.sums) l1.target = nullptr;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
-                       out_depth, cap, l1, sort_small ? b.keys : nullptr);
+                       out_depth, cap, l1, sort_small ? b.keys : nullptr, im.tile_cursor);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

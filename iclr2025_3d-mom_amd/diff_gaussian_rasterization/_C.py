@@ -161,7 +161,9 @@ def exact_render(lib, a, geom, img, out_color, out_depth, nr_host, P, W, H, dev,
     else:
         torch.cuda.current_stream().synchronize()
     count = int(nr_host[0])
-    if count > guess:
+    if count > guess or ev is None:
+        # (ev is None: nothing was enqueued above -- also the case of a frame with NO instances before any guess exists; the
+        # compositing still has to run, it writes the background image, as the reference does for num_rendered == 0)
         if guess:
             torch.cuda.current_stream().synchronize()      # the truncated pass is out of the way before its buffers are reused
             regeometry()

@@ -88,8 +88,15 @@ class FusedRender:
             md = ops.DeformMLPFunction._desc([p.detach() for p in mlp], None)
             self._desc, self._desc_key = (hp, keep, md), dkey
         hp, keep, md = self._desc
+        # this renderer's OWN field scratch (time-line table + feature buffer): a FusedRenderPool keeps one frame per slot in flight
+        # on unsynchronised streams, and the per-device scratch of ops.field_scratch would be rewritten by frame k+1's line kernel
+        # while frame k's field kernel still reads it
+        need = lib.mom_deform_field_scratch_bytes(C.byref(hp), P)
+        if getattr(self, "_fscratch", None) is None or self._fscratch.numel() < need or self._fscratch.device != dev:
+            self._fscratch = torch.empty(need, dtype=torch.uint8, device=dev)
         ops.field_forward(hp, md, P, xyz, float(cam.time), order, scal, rot, flow, float(delta_scale * cam.frame_num), self.pts,
-                          self.sc_d, self.rot_d, None, None, opac, self.sc, self.rot, self.op, s, scratch_feat=self.feat)
+                          self.sc_d, self.rot_d, None, None, opac, self.sc, self.rot, self.op, s, scratch_feat=self.feat,
+                          scratch=self._fscratch)
         a = N.MomRasterArgs()
         a.P, a.D, a.M, a.W, a.H = P, g.active_sh_degree, 16, W, H
         a.background, a.means3D = bg.data_ptr(), self.pts.data_ptr()

@@ -278,8 +278,9 @@ class FusedStep:
         N.check(lib.mom_raster_forward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                               self.img.data_ptr(), self.color.data_ptr(), self.depth.data_ptr(),
                                               self.flags.data_ptr(), s), "raster_render")
+        early_works = []                        # camera-batch shard: what the early Adam launch must see reduced (below)
         if dc is not None:
-            dc.start(self.flags, "max")         # every rank skips (and later replays) the same steps
+            early_works.append(dc.start(self.flags, "max"))         # every rank skips (and later replays) the same steps
         # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
         n = self.color.numel()
         if not fuse_l1:
@@ -356,8 +357,8 @@ class FusedStep:
                     "raster_bwd_geometry")
         if dc is not None and dc.mode == "camera":
             # densification statistics (train_4DGS.py:203-204,227-229): largest radius, mean 2-D gradient
-            dc.start(self.radii, "max")
-            dc.start(self.g2d, "sum")
+            early_works.append(dc.start(self.radii, "max"))
+            early_works.append(dc.start(self.g2d, "sum"))
         N.check(lib.mom_activations_backward(P, self.sc.data_ptr(), self.rot_d.data_ptr(), self.op.data_ptr(),
                                              self.gsc_act.data_ptr(), self.grot_act.data_ptr(), self.gop_act.data_ptr(),
                                              self.gsc.data_ptr(), self.grot.data_ptr(), self.gop.data_ptr(), s), "act_bwd")
@@ -370,21 +371,33 @@ class FusedStep:
             d_sc, d_rot = self._loc
             d_sc.copy_(self.gsc)
             d_rot.copy_(self.grot)
-            dc.start(self.early, "sum")
+            early_works.append(dc.start(self.early, "sum"))
         # ---- deformation backward: pts = xyz + dx(...) so d xyz starts as d pts (already in gxyz); the HexPlane adds its share
         # the MLP's weight-gradient kernel (matrix pipe) runs on a second stream beside the HexPlane backward (vector issue,
         # memory latency); joined below, before anything reads the weight gradients
         side = self.side.cuda_stream if self.OVERLAP_DW else s
-        if early_adam is not None and dc is None and self.EARLY_ADAM:
+        early_cam = None
+        if early_adam is not None and self.EARLY_ADAM:
             # The appearance parameters' gradients (SH, scaling, rotation, opacity: 56 of a Gaussian's 59 floats) are final here.
             # Their Adam update -- a pure HBM stream, 335 of Adam's 412 MB -- goes to the second stream now and runs underneath the
             # MLP backward (matrix pipe, 2 TB/s); nothing on this stream reads those parameters again before the join below.
             for p, gbuf in ((g._features_dc, self.gdc), (g._features_rest, self.grest), (g._scaling, self.gsc),
                             (g._rotation, self.grot), (g._opacity, self.gop)):
                 p.grad = gbuf
-            self.side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self.side):
-                early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity])
+            if dc is None or dc.mode == "tile-row":
+                # (a tile-row shard's gradients are already the full sums here: the ranks summed the compositing backward's record,
+                # and projection / activation backward ran replicated on it)
+                self.side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.side):
+                    early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity])
+            else:
+                # camera-batch shard: the launch needs the REDUCED bucket (and, for the densification statistics it carries, the
+                # reduced radii / screen-space gradients and the agreed overflow word).  The second stream waits for exactly those
+                # collectives -- each was begun behind the kernels that produced its buffer, so it orders the stream behind them
+                # too -- and not for this stream, which goes on with the deformation backward.  Enqueued BELOW, after that
+                # backward: on RCCL wait() only makes the waiting stream wait, but gloo (the tests) blocks the host in it, and the
+                # host should block with the GPU's work already queued.
+                early_cam = list(early_works)
         if sl is None:
             N.check(lib.mom_deform_backward_split(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
                                                   d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
@@ -423,6 +436,10 @@ class FusedStep:
                                                   None if spo is None else spo[0].data_ptr(), None if spo is None else spo[1].data_ptr(),
                                                   None if spo is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
             dc.start_gather([self.gxyz_rows], S)
+        if early_cam is not None:
+            with torch.cuda.stream(self.side):
+                dc.wait_for(early_cam)
+                early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity])
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
         if dc is not None and dc.mode == "camera":

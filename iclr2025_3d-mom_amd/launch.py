@@ -77,7 +77,10 @@ def main_or_spawn(n, script, args, force=False):
     prints rank 0's stdout, and exits with their status."""
     if launched_by_a_launcher() or (n <= 1 and not force):
         return False
-    rc, out = spawn_ranks(n, [sys.executable, script] + list(args))
+    # MOM_SPAWN_TIMEOUT_S: the whole job's wall-clock limit (unset: none) -- past it the ranks are terminated, then killed, and the
+    # parent exits 124; a rank that fails ends the others at once either way (spawn_ranks)
+    limit = os.environ.get("MOM_SPAWN_TIMEOUT_S")
+    rc, out = spawn_ranks(n, [sys.executable, script] + list(args), timeout=float(limit) if limit else None)
     sys.stdout.write(out or "")
     sys.stdout.flush()
     sys.exit(rc)

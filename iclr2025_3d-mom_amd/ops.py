@@ -165,10 +165,12 @@ def field_scratch(hp, device, P=0):
 
 
 def field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, pts, sc_d, rot_d, feat, a0, opac, sc, rot_act, op, s,
-                  scratch_feat=None):
+                  scratch_feat=None, scratch=None):
     """deform_network.forward for one timestamp: the fused kernel when the field's shape allows it, else HexPlane + MLP.
     feat / a0: [P,64] tensors that receive the features and relu(h0) for the backward, or None (no backward follows; the
-    two-kernel path then needs `scratch_feat` for the features)."""
+    two-kernel path then needs `scratch_feat` for the features).
+    scratch: the caller's own field scratch (mom_deform_field_scratch_bytes) -- callers that keep several frames in flight on
+    different streams must not share the per-device one (the time-line table and the feature buffer live for the whole launch)."""
     lib = N.lib()
     q = lambda t: None if t is None else t.data_ptr()
     if FUSE_FIELD and lib.mom_deform_field_supported(C.byref(hp)):
@@ -176,7 +178,8 @@ def field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, pts, sc_d,
                                              q(order) if FIELD_ORDER else None, scal.data_ptr(),
                                              rot.data_ptr(), flow.data_ptr(), float(coef), pts.data_ptr(), sc_d.data_ptr(),
                                              rot_d.data_ptr(), q(feat), q(a0), q(opac), q(sc), q(rot_act), q(op),
-                                             field_scratch(hp, xyz.device, 0 if feat is not None else P).data_ptr(), s), "deform_field_fwd")
+                                             (scratch if scratch is not None else
+                                              field_scratch(hp, xyz.device, 0 if feat is not None else P)).data_ptr(), s), "deform_field_fwd")
         return True          # the device's field scratch now holds this frame's time lines (mom_hexplane_backward_lines)
     f = feat if feat is not None else scratch_feat
     N.check(lib.mom_hexplane_forward(C.byref(hp), P, xyz.data_ptr(), None, float(time), q(order), f.data_ptr(), s), "hexplane_fwd")

@@ -133,13 +133,33 @@ class DistContext:
         """Begin an in-place all-reduce of `tensor` (a whole, contiguous buffer) without waiting for it."""
         if not tensor.is_contiguous():
             raise ValueError("start() all-reduces in place and needs a contiguous buffer")
-        self._pending.append(dist.all_reduce(tensor, op=self._OPS[op], async_op=True))
+        w = dist.all_reduce(tensor, op=self._OPS[op], async_op=True)
+        self._pending.append(w)
+        return w
+
+    # A collective that cannot complete (a peer died, a rank took another branch) must end the job, not hang it: gloo's wait()
+    # honours a timeout and raises; RCCL's wait() only orders streams -- there the process group's own timeout (init_process_group)
+    # and its watchdog abort the communicator.  MOM_COLLECTIVE_TIMEOUT_S overrides (seconds).
+    TIMEOUT_S = float(__import__("os").environ.get("MOM_COLLECTIVE_TIMEOUT_S", "120"))
+
+    def _wait(self, w):
+        if dist.get_backend() == "gloo":
+            import datetime
+            w.wait(datetime.timedelta(seconds=self.TIMEOUT_S))
+        else:
+            w.wait()
+
+    def wait_for(self, works):
+        """The CURRENT stream waits for these collectives (handles returned by start()); they stay pending for finish(), which
+        waits for them again on its own stream (waiting twice is harmless)."""
+        for w in works:
+            self._wait(w)
 
     def finish(self):
         """Every all-reduce begun with start() is complete for work issued after this returns (on a GPU the current
         stream waits for RCCL's; the host does not block)."""
         for w in self._pending:
-            w.wait()
+            self._wait(w)
         self._pending.clear()
 
     def sync_param_grads(self, optimizer):

@@ -254,7 +254,7 @@ class Trainer:
             # the reference's step() then skips them: train_4DGS.py:266-297)
             early = None
             self._stats_done = False
-            if self.dist is None and iteration < self.opt.iterations and not self._boundary(iteration):
+            if iteration < self.opt.iterations and not self._boundary(iteration):
                 early = self._early_adam
                 self._early_iter = iteration
                 g_ = self.g

@@ -51,7 +51,7 @@ typedef void* mom_stream_t; /* hipStream_t */
  *   - MomRasterArgs, the struct that changes most often, additionally starts with `struct_size`: every entry point that
  *     takes it returns MOM_EINVAL unless struct_size == sizeof(MomRasterArgs) of the library.
  * (The reference's counterpart is a C++ static-method signature, rasterizer.h:19-87: there the compiler checks it.) */
-#define MOM_ABI_VERSION 4
+#define MOM_ABI_VERSION 5
 int mom_abi_version(void);
 enum {
     MOM_STRUCT_RASTER_ARGS = 0, MOM_STRUCT_RASTER_GRADS, MOM_STRUCT_RASTER_LAYOUT, MOM_STRUCT_HEXPLANE, MOM_STRUCT_ADAM_TENSOR,
@@ -204,6 +204,8 @@ typedef struct MomRasterLayout {
     size_t geom_rec, geom_cov3D, geom_clamped, geom_gacc;
     size_t img_ranges, img_n_contrib, img_final_T, img_tile_counts;
     size_t bin_keys, bin_point_list;
+    size_t img_tile_walked;   /* u32 per tile, valid after mom_raster_forward_render: list entries the tile's workgroup walked before
+                               * every pixel was done, in rounds of 256 like forward.cu:305-327 (Q = 256 x their sum) */
 } MomRasterLayout;
 int mom_raster_layout(int P, int W, int H, size_t capacity, MomRasterLayout* out);
 

@@ -92,6 +92,9 @@ class _CamRank:
     def finish(self):
         pass
 
+    def wait_for(self, works):
+        pass
+
     def seed_for(self, iteration):
         importlib.import_module("iclr2025_3d-mom_amd.parallel").DistContext.seed_for(self, iteration)
 

@@ -89,6 +89,9 @@ class _VirtualRank:
     def finish(self):
         pass
 
+    def wait_for(self, works):
+        pass
+
 
 def test_camera_batch_buckets_of_two_virtual_ranks_sum_to_the_batch_mean():
     """Multi-GPU exchange of the fused step, checked on one GPU: with world = 2 each rank's buckets carry 1/2, so the

@@ -246,7 +246,7 @@ def test_oversized_tile_bucket_uses_global_sort_path():
 
 
 def test_empty_and_all_culled():
-    from hip_helpers import hip_forward
+    from hip_helpers import hip_backward, hip_forward
     s = random_gaussians(10, seed=1, W=48, H=32)
     s0 = {k: (v[:0] if isinstance(v, np.ndarray) and v.shape[:1] == (10,) else v) for k, v in s.items()}
     fw = hip_forward(s0)
@@ -255,6 +255,18 @@ def test_empty_and_all_culled():
     fw = hip_forward(s)
     assert fw["R"] == 0 and (fw["radii"] == 0).all()
     np.testing.assert_allclose(fw["color"], np.broadcast_to(s["bg"][:, None, None], (3, 32, 48)))
+    # ... and as the FIRST frames of a process (exact mode has no guess yet): every frame of a run of empty frames
+    # must still composite -- the background image, as the reference returns for num_rendered == 0 -- and hand back a buffer
+    from hip_helpers import RC
+    RC._state["exact_cap"] = 0
+    s["bg"] = np.array([0.25, 0.5, 0.75], np.float32)
+    for _ in range(2):
+        fw = hip_forward(s)
+        assert fw["R"] == 0 and RC._state["exact_cap"] == 0
+        np.testing.assert_array_equal(fw["color"], np.broadcast_to(s["bg"][:, None, None], (3, 32, 48)))
+        assert (fw["depth"] == 0).all()
+        g = hip_backward(fw, np.ones((3, 32, 48), np.float32))          # the backward of an empty frame: zero gradients
+        assert all((v == 0).all() for v in g.values())
 
 
 @pytest.mark.parametrize("seed,P,W,H,kw", [

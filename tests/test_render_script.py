@@ -131,6 +131,12 @@ def test_frames_on_alternating_streams_are_the_frames_of_one_stream():
                     assert torch.equal(o["render"], a[0]) and torch.equal(o["depth"], a[1]), (mode, i)
                     assert torch.equal(o["radii"], a[2]) and torch.equal(o["visibility_filter"], a[3]), (mode, i)
                 assert g._fused_render_pool.overflowed() == []
+            # every slot works in its own field scratch (time-line table + feature buffer live for the whole field launch; frames on
+            # different streams overlap): none shares the per-device scratch of the training step or another slot's
+            ops = importlib.import_module(pkg_name + ".ops")
+            ptrs = [sl._fscratch.data_ptr() for sl in g._fused_render_pool.slots]
+            shared = [t.data_ptr() for t in ops._field_scratch.values()]
+            assert len(set(ptrs)) == 3 and not set(ptrs) & set(shared)
     finally:
         R.set_render_streams(1)
         DGR.set_sync_mode("exact")

@@ -7,6 +7,7 @@ ordering of start() / finish() around in-place asynchronous reductions of device
 import importlib
 import os
 import sys
+import time
 
 import pytest
 import torch
@@ -31,16 +32,21 @@ def test_two_processes_on_one_gpu_end_with_identical_replicas_and_the_single_pro
     import two_process_rank as R
     prefix = str(tmp_path / f"snap_{mode}")
     # Two processes time-sharing ONE GPU through gloo is a harness configuration (RCCL refuses it; production is one process per GPU).
-    # In 25 runs of the whole suite this round, two -- consecutive, on one box -- saw the pair stop making progress here with no
-    # error on either rank; alone and in every later run it passes.  A stuck pair is therefore given one fresh rendezvous, loudly; each
-    # rank dumps its Python stacks to stderr after MOM_RANK_STACKS_AFTER seconds (default 120) so that a repeat says where it stood.
+    # No second chance: a pair that does not finish FAILS, with both ranks' progress logs (time stamps per phase and, after
+    # MOM_RANK_STACKS_AFTER seconds, their Python stacks) in the message.  Every collective carries a timeout (DistContext._wait,
+    # init_process_group), so a rank stuck in one raises by itself well before the spawn timeout.
     argv = [sys.executable, os.path.join(ROOT, "tests", "two_process_rank.py"), mode, prefix]
-    timeout = float(os.environ.get("MOM_TEST_SPAWN_TIMEOUT", "180"))
+    timeout = float(os.environ.get("MOM_TEST_SPAWN_TIMEOUT", "240"))
+    t0 = time.time()
     rc, out = launch.spawn_ranks(2, argv, timeout=timeout)
-    if rc == 124:
-        print(f"two_process_rank ({mode}): no progress within {timeout:.0f} s; starting the pair once more", file=sys.stderr, flush=True)
-        rc, out = launch.spawn_ranks(2, argv, timeout=timeout)
-    assert rc == 0, out
+    logs = ""
+    for r in (0, 1):
+        try:
+            with open(f"{prefix}_{r}.log") as fh:
+                logs += f"\n--- rank {r} ---\n" + fh.read()
+        except OSError:
+            logs += f"\n--- rank {r}: no log ---\n"
+    assert rc == 0, f"rank pair ended with {rc} after {time.time() - t0:.0f} s (124 = no progress within {timeout:.0f} s){logs}\n{out}"
     a, b = torch.load(prefix + "_0.pt"), torch.load(prefix + "_1.pt")
     diff = {k: float((a[k].float() - b[k].float()).abs().max()) for k in a if not torch.equal(a[k], b[k])}
     assert not diff, f"replicas differ: {diff}"

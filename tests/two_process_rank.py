@@ -26,23 +26,46 @@ def snapshot(g):
 
 def main():
     mode, prefix = sys.argv[1], sys.argv[2]
+    import datetime
     import faulthandler
-    faulthandler.dump_traceback_later(float(os.environ.get("MOM_RANK_STACKS_AFTER", "120")), exit=False)      # a hung rank says where
+    import time
+    rank_env = os.environ.get("RANK", "?")
+    t_start = time.time()
+    log = open(f"{prefix}_{rank_env}.log", "w")
+
+    def stamp(what):
+        """Progress marks of this rank (the parent test attaches both ranks' files to a failure: where each one stood, and when)."""
+        log.write(f"{time.time() - t_start:8.2f} s  {what}\n")
+        log.flush()
+
+    stamp("process up, torch imported")
+    # a hung rank says where: its Python stacks go to its log file (the parent's stderr is captured by pytest and easily lost)
+    faulthandler.dump_traceback_later(float(os.environ.get("MOM_RANK_STACKS_AFTER", "100")), exit=False, file=log)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    # a collective that cannot complete raises after the timeout instead of waiting for ever (gloo honours it per operation;
+    # DistContext passes its own to every wait)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("MOM_PG_TIMEOUT_S", "90"))))
     rank, world = dist.get_rank(), dist.get_world_size()
+    stamp("process group up")
     par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
     scene, g, trainer, op = bench.build_state(CFG, torch.device("cuda"), fused=True, lambda_dssim=0.2)
     par.attach(trainer, rank, world, mode=mode)
+    stamp("state built")
     cams = trainer.cams
     for i in range(3):
         cam = cams[(i * world + rank) % len(cams)] if mode == "camera" else cams[i % len(cams)]
         trainer.step(5001 + i, cams=[cam])
+        stamp(f"step {i} enqueued (replayed so far: {trainer.replayed})")
     trainer.drain()
+    stamp("drained")
     torch.cuda.synchronize()
+    stamp("device idle")
     torch.save({k: v.detach().cpu() for k, v in snapshot(g).items()}, f"{prefix}_{rank}.pt")
     dist.barrier()
+    stamp("barrier passed")
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+    stamp("done")
     if rank == 0:
         print("done", flush=True)
 

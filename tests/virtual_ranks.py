@@ -54,6 +54,9 @@ class VRank:
     def finish(self):
         pass
 
+    def wait_for(self, works):
+        pass
+
     def _collective(self, kind, tensors):
         i, self.n = self.n, self.n + 1
         done = self.w.resolved
