@@ -44,7 +44,7 @@ class grads_through_graph:
 class _State:
     __slots__ = ("a", "keep", "P", "W", "H", "cam_time", "order", "porders", "feat", "a0", "pts", "sc_d", "rot_d", "sc", "rot", "op",
                  "color", "depth", "radii", "geom", "img", "binning", "cap", "xyz", "scal", "rotq", "opac", "flow", "coef", "planes",
-                 "mlp", "field", "f_dc", "f_rest")
+                 "mlp", "field", "f_dc", "f_rest", "ready", "side")
 
 
 def applies(cam, pc, pipe, stage, override_color, cam_type):
@@ -239,12 +239,27 @@ def _backward(st, dcolor, ddepth, direct=True):
     N.check(lib.mom_activations_backward(P, st.sc.data_ptr(), st.rot_d.data_ptr(), st.op.data_ptr(), gsc_act.data_ptr(),
                                          grot_act.data_ptr(), gop_act.data_ptr(), gsc.data_ptr(), grot.data_ptr(), gop.data_ptr(), s),
             "act_bwd")
+    overlap = ops.API_OVERLAP and direct
+    ready = side = None
+    if overlap:
+        # the appearance parameters' gradients (SH, scaling, rotation, opacity) are final here: FusedAdam.step() may start their
+        # update on the second stream behind this event while the deformation backward below still runs (ops.FusedAdam.step)
+        side = ops.side_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record()
     gplanes, gmlp, hp, md, in_place = _field_grads(st, f, direct)
     dfeat = e(P, 64)
     scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
     # pts = xyz + dx(...): d xyz starts as d pts (already in gxyz); scale / rotation residuals likewise
-    N.check(lib.mom_deform_backward(C.byref(md), P, st.feat.data_ptr(), st.a0.data_ptr(), gxyz.data_ptr(), gsc.data_ptr(),
-                                    grot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s), "deform_bwd")
+    if overlap:
+        # with a second stream the MLP backward leaves an eighth of the chip free (for that Adam launch) and its partial-sum
+        # reduction goes there too (csrc/deform_bwd_b3.hip); joined below
+        N.check(lib.mom_deform_backward_split(C.byref(md), P, st.feat.data_ptr(), st.a0.data_ptr(), gxyz.data_ptr(), gsc.data_ptr(),
+                                              grot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s, side.cuda_stream), "deform_bwd")
+    else:
+        N.check(lib.mom_deform_backward(C.byref(md), P, st.feat.data_ptr(), st.a0.data_ptr(), gxyz.data_ptr(), gsc.data_ptr(),
+                                        grot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s), "deform_bwd")
+    ops.wait_reg_pending(dev)          # the regulariser's gradient kernel (second stream) adds into the plane gradients too
     porders = st.porders
     hscratch = None
     if porders is not None:
@@ -254,6 +269,9 @@ def _backward(st, dcolor, ddepth, direct=True):
                                       None if porders is None else porders[0].data_ptr(),
                                       None if porders is None else porders[1].data_ptr(),
                                       None if hscratch is None else hscratch.data_ptr(), s), "hexplane_bwd")
+    if overlap:
+        torch.cuda.current_stream().wait_stream(side)      # the MLP weight gradients are complete for whoever reads them next
+    st.ready, st.side = ready, side
     return g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp, in_place
 
 
@@ -285,11 +303,23 @@ class FusedRenderFunction(torch.autograd.Function):
             # The 32 parameter gradients are handed to the parameters here (set, or added to what an earlier camera of the
             # batch left) instead of being returned: 32 AccumulateGrad nodes cost the autograd engine more host time than the
             # whole forward.  Only the 2-D gradient holder, a non-leaf, goes back through the graph.
+            fresh = True
             for p, g in zip(params, (gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp)):
                 if p.grad is None:
                     p.grad = g
                 elif p.grad is not g:                   # (a plane accumulated into in place IS its own gradient)
                     p.grad.add_(g)
+                    fresh = False
+            # one camera per optimizer step (the reference's batch_size 1): tell the optimizer when the appearance gradients were
+            # final, so that its step() can start their update underneath the rest of this backward (ops.FusedAdam.step checks that
+            # nothing touched them in between).  A second camera accumulating into them withdraws the hint.
+            opt = getattr(pc, "optimizer", None)
+            if opt is not None and hasattr(opt, "early_hint"):
+                app = (pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity)
+                if st.ready is not None and fresh and all(p.grad is g for p, g in zip(app, (gdc, grest, gsc, grot, gop))):
+                    opt.early_hint = (st.ready, st.side, [(p, p.grad, p.grad._version) for p in app])
+                else:
+                    opt.early_hint = None
             return (None, None, None, None, None, None, g2d) + (None,) * (6 + len(gplanes) + len(gmlp))
         # through the graph (fresh buffers: nothing is accumulated in place on this path); inputs that were not asked for get None
         out = [g if n else None for g, n in zip((gxyz, gdc, grest, gsc, grot, gop, *gplanes, *gmlp), needs)]

@@ -396,6 +396,32 @@ def ssim(img1, img2):
     return SSIMFunction.apply(img1, img2)
 
 
+# --------------------------------------------------------------------------- second stream of the autograd path
+API_OVERLAP = _os.environ.get("MOM_API_OVERLAP", "1") != "0"
+_side_streams = {}
+_reg_pending = {}      # device -> event: the regulariser's gradient kernel on the second stream; the next writer of plane gradients waits
+_params_ready = {}     # device -> (event recorded at the end of the last FusedAdam.step(), ((id, version) of every plane it updated))
+
+
+def side_stream(device):
+    """One second stream per device for the render() + loss.backward() path: it carries what does not depend on the compositing
+    (the plane regularisers' two kernels), the MLP backward's partial-sum reduction and -- the largest piece -- the appearance
+    parameters' Adam launch, which FusedAdam.step() starts there behind the event the backward recorded when those gradients
+    became final (fused_autograd.py).  MOM_API_OVERLAP=0 keeps everything on the caller's stream."""
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def wait_reg_pending(device):
+    """The current stream waits for a regulariser gradient kernel still running on the second stream (it ADDS into plane gradient
+    buffers the caller is about to add into as well)."""
+    ev = _reg_pending.pop(device, None)
+    if ev is not None:
+        torch.cuda.current_stream(device).wait_event(ev)
+
+
 # --------------------------------------------------------------------------- plane regularisers
 def direct_grads_ok(params, needs):
     """May a backward hand these parameters their gradients itself (p.grad = ...) instead of returning them to the engine?  Only
@@ -430,8 +456,24 @@ class PlaneRegFunction(torch.autograd.Function):
             arr[i].plane, arr[i].grad = st.data_ptr(), None
             arr[i].H, arr[i].W = st.shape[0], st.shape[1]
             arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), 0.0
-        val = torch.empty(1, dtype=torch.float32, device=planes[0].device)
-        N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), N.current_stream()), "mom_plane_regulation")
+        dev = planes[0].device
+        val = torch.empty(1, dtype=torch.float32, device=dev)
+        if API_OVERLAP:
+            # the value depends on the planes only: on the second stream it runs beside the compositing the caller's stream is
+            # still busy with (the loop calls this right after render()); the caller's stream waits for it before it reads `val`.
+            # The second stream need not wait for the whole of the caller's queue if the planes are exactly as the last
+            # FusedAdam.step() left them (same tensors, same versions -- any torch write since would have bumped one): then the
+            # event that step recorded is the only dependency
+            cur, side = torch.cuda.current_stream(dev), side_stream(dev)
+            mark = _params_ready.get(dev)
+            if mark is not None and mark[1] >= frozenset((id(p), p._version) for p in planes):
+                side.wait_event(mark[0])
+            else:
+                side.wait_stream(cur)
+            N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), side.cuda_stream), "mom_plane_regulation")
+            cur.wait_stream(side)
+        else:
+            N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), N.current_stream()), "mom_plane_regulation")
         ctx.save_for_backward(*planes)
         ctx.w = (list(w_smooth), list(w_l1))
         return val[0]
@@ -476,14 +518,30 @@ class PlaneRegFunction(torch.autograd.Function):
             c[1].zero_()
         _, flat, grads, arr, val = c
         up = g.detach().reshape(1).float()
-        N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), N.current_stream()),
-                "mom_plane_regulation")
+        dev = planes[0].device
+        if API_OVERLAP and direct:
+            # the engine runs this node BEFORE render()'s (it was created later): on the second stream the kernel runs beside the
+            # compositing backward; whoever adds into the plane gradients next (the HexPlane backward, a second regulariser call)
+            # waits for the event first (wait_reg_pending)
+            wait_reg_pending(dev)
+            cur, side = torch.cuda.current_stream(dev), side_stream(dev)
+            side.wait_stream(cur)                      # the upstream weight, and the clearing of the buffer above
+            N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), side.cuda_stream),
+                    "mom_plane_regulation")
+            up.record_stream(side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            _reg_pending[dev] = ev
+        else:
+            N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), N.current_stream()),
+                    "mom_plane_regulation")
         if direct:
             for p, gp, ip in zip(planes, grads, in_place):
                 if not ip:
                     if p.grad is None:
                         p.grad = gp
                     else:
+                        wait_reg_pending(dev)          # (a torch op on the caller's stream reads what the second stream writes)
                         p.grad.add_(gp)
             return (None, None) + (None,) * len(planes)
         return (None, None, *[gp if n else None for gp, n in zip(grads, ctx.needs_input_grad[2:])])
@@ -558,6 +616,9 @@ class FusedAdam(torch.optim.Optimizer):
         # the asynchronous training step points it at the rasterizer's sticky overflow word, so that a step whose image was
         # truncated never reaches the model; the host notices later and replays (train.Trainer._recover, rewind()).
         self.skip_flag = None
+        # (event, second stream, [(param, its gradient tensor, the gradient's version)]) left by render()'s backward when the
+        # appearance parameters' gradients became final, or None: see step()
+        self.early_hint = None
 
     def zero_grad(self, set_to_none=True):
         """torch.optim.Optimizer.zero_grad without its dynamo guard, foreach grouping and profiler range (30 us per call on the
@@ -687,12 +748,38 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        hint, self.early_hint = self.early_hint, None
+        joined = None
+        if hint is not None and self._early is None:
+            # render()'s backward (fused_autograd.py) recorded an event when the appearance parameters' gradients -- SH, scaling,
+            # rotation, opacity: four fifths of Adam's bytes -- were final, half-way through the backward.  If nothing has touched
+            # them since (same gradient tensors, same versions: any torch in-place op bumps the version; densify / prune replace the
+            # parameters and with them the optimizer's entries), their update goes to the second stream behind that event and runs
+            # underneath the deformation backward the GPU is still working on, as in the fused step (fused_step.py: early_adam).
+            # Element for element the same update as one step().
+            ev, side, entries = hint
+            mine = {id(p) for group in self.param_groups for p in group["params"]}
+            if all(id(p) in mine and p.grad is g and g._version == v for p, g, v in entries):
+                ps = [p for p, _, _ in entries]
+                self.ensure_state(ps)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    self.step_partial(ps)
+                joined = side
         early, self._early = self._early, None
         live = [(group, p) for group in self.param_groups for p in group["params"]
                 if p.grad is not None and (early is None or id(p) not in early)]
-        if not live:
-            return loss
-        self._launch(live, None if early is None else "late")
+        if live:
+            self._launch(live, None if early is None else "late")
+        if joined is not None:
+            torch.cuda.current_stream().wait_stream(joined)     # the step is complete for whatever the caller enqueues next
+        if API_OVERLAP and live:
+            # what a consumer of the parameters alone (the plane regularisers' forward) may wait for instead of the whole stream
+            planes = [p for _, p in live if p.dim() == 4]
+            if planes:
+                ev = torch.cuda.Event()
+                ev.record()
+                _params_ready[planes[0].device] = (ev, frozenset((id(p), p._version) for p in planes))
         return loss
 
 

@@ -53,6 +53,19 @@ for t in rng.choice(tiles, 200, replace=False):
     vb = v & (np.arange(n)[:, None, None] < nc[None])             # what render_bwd's `valid` is
     per_strip = vb.reshape(n, 4, 4, 16).sum(axis=(2, 3)).reshape(-1)
     lane_hist += np.bincount(per_strip, minlength=65)
+    # two splats per wave iteration, one per half-wave (denser pairs): each half of a strip walks its own list;
+    # an iteration serves one entry of each, so a strip needs max(|A|, |B|) iterations instead of |A u B|
+    strips = vb.reshape(n, 4, 4, 16)                                  # [n, strip, row in strip, x]
+    any_strip = strips.any(axis=(2, 3))                               # [n, 4]
+    halves = {"16x2": (strips[:, :, :2, :].any(axis=(2, 3)), strips[:, :, 2:, :].any(axis=(2, 3))),
+              "8x4": (strips[:, :, :, :8].any(axis=(2, 3)), strips[:, :, :, 8:].any(axis=(2, 3)))}
+    tot.setdefault("it_union", 0)
+    tot["it_union"] += int(any_strip.sum())
+    for name, (A, B) in halves.items():
+        tot.setdefault("it_" + name, 0)
+        tot.setdefault("halfpairs_" + name, 0)
+        tot["it_" + name] += int(np.maximum(A.sum(axis=0), B.sum(axis=0)).sum())
+        tot["halfpairs_" + name] += int(A.sum() + B.sum())
 print(tot)
 i = tot["inst"]
 print("valid pixels per instance", tot["px_valid"] / i)
@@ -64,3 +77,6 @@ print("render_bwd: executed (wave, splat) pairs per instance %.2f; valid lanes p
       (executed / i, float((lane_hist * np.arange(65)).sum()) / executed))
 edges = [(1, 1), (2, 4), (5, 8), (9, 16), (17, 32), (33, 48), (49, 64)]
 print("  share of executed pairs by valid lanes: " + ", ".join(f"{a}-{b}: {lane_hist[a:b + 1].sum() / executed:.3f}" for a, b in edges))
+for name in ("16x2", "8x4"):
+    print(f"half-wave lists {name}: iterations {tot['it_' + name]} against {tot['it_union']} now ({tot['it_' + name] / tot['it_union']:.3f}); "
+          f"(half, splat) pairs {tot['halfpairs_' + name]} = {tot['halfpairs_' + name] / tot['it_union']:.2f} per executed pair now (atomic rows)")
