@@ -244,9 +244,8 @@ def _backward(st, dcolor, ddepth, direct=True):
     if overlap:
         # the appearance parameters' gradients (SH, scaling, rotation, opacity) are final here: FusedAdam.step() may start their
         # update on the second stream behind this event while the deformation backward below still runs (ops.FusedAdam.step)
-        side = ops.side_stream(dev)
-        ready = torch.cuda.Event()
-        ready.record()
+        side = ops.side_stream(dev).cuda_stream
+        ready = ops.next_ring_mark(s)
     gplanes, gmlp, hp, md, in_place = _field_grads(st, f, direct)
     dfeat = e(P, 64)
     scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
@@ -255,7 +254,7 @@ def _backward(st, dcolor, ddepth, direct=True):
         # with a second stream the MLP backward leaves an eighth of the chip free (for that Adam launch) and its partial-sum
         # reduction goes there too (csrc/deform_bwd_b3.hip); joined below
         N.check(lib.mom_deform_backward_split(C.byref(md), P, st.feat.data_ptr(), st.a0.data_ptr(), gxyz.data_ptr(), gsc.data_ptr(),
-                                              grot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s, side.cuda_stream), "deform_bwd")
+                                              grot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s, side), "deform_bwd")
     else:
         N.check(lib.mom_deform_backward(C.byref(md), P, st.feat.data_ptr(), st.a0.data_ptr(), gxyz.data_ptr(), gsc.data_ptr(),
                                         grot.data_ptr(), dfeat.data_ptr(), scratch.data_ptr(), s), "deform_bwd")
@@ -270,7 +269,7 @@ def _backward(st, dcolor, ddepth, direct=True):
                                       None if porders is None else porders[1].data_ptr(),
                                       None if hscratch is None else hscratch.data_ptr(), s), "hexplane_bwd")
     if overlap:
-        torch.cuda.current_stream().wait_stream(side)      # the MLP weight gradients are complete for whoever reads them next
+        ops.stream_wait_stream(s, side)                    # the MLP weight gradients are complete for whoever reads them next
     st.ready, st.side = ready, side
     return g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp, in_place
 

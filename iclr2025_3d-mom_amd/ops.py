@@ -414,12 +414,38 @@ def side_stream(device):
     return st
 
 
+# Ordering goes through libmom4d's stream helpers (csrc/stream_order.hip), not torch's Stream / Event objects: a dozen of these per
+# iteration at 8-10 us each were a tenth of the path's host time.  Mark slots: 0 = the parameters as the last FusedAdam.step() left
+# them, 1 = the regulariser's gradient kernel on the second stream, 2.. = a ring for the backward's "appearance gradients final".
+MARK_PARAMS, MARK_REG, MARK_RING0, MARK_RING_N = 0, 1, 2, 62
+_ring = [0]
+
+
+def stream_wait_stream(waiter, signaler):
+    N.check(N.lib().mom_stream_wait_stream(waiter, signaler), "mom_stream_wait_stream")
+
+
+def stream_mark(slot, stream):
+    N.check(N.lib().mom_stream_mark(slot, stream), "mom_stream_mark")
+
+
+def stream_wait_mark(stream, slot):
+    N.check(N.lib().mom_stream_wait_mark(stream, slot), "mom_stream_wait_mark")
+
+
+def next_ring_mark(stream):
+    """Record the tail of `stream` under the next slot of the ring; returns the slot (valid until 62 more have been taken)."""
+    _ring[0] = (_ring[0] + 1) % MARK_RING_N
+    slot = MARK_RING0 + _ring[0]
+    stream_mark(slot, stream)
+    return slot
+
+
 def wait_reg_pending(device):
     """The current stream waits for a regulariser gradient kernel still running on the second stream (it ADDS into plane gradient
     buffers the caller is about to add into as well)."""
-    ev = _reg_pending.pop(device, None)
-    if ev is not None:
-        torch.cuda.current_stream(device).wait_event(ev)
+    if _reg_pending.pop(device, None) is not None:
+        stream_wait_mark(N.current_stream(), MARK_REG)
 
 
 # --------------------------------------------------------------------------- plane regularisers
@@ -450,12 +476,19 @@ class PlaneRegFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w_smooth, w_l1, *planes):
         _need_cuda(planes[0], "plane_regulation")
-        arr = (N.MomRegPlane * len(planes))()
-        for i, p in enumerate(planes):
-            st = plane_storage(p)
-            arr[i].plane, arr[i].grad = st.data_ptr(), None
-            arr[i].H, arr[i].W = st.shape[0], st.shape[1]
-            arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), 0.0
+        # the descriptor array holds pointers, shapes and weights only: rebuilt when one of them moves (the loop hands in the same
+        # twelve planes every iteration; twelve plane_storage() views and sixty field stores were 40 us of host time per call)
+        key = (tuple((p.data_ptr(), p.shape, p.stride()) for p in planes), tuple(w_smooth), tuple(w_l1))
+        c = PlaneRegFunction._fwd_cache
+        if c is None or c[0] != key:
+            arr = (N.MomRegPlane * len(planes))()
+            for i, p in enumerate(planes):
+                st = plane_storage(p)
+                arr[i].plane, arr[i].grad = st.data_ptr(), None
+                arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+                arr[i].w_smooth, arr[i].w_l1, arr[i].grad_scale = float(w_smooth[i]), float(w_l1[i]), 0.0
+            c = PlaneRegFunction._fwd_cache = (key, arr)
+        arr = c[1]
         dev = planes[0].device
         val = torch.empty(1, dtype=torch.float32, device=dev)
         if API_OVERLAP:
@@ -464,14 +497,14 @@ class PlaneRegFunction(torch.autograd.Function):
             # The second stream need not wait for the whole of the caller's queue if the planes are exactly as the last
             # FusedAdam.step() left them (same tensors, same versions -- any torch write since would have bumped one): then the
             # event that step recorded is the only dependency
-            cur, side = torch.cuda.current_stream(dev), side_stream(dev)
+            cur, side = N.current_stream(), side_stream(dev).cuda_stream
             mark = _params_ready.get(dev)
-            if mark is not None and mark[1] >= frozenset((id(p), p._version) for p in planes):
-                side.wait_event(mark[0])
+            if mark is not None and mark[0] == cur and mark[1] >= frozenset((id(p), p._version) for p in planes):
+                stream_wait_mark(side, MARK_PARAMS)
             else:
-                side.wait_stream(cur)
-            N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), side.cuda_stream), "mom_plane_regulation")
-            cur.wait_stream(side)
+                stream_wait_stream(side, cur)
+            N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), side), "mom_plane_regulation")
+            stream_wait_stream(cur, side)
         else:
             N.check(N.lib().mom_plane_regulation(arr, len(planes), val.data_ptr(), N.current_stream()), "mom_plane_regulation")
         ctx.save_for_backward(*planes)
@@ -524,14 +557,13 @@ class PlaneRegFunction(torch.autograd.Function):
             # compositing backward; whoever adds into the plane gradients next (the HexPlane backward, a second regulariser call)
             # waits for the event first (wait_reg_pending)
             wait_reg_pending(dev)
-            cur, side = torch.cuda.current_stream(dev), side_stream(dev)
-            side.wait_stream(cur)                      # the upstream weight, and the clearing of the buffer above
-            N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), side.cuda_stream),
-                    "mom_plane_regulation")
-            up.record_stream(side)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            _reg_pending[dev] = ev
+            side_t = side_stream(dev)
+            cur, side = N.current_stream(), side_t.cuda_stream
+            stream_wait_stream(side, cur)              # the upstream weight, and the clearing of the buffer above
+            N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), side), "mom_plane_regulation")
+            up.record_stream(side_t)                   # (the engine frees it when this node returns; the second stream still reads it)
+            stream_mark(MARK_REG, side)
+            _reg_pending[dev] = True
         else:
             N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), N.current_stream()),
                     "mom_plane_regulation")
@@ -547,6 +579,7 @@ class PlaneRegFunction(torch.autograd.Function):
         return (None, None, *[gp if n else None for gp, n in zip(grads, ctx.needs_input_grad[2:])])
 
     _cache = None
+    _fwd_cache = None
     DIRECT_GRADS = True
 
 
@@ -616,7 +649,7 @@ class FusedAdam(torch.optim.Optimizer):
         # the asynchronous training step points it at the rasterizer's sticky overflow word, so that a step whose image was
         # truncated never reaches the model; the host notices later and replays (train.Trainer._recover, rewind()).
         self.skip_flag = None
-        # (event, second stream, [(param, its gradient tensor, the gradient's version)]) left by render()'s backward when the
+        # (mark slot, second stream's handle, [(param, its gradient tensor, the gradient's version)]) left by render()'s backward when the
         # appearance parameters' gradients became final, or None: see step()
         self.early_hint = None
 
@@ -679,27 +712,30 @@ class FusedAdam(torch.optim.Optimizer):
         return tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
                       self.state[p]["step"].data_ptr(), p.numel()) for _, p in live)
 
-    def _launch(self, live, which):
-        for _, p in live:
-            st = self.state[p]
+    def _launch(self, live, which, stream=None):
+        state, key = self.state, []
+        for _, p in live:               # one pass: create missing state, and read the pointers the plan is keyed on
+            st = state[p]
             if len(st) == 0:
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-        key = self._plan_key(live)
+            key.append((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel()))
+        key = tuple(key)
         plan = self._plans.get(which)
         if plan is None or plan["key"] != key:
             plan = self._plans[which] = self._build_plan(live, key)
         if which is None:
             self._plan = plan
-        # this step's gradients: pointers refreshed and layouts checked every step (a pointer or an id() may be reused by another tensor)
+        # this step's gradients: pointers refreshed and strides checked every step.  (Shape, device and dtype need no check here:
+        # torch refuses a .grad assignment whose size, device or dtype differs from the parameter's -- THPVariable_set_grad --
+        # but it accepts any strides.)
+        arrs = plan["arrs"]
         for (group, b1, b2, cfg, i), p in zip(plan["entries"], plan["params"]):
             g = p.grad
-            if g.shape != p.shape or not g.is_cuda or g.dtype != p.dtype:
-                raise N.MomError("FusedAdam: gradient of another shape, device or dtype than its parameter")
             if g.stride() != p.stride() and not _same_layout(g, p):
                 raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
-            plan["arrs"][cfg][i].grad = g.data_ptr()
+            arrs[cfg][i].grad = g.data_ptr()
         plan["step_buf"] += 1
         arrs = plan["arrs"]
         # the step counters are host tensors the state surgery and rewind() may have touched: read them all in one go, and form
@@ -715,8 +751,8 @@ class FusedAdam(torch.optim.Optimizer):
             t.bias_correction1, t.bias_correction2_sqrt = bc
         for (b1, b2, eps), arr in arrs.items():
             N.check(N.lib().mom_adam_step(arr, len(arr), b1, b2, eps,
-                                          None if self.skip_flag is None else self.skip_flag.data_ptr(), N.current_stream()),
-                    "mom_adam_step")
+                                          None if self.skip_flag is None else self.skip_flag.data_ptr(),
+                                          N.current_stream() if stream is None else stream), "mom_adam_step")
 
     @torch.no_grad()
     def ensure_state(self, params):
@@ -730,7 +766,7 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
 
     @torch.no_grad()
-    def step_partial(self, params):
+    def step_partial(self, params, stream=None):
         """Advance only `params` (their gradients are final) on the CURRENT stream; the step() that follows in the same iteration
         advances the rest.  The fused training step uses it to put the Gaussians' appearance parameters -- 56 of their 59 floats,
         four fifths of Adam's bytes -- on its second stream underneath the deformation backward (fused_step.py).  Element for
@@ -739,7 +775,7 @@ class FusedAdam(torch.optim.Optimizer):
         live = [(group, p) for group in self.param_groups for p in group["params"] if id(p) in ids and p.grad is not None]
         if not live:
             return
-        self._launch(live, "early")
+        self._launch(live, "early", stream=stream)
         self._early = {id(p) for _, p in live}
 
     @torch.no_grad()
@@ -757,14 +793,13 @@ class FusedAdam(torch.optim.Optimizer):
             # parameters and with them the optimizer's entries), their update goes to the second stream behind that event and runs
             # underneath the deformation backward the GPU is still working on, as in the fused step (fused_step.py: early_adam).
             # Element for element the same update as one step().
-            ev, side, entries = hint
+            slot, side, entries = hint
             mine = {id(p) for group in self.param_groups for p in group["params"]}
             if all(id(p) in mine and p.grad is g and g._version == v for p, g, v in entries):
                 ps = [p for p, _, _ in entries]
                 self.ensure_state(ps)
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    self.step_partial(ps)
+                stream_wait_mark(side, slot)
+                self.step_partial(ps, stream=side)
                 joined = side
         early, self._early = self._early, None
         live = [(group, p) for group in self.param_groups for p in group["params"]
@@ -772,14 +807,14 @@ class FusedAdam(torch.optim.Optimizer):
         if live:
             self._launch(live, None if early is None else "late")
         if joined is not None:
-            torch.cuda.current_stream().wait_stream(joined)     # the step is complete for whatever the caller enqueues next
+            stream_wait_stream(N.current_stream(), joined)      # the step is complete for whatever the caller enqueues next
         if API_OVERLAP and live:
             # what a consumer of the parameters alone (the plane regularisers' forward) may wait for instead of the whole stream
             planes = [p for _, p in live if p.dim() == 4]
-            if planes:
-                ev = torch.cuda.Event()
-                ev.record()
-                _params_ready[planes[0].device] = (ev, frozenset((id(p), p._version) for p in planes))
+            if planes and planes[0].is_cuda:
+                cur = N.current_stream()
+                stream_mark(MARK_PARAMS, cur)
+                _params_ready[planes[0].device] = (cur, frozenset((id(p), p._version) for p in planes))
         return loss
 
 

@@ -22,12 +22,20 @@ from .gaussian_renderer import render
 from .utils.image_io import save_image, save_uint8
 
 
+# zlib level of the asynchronous writer's PNGs.  PNG is lossless at every level: the decoded pixels are the same bytes, only the
+# files are larger (1.2 MB instead of 1.0 MB per 960x540 frame of the synthetic scene) -- and deflate is what the as-scripted
+# render loop waits for (a frame takes 0.26 ms to render and ~35 ms of one host core to compress at level 6, torchvision's / PIL's
+# default, which the blocking order `scripted=True` keeps).
+PNG_COMPRESS_LEVEL = int(os.environ.get("MOM_PNG_LEVEL", "1"))
+
+
 class AsyncPNGWriter:
     """submit(image [3,H,W] on the GPU, path): quantise on the device, copy to a pinned slot behind the frame's kernels, encode on
     a worker thread.  At most `slots` frames are in flight; submit() blocks only when all slots are busy."""
 
-    def __init__(self, H, W, C=3, slots=48, workers=None):
+    def __init__(self, H, W, C=3, slots=48, workers=None, compress_level=None):
         self.H, self.W, self.C = H, W, C
+        self.level = PNG_COMPRESS_LEVEL if compress_level is None else int(compress_level)
         self.host = [torch.empty((H, W, C), dtype=torch.uint8).pin_memory() for _ in range(slots)]
         self.dev = [None] * slots
         self.free = queue.Queue()
@@ -52,7 +60,7 @@ class AsyncPNGWriter:
     def _encode(self, slot, ev, path):
         try:
             ev.synchronize()
-            save_uint8(self.host[slot].numpy(), path)
+            save_uint8(self.host[slot].numpy(), path, self.level)
         finally:
             self.free.put(slot)
 

@@ -447,6 +447,17 @@ int mom_profile_enable(int slot, int on);
 int mom_profile_read(int slot, double* total_ms, long long* count, int reset);
 const char* mom_profile_name(int slot);
 
+/* Stream ordering for a host mirror that runs parts of a step on a second stream (no counterpart in the reference, whose loop is
+ * single-stream; torch's own Stream / Event objects do the same at 8-10 us of host time per call).
+ * mom_stream_wait_stream: everything enqueued on `waiter` after this call runs after everything enqueued on `signaler` before it.
+ * mom_stream_mark / mom_stream_wait_mark: a ring of MOM_STREAM_MARKS reusable marks per device -- record the current tail of a
+ * stream under a slot number, make another stream wait for it later (a wait refers to the slot's most recent record at the time of
+ * the call; waiting for a slot that was never recorded is MOM_EINVAL). */
+#define MOM_STREAM_MARKS 64
+int mom_stream_wait_stream(mom_stream_t waiter, mom_stream_t signaler);
+int mom_stream_mark(int slot, mom_stream_t stream);
+int mom_stream_wait_mark(mom_stream_t stream, int slot);
+
 /* Self test of the wave64 DPP reduction used by the render backward:
  * out[w] = sum(in[64w .. 64w+63]). */
 int mom_selftest_wave_sum(const float* in, float* out, int waves, mom_stream_t stream);

@@ -214,10 +214,10 @@ def _api_steps(overlap, steps=4, touch=None):
         scene, g, trainer, op = bench.build_state(cfg, torch.device("cuda"), fused=False, lambda_dssim=0.2)
         orig = g.optimizer.step_partial
 
-        def counted(params):
+        def counted(params, stream=None):
             calls[0] += 1
-            assert torch.cuda.current_stream() != torch.cuda.default_stream()        # on the second stream
-            return orig(params)
+            assert stream is not None and stream != torch.cuda.current_stream().cuda_stream        # on the second stream
+            return orig(params, stream=stream)
         g.optimizer.step_partial = counted
         if touch is not None:
             after = trainer._after_backward

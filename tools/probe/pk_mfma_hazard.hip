@@ -33,6 +33,26 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c)
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// the forms the SLP vectoriser emits in the real kernel: one 32-bit register broadcast to both halves through op_sel_hi
+// (src0 = {b, b} read from the LOW register of the pair `b2`: op_sel_hi:[0,1,1])
+__device__ __forceinline__ f32x2 pk_fma_bcast0(f32x2 b2, f32x2 x, f32x2 c)
+{
+    f32x2 d;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(b2), "v"(x), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_mul_bcast1(f32x2 x, f32x2 b2)
+{
+    f32x2 d;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(x), "v"(b2));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
 {
     f32x2 d;
@@ -41,10 +61,11 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
 }
 
 // mfma: 0 none (matrix waves idle), 1 bf16 32x32x16, 2 f32 32x32x2.  packed: the vector waves' arithmetic.
-template <int MFMA, bool PACKED>
-__global__ void __launch_bounds__(512) probe(const float4* __restrict__ texels, const float2* __restrict__ frac, float4* __restrict__ out, float* sink)
+template <int MFMA, bool PACKED, bool OPSEL, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) probe(const float4* __restrict__ texels, const float2* __restrict__ frac, float4* __restrict__ out, float* sink)
 {
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ bf16x8 s_w[4][64 * 8];
     if (wv < 4) {
         if (MFMA == 0) return;
         f32x16 acc0 = {0}, acc1 = {0};
@@ -52,9 +73,13 @@ __global__ void __launch_bounds__(512) probe(const float4* __restrict__ texels, 
             bf16x8 a, b;
 #pragma unroll
             for (int j = 0; j < 8; j++) { a[j] = (__bf16)(0.001f * (lane + j)); b[j] = (__bf16)1.0f; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) s_w[wv][j * 64 + lane] = a;
+            __builtin_amdgcn_wave_barrier();
             for (int i = 0; i < kIters * 12; i++) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, acc1, 0, 0, 0);
+                const bf16x8 w = s_w[wv][(i & 7) * 64 + lane];          // the A operand comes out of LDS, as the weights do in the real kernel
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, b, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, w, acc1, 0, 0, 0);
             }
         } else {
             const float a = 0.001f * lane, b = 1.0f;
@@ -67,7 +92,7 @@ __global__ void __launch_bounds__(512) probe(const float4* __restrict__ texels, 
         return;
     }
     // vector waves: kIters bilinear samples of four float4 texels each, as the HexPlane gather forms them
-    const int vw = blockIdx.x * 4 + (wv - 4);
+    const int vw = blockIdx.x * (WAVES - 4) + (wv - 4);
     for (int it = 0; it < kIters; it++) {
         const unsigned idx = (unsigned)(vw * kIters + it) * 64u + lane;
         const unsigned t0 = (idx * 2654435761u) >> 16;                   // 16-bit texel index
@@ -75,7 +100,17 @@ __global__ void __launch_bounds__(512) probe(const float4* __restrict__ texels, 
         const float4 q10 = texels[(t0 + 257) & (kTexels - 1)], q11 = texels[(t0 + 258) & (kTexels - 1)];
         const float2 b = frac[idx & (kTexels - 1)];
         float4 r;
-        if (PACKED) {
+        if (PACKED && OPSEL) {
+            // the same arithmetic with the broadcast forms (the fractions live in ONE register each, the low one of a pair)
+            const f32x2 bxy = {b.x, b.y}, axy = {1.f - b.x, 1.f - b.y}, byx = {b.y, b.x}, ayx = {1.f - b.y, 1.f - b.x};
+            const f32x2 a0 = {q00.x, q00.y}, a1 = {q00.z, q00.w}, b0 = {q01.x, q01.y}, b1 = {q01.z, q01.w};
+            const f32x2 c0 = {q10.x, q10.y}, c1 = {q10.z, q10.w}, d0 = {q11.x, q11.y}, d1 = {q11.z, q11.w};
+            const f32x2 top0 = pk_fma_bcast0(bxy, b0, pk_mul_bcast1(a0, axy)), top1 = pk_fma_bcast0(bxy, b1, pk_mul_bcast1(a1, axy));
+            const f32x2 bot0 = pk_fma_bcast0(bxy, d0, pk_mul_bcast1(c0, axy)), bot1 = pk_fma_bcast0(bxy, d1, pk_mul_bcast1(c1, axy));
+            const f32x2 v0 = pk_fma_bcast0(byx, bot0, pk_mul_bcast1(top0, ayx)), v1 = pk_fma_bcast0(byx, bot1, pk_mul_bcast1(top1, ayx));
+            const f32x2 w0 = pk_add(pk_mul(v0, v0), top0), w1 = pk_add(pk_mul(v1, v1), top1);
+            r = make_float4(w0.x, w0.y, w1.x, w1.y);
+        } else if (PACKED) {
             const f32x2 bx = {b.x, b.x}, by = {b.y, b.y}, ax = {1.f - b.x, 1.f - b.x}, ay = {1.f - b.y, 1.f - b.y};
             const f32x2 a0 = {q00.x, q00.y}, a1 = {q00.z, q00.w}, b0 = {q01.x, q01.y}, b1 = {q01.z, q01.w};
             const f32x2 c0 = {q10.x, q10.y}, c1 = {q10.z, q10.w}, d0 = {q11.x, q11.y}, d1 = {q11.z, q11.w};
@@ -102,16 +137,16 @@ __global__ void __launch_bounds__(512) probe(const float4* __restrict__ texels, 
     }
 }
 
-template <int MFMA, bool PACKED>
+template <int MFMA, bool PACKED, bool OPSEL = false, int WAVES = 8>
 static void launch(const float4* tex, const float2* frac, float4* out, float* sink)
 {
-    hipLaunchKernelGGL((probe<MFMA, PACKED>), dim3(kBlocks), dim3(512), 0, 0, tex, frac, out, sink);
+    hipLaunchKernelGGL((probe<MFMA, PACKED, OPSEL, WAVES>), dim3(kBlocks), dim3(64 * WAVES), 0, 0, tex, frac, out, sink);
 }
 
 int main(int argc, char** argv)
 {
     const int launches = argc > 1 ? atoi(argv[1]) : 1000;
-    const size_t n = (size_t)kBlocks * 4 * kIters * 64;
+    const size_t n = (size_t)kBlocks * 12 * kIters * 64;          // the largest case: twelve vector waves per workgroup
     std::vector<float4> h_tex(kTexels);
     std::vector<float2> h_frac(kTexels);
     unsigned s = 12345u;
@@ -132,9 +167,12 @@ int main(int argc, char** argv)
         {"packed fp32 beside f32 MFMA  (v_mfma_f32_32x32x2_f32)  ", launch<0, true>, launch<2, true>},
         {"scalar fp32 beside bf16 MFMA                            ", launch<0, false>, launch<1, false>},
         {"packed fp32, matrix waves idle                          ", launch<0, true>, launch<0, true>},
+        {"packed fp32 with op_sel broadcasts beside bf16 MFMA     ", launch<0, true, true>, launch<1, true, true>},
+        {"the same, 16 waves per workgroup (1 matrix + 3 vector waves per SIMD, the real kernel's shape)", launch<0, true, true, 16>, launch<1, true, true, 16>},
     };
     printf("{\"launches_per_case\": %d, \"elements_per_launch\": %zu, \"cases\": [\n", launches, n * 4);
     for (size_t c = 0; c < sizeof(cases) / sizeof(cases[0]); c++) {
+        (void)hipMemset(ref, 0xff, n * 16);
         cases[c].ref_fn(tex, frac, ref, sink);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h_ref.data(), ref, n * 16, hipMemcpyDeviceToHost);
