@@ -38,52 +38,75 @@ class FusedStep:
         return dc.world * dc.slice_rows(P) if (dc is not None and dc.mode == "tile-row") else P
 
     def _ensure(self, P, W, H, dev):
-        if P == self.P and getattr(self, "_wh", None) == (W, H) and getattr(self, "_pad", None) == self._rows(P):
+        """The step's buffers.  Per-Gaussian storage is CAPACITY based: a densify / prune round changes P by a few percent every
+        hundred iterations (train_4DGS.py:264-290), and re-making fifty buffers each time sent the step after every round back to
+        the driver for fresh memory (tools/probe/c5_leg.py: the first round of a process cost 148 ms instead of 13 and the steps
+        behind it ran at 59 instead of 94 per second until the new pages had been touched).  Storage is re-made only when the
+        model outgrows it (then with a quarter of headroom) or shrinks below half of it; otherwise the attributes below are
+        re-sliced views of the same memory."""
+        pad = self._rows(P)
+        key = (P, W, H, pad, dev)
+        if key == getattr(self, "_key", None):
             return
-        self.P, self._wh = P, (W, H)
-        Pp = self._pad = self._rows(P)
+        self._key = key
+        self.P, self._wh, self._pad = P, (W, H), pad
         f = dict(dtype=torch.float32, device=dev)
         e = lambda *s: torch.empty(*s, **f)
-        self.feat, self.a0, self.dfeat = e(P, 64), e(P, 64), e(P, 64)
-        # (the gathered buffers of a tile-row shard carry world x S >= P rows; every kernel reads the first P)
-        self.pts, self.sc_d, self.rot_d = e(Pp, 3), e(P, 3), e(Pp, 4)
-        self.sc, self.rot, self.op = e(Pp, 3), e(Pp, 4), e(Pp, 1)
-        self.color, self.depth = e(3, H, W), e(1, H, W)
-        self.radii = torch.empty(P, dtype=torch.int32, device=dev)
-        self.geom = torch.empty(self.lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
-        self.img = torch.empty(self.lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
-        self.nr_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        # Sticky overflow word (mom_raster_forward_render only ever sets bits in it).  The binning buffer is sized from
-        # earlier frames without waiting for this frame's count; when a frame does not fit, its image and gradients are
-        # truncated, the word becomes nonzero and stays so, and Adam / the densification statistics of that step and of every
-        # later one are no-ops ON THE DEVICE (mom_adam_step / mom_densify_stats skip_if_nonzero) until the host -- which
-        # runs several steps ahead and reads the word through flag_ring a few steps later -- clears it and replays the
-        # skipped iterations with an exactly sized buffer (train.Trainer._recover).  Nothing truncated ever reaches the model.
-        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.flag_ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+        cap = getattr(self, "_rows_cap", 0)
+        same_frame = getattr(self, "_store_for", None) == (W, H, dev)
+        if not same_frame:
+            self._store_for = (W, H, dev)
+            self.color, self.depth, self.dimg = e(3, H, W), e(1, H, W), e(3, H, W)
+            self.img = torch.empty(self.lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
+            self.nr_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            # Sticky overflow word (mom_raster_forward_render only ever sets bits in it).  The binning buffer is sized from
+            # earlier frames without waiting for this frame's count; when a frame does not fit, its image and gradients are
+            # truncated, the word becomes nonzero and stays so, and Adam / the densification statistics of that step and of every
+            # later one are no-ops ON THE DEVICE (mom_adam_step / mom_densify_stats skip_if_nonzero) until the host -- which
+            # runs several steps ahead and reads the word through flag_ring a few steps later -- clears it and replays the
+            # skipped iterations with an exactly sized buffer (train.Trainer._recover).  Nothing truncated ever reaches the model.
+            self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.flag_ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
+            self.next_tag = 1
+            # loss accumulators live in spare words of the image scratch's header, which the rasterizer forward clears at the
+            # start of every step together with its tile counters: no memset of their own (mom_l1_loss_acc / mom_plane_regulation_acc)
+            hdr_f = self.img[(-self.img.data_ptr()) % 256:][:256].view(torch.float32)
+            self.sums, self.regval = hdr_f[8:10], hdr_f[10:11]
+            self.ssim_dm = None                  # SSIM term: made on first use (lambda_dssim may be switched on later)
+            self.binning = None
+        if not same_frame or pad > cap or 2 * pad < cap:
+            grew = same_frame and cap and pad > cap
+            cap = self._rows_cap = pad + pad // 4 if grew else pad
+            st = self._store = {name: e(cap, cols) for name, cols, _ in self._ROW_BUFFERS}
+            st["radii"] = torch.empty(cap, dtype=torch.int32, device=dev)
+            st["early"] = e(56 * cap)
+            st["loc"] = (e(cap, 3), e(cap, 4))
+            self.geom = torch.empty(self.lib.mom_raster_geom_bytes(cap), dtype=torch.uint8, device=dev)
+            self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+        # the step after a change of P sizes its binning buffer from its own count (one sync); the buffer itself is kept if it fits
         self.cap = 0
-        self.binning = None
         self._resize_next = False
-        self.next_tag = 1
-        self.dimg = e(3, H, W)
-        # loss accumulators live in spare words of the image scratch's header, which the rasterizer forward clears at the start
-        # of every step together with its tile counters: no memset of their own (mom_l1_loss_acc / mom_plane_regulation_acc)
-        hdr_f = self.img[(-self.img.data_ptr()) % 256:][:256].view(torch.float32)
-        self.sums, self.regval = hdr_f[8:10], hdr_f[10:11]
-        self.ssim_dm = None                  # SSIM term: made on first use (lambda_dssim may be switched on later)
-        self.g2d, self.gcol, self.gop_act, self.gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 6)
-        self.gsc_act, self.grot_act = e(P, 3), e(P, 4)
+        st = self._store
+        # (the gathered buffers of a tile-row shard carry world x S >= P rows; every kernel reads the first P)
+        for name, _, padded in self._ROW_BUFFERS:
+            setattr(self, name, st[name][:pad if padded else P])
+        self.radii = st["radii"][:P]
         # parameter gradients (persist across steps; .grad points at them).  They live in two flat buckets so that a
         # multi-GPU run all-reduces them in place, without packing: `early` (final once the activation backward has run:
         # SH, scaling, rotation, opacity = 56 floats per Gaussian) and `late` (xyz + the deformation field, final only
         # after the HexPlane backward; made in _deform_grads).
-        self.early = e(56 * P)
+        self.early = st["early"][:56 * P]
         cut = [0, 3 * P, 48 * P, 51 * P, 55 * P, 56 * P]
         seg = lambda i: self.early[cut[i]:cut[i + 1]]
         self.gdc, self.grest = seg(0).view(P, 1, 3), seg(1).view(P, 15, 3)
         self.gsc, self.grot, self.gop = seg(2).view(P, 3), seg(3).view(P, 4), seg(4).view(P, 1)
-        self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+        self._loc = (st["loc"][0][:P], st["loc"][1][:P])
+
+    # per-Gaussian float buffers: (attribute, floats per row, sized for a tile-row shard's padded row count)
+    _ROW_BUFFERS = (("feat", 64, False), ("a0", 64, False), ("dfeat", 64, False), ("pts", 3, True), ("sc_d", 3, False),
+                    ("rot_d", 4, True), ("sc", 3, True), ("rot", 4, True), ("op", 1, True), ("g2d", 3, False), ("gcol", 3, False),
+                    ("gop_act", 1, False), ("gcov", 6, False), ("gsc_act", 3, False), ("grot_act", 4, False))
 
     RING = 64
     OVERLAP_DW = os.environ.get("MOM_OVERLAP_DW", "1") != "0"     # the MLP weight-gradient kernel on a second stream, beside the HexPlane backward
@@ -104,6 +127,15 @@ class FusedStep:
         ev.record()
         return ev
 
+    def _hex_scratch_for(self, hp, rows, dev):
+        """Scratch of the two-pass HexPlane backward for `rows` points (common-factor rows + the time lines): kept while it is
+        large enough and not more than twice too large."""
+        need = self.lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), rows)
+        t = getattr(self, "_hex_scratch", None)
+        if t is None or t.device != dev or t.numel() < need or t.numel() > 2 * need + (1 << 20):
+            grow = t is not None and t.device == dev and t.numel() < need
+            self._hex_scratch = torch.empty(need + need // 4 if grow else need, dtype=torch.uint8, device=dev)
+
     def _gacc_view(self, P, W, H):
         """The per-Gaussian record of the compositing backward inside the geometry scratch, as a flat fp32 tensor."""
         lay = N.MomRasterLayout()
@@ -116,10 +148,13 @@ class FusedStep:
         dn = self.g._deformation.deformation_net
         planes = [p for lv in dn.grid.grids for p in lv]
         mlp = dn._fused_params()
-        key = tuple(p.data_ptr() for p in planes + mlp) + (self.P, self._pad)
+        key = tuple(p.data_ptr() for p in planes + mlp) + (self.P, self._pad, self._rows_cap)
         if getattr(self, "_dg_key", None) != key:
             n = self._dg_n = sum(p.numel() for p in planes + mlp)
-            self._dg_flat = torch.zeros(n + 3 * self._pad, dtype=torch.float32, device=planes[0].device)   # the `late` bucket
+            store = getattr(self, "_dg_store", None)
+            if store is None or store.numel() != n + 3 * self._rows_cap or store.device != planes[0].device:
+                store = self._dg_store = torch.zeros(n + 3 * self._rows_cap, dtype=torch.float32, device=planes[0].device)
+            self._dg_flat = store[:n + 3 * self._pad]                                                       # the `late` bucket
             self.gxyz_rows = self._dg_flat[n:].view(self._pad, 3)
             self.gxyz = self.gxyz_rows[:self.P]
             off, self._dg_planes, self._dg_mlp = 0, [], []
@@ -272,9 +307,10 @@ class FusedStep:
             torch.cuda.current_stream().synchronize()
             prev_R = int(self.nr_host[0])
         want = max(prev_R, int(prev_R * self.HEADROOM) + self.MARGIN)
-        if self.binning is None or want > self.cap or want < self.cap // 4:
-            self.cap = want
-            self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, self.cap), dtype=torch.uint8, device=dev)
+        if self.binning is None or want > self._bin_cap or want < self._bin_cap // 4:
+            self._bin_cap = want
+            self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, want), dtype=torch.uint8, device=dev)
+        self.cap = self._bin_cap          # the capacity every launch of this step is told (cap == 0 above: "size exactly")
         N.check(lib.mom_raster_forward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                               self.img.data_ptr(), self.color.data_ptr(), self.depth.data_ptr(),
                                               self.flags.data_ptr(), s), "raster_render")
@@ -366,8 +402,6 @@ class FusedStep:
         if dc is not None and dc.mode == "camera":      # 56 of the 59 floats per Gaussian travel underneath the deformation backward
             # the deformation backward below still reads this rank's own d_sc / d_rot while the bucket is being reduced in
             # place: give it private copies (7 floats per Gaussian)
-            if getattr(self, "_loc", None) is None or self._loc[0].shape[0] != P:
-                self._loc = (torch.empty_like(self.gsc), torch.empty_like(self.grot))
             d_sc, d_rot = self._loc
             d_sc.copy_(self.gsc)
             d_rot.copy_(self.grot)
@@ -402,9 +436,8 @@ class FusedStep:
             N.check(lib.mom_deform_backward_split(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
                                                   d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
                                                   self.dh_scratch.data_ptr(), s, side), "deform_bwd")
-            if porders is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (P, hp.levels)):
-                self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
-                self._hex_scratch_key = (P, hp.levels)
+            if porders is not None:
+                self._hex_scratch_for(hp, P, dev)
             if porders is not None and lines_kept:      # the forward's time lines are still in the field scratch
                 N.check(lib.mom_hexplane_backward_lines(C.byref(hp), P, xyz.data_ptr(), time, optr, self.dfeat.data_ptr(),
                                                         self.gxyz.data_ptr(), porders[0].data_ptr(), porders[1].data_ptr(),
@@ -428,9 +461,8 @@ class FusedStep:
                                                       v(self.dfeat).data_ptr(), self.dh_scratch.data_ptr(), s, side), "deform_bwd")
                 so = field._slice_order(xyz, g0, g1, bump=False)      # the forward's order of this step
                 spo = field._slice_plane_orders(xyz, g0, g1)
-                if spo is not None and (getattr(self, "_hex_scratch", None) is None or self._hex_scratch_key != (ns, hp.levels)):
-                    self._hex_scratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), ns), dtype=torch.uint8, device=dev)
-                    self._hex_scratch_key = (ns, hp.levels)
+                if spo is not None:
+                    self._hex_scratch_for(hp, ns, dev)
                 N.check(lib.mom_hexplane_backward(C.byref(hp), ns, v(xyz).data_ptr(), None, time, None if so is None else so.data_ptr(),
                                                   v(self.dfeat).data_ptr(), v(self.gxyz).data_ptr(),
                                                   None if spo is None else spo[0].data_ptr(), None if spo is None else spo[1].data_ptr(),
