@@ -397,7 +397,11 @@ def ssim(img1, img2):
 
 
 # --------------------------------------------------------------------------- second stream of the autograd path
-API_OVERLAP = _os.environ.get("MOM_API_OVERLAP", "1") != "0"
+# OFF by default: measured in one process, alternating (tools/probe/api_leg.py, config 2): with it the path enqueues a step in 1.08
+# instead of 0.95 ms of host time (a second Adam launch, a dozen ordering calls) and the HOST is what paces this path -- 925 against
+# 1015 steps/s in async mode, 745 against 780-920 in exact mode.  It pays only where the GPU is the bottleneck (larger models, a
+# faster host); MOM_API_OVERLAP=1 or ops.API_OVERLAP = True switches it on.
+API_OVERLAP = _os.environ.get("MOM_API_OVERLAP", "0") == "1"
 _side_streams = {}
 _reg_pending = {}      # device -> event: the regulariser's gradient kernel on the second stream; the next writer of plane gradients waits
 _params_ready = {}     # device -> (event recorded at the end of the last FusedAdam.step(), ((id, version) of every plane it updated))
@@ -407,7 +411,7 @@ def side_stream(device):
     """One second stream per device for the render() + loss.backward() path: it carries what does not depend on the compositing
     (the plane regularisers' two kernels), the MLP backward's partial-sum reduction and -- the largest piece -- the appearance
     parameters' Adam launch, which FusedAdam.step() starts there behind the event the backward recorded when those gradients
-    became final (fused_autograd.py).  MOM_API_OVERLAP=0 keeps everything on the caller's stream."""
+    became final (fused_autograd.py).  Opt-in (API_OVERLAP above): by default everything stays on the caller's stream."""
     st = _side_streams.get(device)
     if st is None:
         st = _side_streams[device] = torch.cuda.Stream(device=device)
