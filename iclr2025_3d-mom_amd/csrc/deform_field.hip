@@ -531,6 +531,13 @@ __device__ __forceinline__ void layer_b3(const uint4* __restrict__ wf /* [3][2][
         }
 }
 
+// -DMOM_B3_PAD_NOPS: 64 wait states behind every burst of MFMAs (tools/probe/pk_hazard_real.py: does the packed-fp32 observation
+// need a vector instruction close behind the wave's OWN MFMAs?  DESIGN.md section 5).  Empty in the shipped build.
+#ifdef MOM_B3_PAD_NOPS
+#define MOM_B3_PAD() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
+#else
+#define MOM_B3_PAD() do { } while (0)
+#endif
 __global__ void __launch_bounds__(64 * kB3Waves)
 deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float* __restrict__ lines, const float* __restrict__ xyz,
                            const float* __restrict__ scaling, const float* __restrict__ rotation, const float* __restrict__ flow,
@@ -613,6 +620,7 @@ deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const flo
         init_bias(lds + kL3B, acc, h);
 #ifndef MOM_B3_NOMFMA
         layer_b3(wfrag, B, acc, lane);
+        MOM_B3_PAD();
 #else
         acc[0][0] += __uint_as_float(B[0].p[0].x + B[3].p[2].w);
 #endif
@@ -628,6 +636,7 @@ deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const flo
             init_bias(lds + kL3B + (1 + head) * kHid, h1, h);
 #ifndef MOM_B3_NOMFMA
             layer_b3(wfrag + (1 + head) * (3 * 2 * 4 * 64), A0, h1, lane);
+            MOM_B3_PAD();
 #else
             h1[0][0] += __uint_as_float(A0[0].p[0].x + A0[3].p[2].w);
 #endif

@@ -51,6 +51,7 @@ def main():
     inv = torch.empty(P, dtype=torch.int64, device="cuda")
     inv[order.long() & 0xFFFFFFFF] = torch.arange(P, device="cuda")          # position of a Gaussian in the processing order
     wrong_launches = 0
+    other_wrong = {"a0": 0, "pts": 0, "sc_d": 0, "rot_d": 0}        # launches whose MLP outputs leave the two-kernel path's gates
     by_pos32 = torch.zeros(32, dtype=torch.int64, device="cuda")
     by_col = torch.zeros(64, dtype=torch.int64, device="cuda")
     examples = []
@@ -62,6 +63,9 @@ def main():
         bad = (again["feat"] - ref["feat"]).abs() > tol
         bad |= ~torch.isfinite(again["feat"])
         nb = int(bad.sum())
+        for k, tol_k in (("a0", 5e-5 * max(1.0, float(ref["a0"].abs().max()))), ("pts", 1e-4), ("sc_d", 1e-4), ("rot_d", 1e-4)):
+            if bool(((again[k] - ref[k]).abs() > tol_k).any()) or not bool(torch.isfinite(again[k]).all()):
+                other_wrong[k] += 1
         if nb:
             wrong_launches += 1
             rows, cols = bad.nonzero(as_tuple=True)
@@ -72,7 +76,8 @@ def main():
                 examples.append({"launch": i, "wrong_elements": nb, "gaussian": r, "position_in_order": int(inv[r]), "column": c,
                                  "got": float(again["feat"][r, c]), "want": float(ref["feat"][r, c])})
     print(json.dumps({"library": os.environ.get("MOM4D_LIB", "shipped"), "lib_version": lib.mom_version().decode(), "launches": launches,
-                      "wrong_launches": wrong_launches, "wrong_feature_elements_by_position_in_tile_of_32": by_pos32.tolist(),
+                      "wrong_launches": wrong_launches, "launches_with_wrong_mlp_outputs": other_wrong,
+                      "wrong_feature_elements_by_position_in_tile_of_32": by_pos32.tolist(),
                       "wrong_feature_elements_by_column": by_col.tolist(), "examples": examples}))
 
 
