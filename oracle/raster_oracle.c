@@ -475,7 +475,8 @@ void oracle_bin(int P, int W, int H, int num_rendered, const real* points_xy, co
 void oracle_render_forward(int W, int H, const uint32_t* ranges, const uint32_t* point_list,
                            const real* points_xy_image, const real* features, const real* depths,
                            const real* conic_opacity, const real* bg_color, real* final_T, uint32_t* n_contrib,
-                           real* out_color, real* out_depth, uint64_t* pairs_evaluated /* optional */)
+                           real* out_color, real* out_depth, uint64_t* pairs_evaluated /* optional */,
+                           uint32_t* tile_walked /* optional [tiles]: entries the tile's BLOCK walks before it exits */)
 {
     const int grid_x = (W + BLOCK_X - 1) / BLOCK_X, grid_y = (H + BLOCK_Y - 1) / BLOCK_Y;
     uint64_t total_pairs = 0;
@@ -483,6 +484,11 @@ void oracle_render_forward(int W, int H, const uint32_t* ranges, const uint32_t*
     for (int tile = 0; tile < grid_x * grid_y; tile++) {
         const int tx = tile % grid_x, ty = tile / grid_x;
         const uint32_t rx = ranges[2 * tile], ry = ranges[2 * tile + 1];
+        /* the block's own walk (forward.cu:305-312): the list is fetched in rounds of BLOCK_SIZE entries and a round is entered
+         * unless every thread of the block is done (threads outside the image are done from the start).  So the block walks the
+         * whole list if any pixel never saturates, else up to the end of the round in which the last pixel saturated. */
+        uint32_t last_done_at = 0;
+        int any_not_done = 0;
         for (int ly = 0; ly < BLOCK_Y; ly++)
             for (int lx = 0; lx < BLOCK_X; lx++) {
                 const int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
@@ -491,7 +497,7 @@ void oracle_render_forward(int W, int H, const uint32_t* ranges, const uint32_t*
                 const int pix_id = W * py + px;
                 const real pixf[2] = {(real)px, (real)py};
                 real T = (real)1.0;
-                uint32_t contributor = 0, last_contributor = 0;
+                uint32_t contributor = 0, last_contributor = 0, done_at = 0;
                 real C[NUM_CHANNELS] = {0};
                 real Dp = 0;
                 for (uint32_t k = rx; k < ry; k++) {
@@ -508,20 +514,31 @@ void oracle_render_forward(int W, int H, const uint32_t* ranges, const uint32_t*
                     if (alpha < (real)1.0 / (real)255.0)
                         continue;
                     real test_T = T * (1 - alpha);
-                    if (test_T < (real)0.0001f)
+                    if (test_T < (real)0.0001f) {
+                        done_at = contributor;
                         break; /* done = true */
+                    }
                     for (int ch = 0; ch < NUM_CHANNELS; ch++)
                         C[ch] += features[id * NUM_CHANNELS + ch] * alpha * T;
                     Dp += depths[id] * alpha * T;
                     T = test_T;
                     last_contributor = contributor;
                 }
+                if (done_at == 0)
+                    any_not_done = 1;
+                else if (done_at > last_done_at)
+                    last_done_at = done_at;
                 final_T[pix_id] = T;
                 n_contrib[pix_id] = last_contributor;
                 for (int ch = 0; ch < NUM_CHANNELS; ch++)
                     out_color[ch * H * W + pix_id] = C[ch] + T * bg_color[ch];
                 out_depth[pix_id] = Dp;
             }
+        if (tile_walked) {
+            const uint32_t len = ry - rx;
+            const uint32_t upto = (last_done_at + BLOCK_SIZE - 1) / BLOCK_SIZE * BLOCK_SIZE;
+            tile_walked[tile] = (any_not_done || upto > len) ? len : upto;
+        }
     }
     if (pairs_evaluated)
         *pairs_evaluated = total_pairs;

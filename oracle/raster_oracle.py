@@ -114,6 +114,8 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
     st["ranges"] = np.zeros((gx * gy, 2), np.uint32)
     st["final_T"] = np.zeros(H * W, rt)
     st["n_contrib"] = np.zeros(H * W, np.uint32)
+    # entries each tile's BLOCK walks before it exits (forward.cu:305-312): SURVEY 8d's Q = 256 x their sum
+    st["tile_walked"] = np.zeros(gx * gy, np.uint32)
     if P == 0:  # rasterize_points.cu:82 short-circuit
         st["num_rendered"] = 0
         st["point_list"] = np.zeros(0, np.uint32)
@@ -140,7 +142,7 @@ def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, t
     pairs = C.c_uint64(0)
     lib.oracle_render_forward(C.c_int(W), C.c_int(H), _p(st.ranges), _p(st.point_list), _p(st.means2D),
                               _p(feat), _p(st.depths), _p(st.conic_opacity), _p(bg), _p(st.final_T),
-                              _p(st.n_contrib), _p(st.out_color), _p(st.out_depth), C.byref(pairs))
+                              _p(st.n_contrib), _p(st.out_color), _p(st.out_depth), C.byref(pairs), _p(st.tile_walked))
     st["pairs_evaluated"] = int(pairs.value)
     st["_inputs"] = dict(means3D=means3D, shs=shs, colors_precomp=colors_precomp, scales=scales,
                          rotations=rotations, cov3D_precomp=cov3D_precomp, viewmatrix=viewmatrix,

@@ -60,6 +60,7 @@ def hip_forward(s, shs=True, colors_precomp=None, cov3D_precomp=None, sh_degree=
         out["n_contrib"] = im[lay.img_n_contrib:lay.img_n_contrib + W * H * 4].view(np.uint32).copy()
         out["final_T"] = im[lay.img_final_T:lay.img_final_T + W * H * 4].view(np.float32).copy()
         out["tile_counts"] = im[lay.img_tile_counts:lay.img_tile_counts + tiles * 4].view(np.uint32).copy()
+        out["tile_walked"] = im[lay.img_tile_walked:lay.img_tile_walked + tiles * 4].view(np.uint32).copy()
         b = _aligned(binning).cpu().numpy()
         out["point_list"] = b[lay.bin_point_list:lay.bin_point_list + R * 4].view(np.uint32).copy()
     return out

@@ -252,3 +252,52 @@ def test_mark_visible():
     s = random_gaussians(300, seed=4)
     vis = ro.mark_visible(s["means3D"], s["viewmatrix"], s["projmatrix"])
     assert np.array_equal(vis, s["means3D"][:, 2] > 0.2)
+
+
+def test_block_walk_counts_against_a_dense_numpy_statement():
+    """SURVEY 8d's Q = 256 x (list entries a tile's block walks before it exits): `tile_walked` of the oracle against an independent
+    dense statement -- per tile the [entries, 16, 16] alpha array, a cumulative product for T, the first entry at which a pixel would
+    drop below 1e-4 (it stops WITHOUT blending that entry, forward.cu:340-345), and the block rule of forward.cu:305-312: walk the
+    whole list if any pixel inside the image never stops, else to the end of the 256-entry round that holds the last stop.  The
+    left half of the scene is opaque and dense enough that its tiles exit early; the right half is nearly transparent."""
+    W, H = 96, 64
+    s = random_gaussians(6000, seed=21, W=W, H=H, scale=(-4.6, -3.4))
+    s["opacities"][:] = 0.95
+    s["opacities"][s["means3D"][:, 0] > 0] = 0.003           # below 1/255: never blended, so the right half never saturates and walks its whole lists
+    ro.set_threads(4)
+    st = ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], W, H, s["tanfovx"], s["tanfovy"],
+                    s["bg"], shs=s["shs"], sh_degree=3, scales=s["scales"], rotations=s["rotations"])
+    gx, gy = st.grid
+    early = 0
+    for tile in range(gx * gy):
+        a, e = (int(v) for v in st.ranges[tile])
+        n = e - a
+        if n == 0:
+            assert st.tile_walked[tile] == 0
+            continue
+        ids = st.point_list[a:e]
+        tx, ty = tile % gx, tile // gx
+        px = (tx * 16 + np.arange(16))[None, None, :].astype(np.float32)
+        py = (ty * 16 + np.arange(16))[None, :, None].astype(np.float32)
+        dx = st.means2D[ids, 0][:, None, None] - px
+        dy = st.means2D[ids, 1][:, None, None] - py
+        co = st.conic_opacity[ids]
+        power = np.float32(-0.5) * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+        alpha = np.minimum(np.float32(0.99), co[:, 3, None, None] * np.exp(power.astype(np.float64)).astype(np.float32))
+        blends = (power <= 0) & (alpha >= np.float32(1 / 255.0))
+        stop = np.zeros((16, 16), np.int64)                     # 1-based entry at which the pixel stops, 0 = never
+        T = np.ones((16, 16), np.float32)
+        for k in range(n):
+            test_T = T * (1 - alpha[k])
+            hit = blends[k] & (test_T < np.float32(0.0001)) & (stop == 0)
+            stop[hit] = k + 1
+            upd = blends[k] & (stop == 0)
+            T = np.where(upd, test_T, T)
+        inside = ((ty * 16 + np.arange(16))[:, None] < H) & ((tx * 16 + np.arange(16))[None, :] < W)
+        if (stop[inside] == 0).any():
+            want = n
+        else:
+            want = min(n, -(-int(stop[inside].max()) // 256) * 256)
+        assert st.tile_walked[tile] == want, (tile, n, int(st.tile_walked[tile]), want)
+        early += want < n
+    assert early > 0 and early < gx * gy        # the scene exercises both branches

@@ -137,6 +137,17 @@ def _cmp_forward(fw, st, P, feat=None):
         for p in bad:
             assert _near_threshold(st, int(p % W), int(p // W), W), ("n_contrib differs without a threshold pair", p)
     assert np.abs(fw["final_T"] - st.final_T).mean() <= 1e-8
+    # SURVEY 8d's Q: entries each tile's block walks before it exits, in rounds of 256 (forward.cu:305-312): an integer per tile.
+    # On the reference's lists it is the oracle's, but for tiles whose last saturating pixel sits on a threshold (the same counted
+    # exception as n_contrib above, seen through a 256-entry round: rarer); on culled lists it can only be shorter.
+    cnt = (fw["ranges"][:, 1].astype(np.int64) - fw["ranges"][:, 0])
+    assert (fw["tile_walked"] <= cnt).all()
+    if not culled:
+        off = np.nonzero(fw["tile_walked"] != st.tile_walked)[0]
+        assert len(off) <= max(1, len(cnt) // 200), (len(off), len(cnt))
+        assert ((fw["tile_walked"][off] % 256 == 0) | (fw["tile_walked"][off] == cnt[off])).all()
+    else:
+        assert int(fw["tile_walked"].sum()) <= int(st.tile_walked.sum())
 
 
 def _relerr(a, b):
