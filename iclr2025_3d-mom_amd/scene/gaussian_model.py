@@ -383,7 +383,12 @@ class GaussianModel:
         self.densify_and_split(grads, max_grad, extent)
 
     def grow(self, *a, **k):
-        raise NotImplementedError("opt.add_point=True is broken in the reference too (gaussian_model.py:25,629,660)")
+        """Not part of the claimed surface: the reference's grow() (scene/gaussian_model.py:647-680) cannot run
+        either -- add_point_by_mask passes densification_postfix seven of its eight arguments (:629 against :476), and downsample_point /
+        addpoint need open3d, which the reference's environment does not install -- and opt.add_point is False in every shipped
+        configuration (train_4DGS.py:285 is the only caller)."""
+        raise NotImplementedError("GaussianModel.grow(): opt.add_point=True does not run in the reference either (gaussian_model.py:629 "
+                                  "passes densification_postfix 7 of its 8 arguments; downsample_point needs open3d)")
 
     def reset_opacity(self):
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
