@@ -66,7 +66,7 @@ class FusedStep:
             # later one are no-ops ON THE DEVICE (mom_adam_step / mom_densify_stats skip_if_nonzero) until the host -- which
             # runs several steps ahead and reads the word through flag_ring a few steps later -- clears it and replays the
             # skipped iterations with an exactly sized buffer (train.Trainer._recover).  Nothing truncated ever reaches the model.
-            self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+            # (the word itself lives behind the radii, below: one integer bucket for a camera-batch shard's max-all-reduce)
             self.flag_ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
             self.next_tag = 1
             # loss accumulators live in spare words of the image scratch's header, which the rasterizer forward clears at the
@@ -79,8 +79,8 @@ class FusedStep:
             grew = same_frame and cap and pad > cap
             cap = self._rows_cap = pad + pad // 4 if grew else pad
             st = self._store = {name: e(cap, cols) for name, cols, _ in self._ROW_BUFFERS}
-            st["radii"] = torch.empty(cap, dtype=torch.int32, device=dev)
-            st["early"] = e(56 * cap)
+            st["radii"] = torch.zeros(cap + 1, dtype=torch.int32, device=dev)      # + the sticky overflow word behind the P radii
+            st["early"] = e(59 * cap)                                              # + the screen-space gradients behind the 56 P
             st["loc"] = (e(cap, 3), e(cap, 4))
             self.geom = torch.empty(self.lib.mom_raster_geom_bytes(cap), dtype=torch.uint8, device=dev)
             self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(cap), dtype=torch.uint8, device=dev)
@@ -91,12 +91,24 @@ class FusedStep:
         # (the gathered buffers of a tile-row shard carry world x S >= P rows; every kernel reads the first P)
         for name, _, padded in self._ROW_BUFFERS:
             setattr(self, name, st[name][:pad if padded else P])
-        self.radii = st["radii"][:P]
+        # [radii (P) | overflow word]: contiguous, so that a camera-batch shard agrees on both with ONE max-all-reduce.  The word is
+        # sticky across steps: its value moves with it when P (and so its position) changes
+        old_flags = getattr(self, "flags", None)
+        self.ibucket = st["radii"][:P + 1]
+        self.radii, self.flags = self.ibucket[:P], self.ibucket[P:]
+        if old_flags is not None and old_flags.device == self.flags.device and old_flags.data_ptr() != self.flags.data_ptr():
+            self.flags.copy_(old_flags)
+        elif old_flags is None or old_flags.device != self.flags.device:
+            self.flags.zero_()
         # parameter gradients (persist across steps; .grad points at them).  They live in two flat buckets so that a
         # multi-GPU run all-reduces them in place, without packing: `early` (final once the activation backward has run:
         # SH, scaling, rotation, opacity = 56 floats per Gaussian) and `late` (xyz + the deformation field, final only
         # after the HexPlane backward; made in _deform_grads).
-        self.early = st["early"][:56 * P]
+        # (behind the 56 P: the screen-space gradients, 3 P -- the densification statistics' input, summed over a camera-batch
+        # shard's ranks in the same all-reduce)
+        self.early_bucket = st["early"][:59 * P]
+        self.early = self.early_bucket[:56 * P]
+        self.g2d = self.early_bucket[56 * P:].view(P, 3)
         cut = [0, 3 * P, 48 * P, 51 * P, 55 * P, 56 * P]
         seg = lambda i: self.early[cut[i]:cut[i + 1]]
         self.gdc, self.grest = seg(0).view(P, 1, 3), seg(1).view(P, 15, 3)
@@ -105,7 +117,7 @@ class FusedStep:
 
     # per-Gaussian float buffers: (attribute, floats per row, sized for a tile-row shard's padded row count)
     _ROW_BUFFERS = (("feat", 64, False), ("a0", 64, False), ("dfeat", 64, False), ("pts", 3, True), ("sc_d", 3, False),
-                    ("rot_d", 4, True), ("sc", 3, True), ("rot", 4, True), ("op", 1, True), ("g2d", 3, False), ("gcol", 3, False),
+                    ("rot_d", 4, True), ("sc", 3, True), ("rot", 4, True), ("op", 1, True), ("gcol", 3, False),
                     ("gop_act", 1, False), ("gcov", 6, False), ("gsc_act", 3, False), ("grot_act", 4, False))
 
     RING = 64
@@ -315,8 +327,9 @@ class FusedStep:
                                               self.img.data_ptr(), self.color.data_ptr(), self.depth.data_ptr(),
                                               self.flags.data_ptr(), s), "raster_render")
         early_works = []                        # camera-batch shard: what the early Adam launch must see reduced (below)
-        if dc is not None:
+        if dc is not None and dc.mode != "camera":
             early_works.append(dc.start(self.flags, "max"))         # every rank skips (and later replays) the same steps
+            # (a camera-batch shard agrees on the word together with the radii, behind its own backward: below)
         # ---- loss: L1 (+ its gradient image) ; regulariser value and gradient
         n = self.color.numel()
         if not fuse_l1:
@@ -393,8 +406,9 @@ class FusedStep:
                     "raster_bwd_geometry")
         if dc is not None and dc.mode == "camera":
             # densification statistics (train_4DGS.py:203-204,227-229): largest radius, mean 2-D gradient
-            early_works.append(dc.start(self.radii, "max"))
-            early_works.append(dc.start(self.g2d, "sum"))
+            # (this rank's backward has read its OWN radii by now; the overflow word rides in the same integer bucket.  Every
+            # torch.distributed call costs the host 40-50 us and the host paces a rank: three collectives per step, not five)
+            early_works.append(dc.start(self.ibucket, "max"))
         N.check(lib.mom_activations_backward(P, self.sc.data_ptr(), self.rot_d.data_ptr(), self.op.data_ptr(),
                                              self.gsc_act.data_ptr(), self.grot_act.data_ptr(), self.gop_act.data_ptr(),
                                              self.gsc.data_ptr(), self.grot.data_ptr(), self.gop.data_ptr(), s), "act_bwd")
@@ -405,7 +419,7 @@ class FusedStep:
             d_sc, d_rot = self._loc
             d_sc.copy_(self.gsc)
             d_rot.copy_(self.grot)
-            early_works.append(dc.start(self.early, "sum"))
+            early_works.append(dc.start(self.early_bucket, "sum"))     # appearance gradients + mean 2-D gradients
         # ---- deformation backward: pts = xyz + dx(...) so d xyz starts as d pts (already in gxyz); the HexPlane adds its share
         # the MLP's weight-gradient kernel (matrix pipe) runs on a second stream beside the HexPlane backward (vector issue,
         # memory latency); joined below, before anything reads the weight gradients

@@ -12,10 +12,13 @@ one camera per rank: every rank holds the full model (replica), renders and back
     (train_4DGS.py:203-204,227-229).
 
 The fused training step (fused_step.py) keeps its gradients in two flat buckets from the start, scales the loss
-gradient by 1/world at its source and calls start() as soon as a bucket is final: the 56-floats-per-Gaussian bucket
-(SH, scaling, rotation, opacity) is all-reduced on RCCL's stream while the deformation backward still runs; only the
-bucket with xyz and the deformation field (3 floats per Gaussian + 2.9 M) is exposed.  finish() makes the compute
-stream wait for all of them before Adam.  No packing, no rescaling pass.
+gradient by 1/world at its source and calls start() as soon as a bucket is final: the early bucket (SH, scaling,
+rotation, opacity: 56 floats per Gaussian, with the 3 floats of the screen-space gradient behind them) is all-reduced
+on RCCL's stream while the deformation backward still runs -- and the appearance parameters' Adam launch follows it on
+the step's second stream (DistContext.wait_for) --; only the bucket with xyz and the deformation field (3 floats per
+Gaussian + 2.9 M) is exposed.  The radii and the sticky overflow word travel as ONE integer bucket (max).  Three
+collectives per step: every torch.distributed call costs the rank's host 40-50 us, and the host paces a rank.
+finish() makes the compute stream wait for all of them before Adam.  No packing, no rescaling pass.
 
 Everything downstream (densify / prune / Adam) then runs replicated and stays bit-identical across ranks.  The one
 random draw in densify_and_split (gaussian_model.py:525) is made identical by seeding every rank's generator with

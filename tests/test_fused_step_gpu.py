@@ -83,8 +83,13 @@ class _VirtualRank:
         if tensor.dtype == torch.int32 and tensor.numel() == 1:      # the sticky overflow word (max over the ranks): leave it
             assert op == "max"
             return
+        if tensor.dtype == torch.int32:      # camera-batch shard: [radii (P) | the overflow word], one max-all-reduce; the word is left alone
+            assert op == "max"
+            self.captured.append((op, tensor[:-1].clone()))
+            tensor[:-1].fill_(-7)
+            return
         self.captured.append((op, tensor.clone()))
-        tensor.fill_(float("nan") if tensor.is_floating_point() else -7)
+        tensor.fill_(float("nan"))
 
     def finish(self):
         pass
@@ -105,7 +110,7 @@ def test_camera_batch_buckets_of_two_virtual_ranks_sum_to_the_batch_mean():
 
     def snapshot():
         torch.cuda.synchronize()
-        return {"radii": fs.radii.clone(), "g2d": fs.g2d.clone(), "early": fs.early.clone(), "late": fs._dg_flat.clone()}
+        return {"radii": fs.radii.clone(), "early": fs.early_bucket.clone(), "late": fs._dg_flat.clone()}
 
     plain = []
     for cam in cams:                                   # no optimiser step in between: both see the same model
@@ -117,13 +122,16 @@ def test_camera_batch_buckets_of_two_virtual_ranks_sum_to_the_batch_mean():
         fs.forward_backward(cam, 1)
         torch.cuda.synchronize()
         ops_seen = [o for o, _ in fs.dist.captured]
-        assert ops_seen == ["max", "sum", "sum", "sum"], ops_seen          # radii, g2d, early bucket, late bucket
-        ranks.append(dict(zip(("radii", "g2d", "early", "late"), [t for _, t in fs.dist.captured])))
+        # three collectives per step: [radii | overflow word] (max), [appearance gradients 56 P | mean 2-D gradients 3 P] (sum), the
+        # late bucket (sum) -- every torch.distributed call costs a rank's host 40-50 us
+        assert ops_seen == ["max", "sum", "sum"], ops_seen
+        ranks.append(dict(zip(("radii", "early", "late"), [t for _, t in fs.dist.captured])))
     fs.dist = None
-    assert ranks[0]["early"].numel() == 56 * 6000 and ranks[0]["late"].numel() == fs._dg_flat.numel()
+    assert ranks[0]["early"].numel() == 59 * 6000 and ranks[0]["late"].numel() == fs._dg_flat.numel()
+    assert fs.g2d.data_ptr() == fs.early_bucket[56 * 6000:].data_ptr() and int(fs.flags[0]) == 0
     torch.testing.assert_close(torch.maximum(ranks[0]["radii"], ranks[1]["radii"]),
                                torch.maximum(plain[0]["radii"], plain[1]["radii"]), rtol=0, atol=0)
-    for k in ("g2d", "early", "late"):
+    for k in ("early", "late"):
         got = ranks[0][k] + ranks[1][k]
         want = 0.5 * (plain[0][k] + plain[1][k])
         assert torch.isfinite(got).all(), k
