@@ -133,6 +133,7 @@ def _sig(lib):
     lib.mom_stream_wait_stream.argtypes = [vp, vp]
     lib.mom_stream_mark.argtypes = [i32, vp]
     lib.mom_stream_wait_mark.argtypes = [vp, i32]
+    lib.mom_zero_async.argtypes = [vp, sz, vp]
     lib.mom_raster_forward_geometry.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, vp, vp, vp]
     lib.mom_raster_forward_render.argtypes = [C.POINTER(MomRasterArgs), vp, vp, sz, vp, vp, vp, vp, vp]
     lib.mom_raster_backward.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, sz, vp, vp, vp, C.POINTER(MomRasterGrads), vp]
@@ -214,7 +215,7 @@ EXPORTS = [
     "mom_hexplane_backward_scratch_bytes", "mom_hexplane_orders_scratch_bytes", "mom_hexplane_orders", "mom_image_to_rgb8",
     "mom_l1_loss_acc", "mom_plane_regulation_acc", "mom_plane_regulation_grad",
     "mom_deform_field_supported", "mom_deform_field_scratch_bytes", "mom_deform_field_forward",
-    "mom_stream_wait_stream", "mom_stream_mark", "mom_stream_wait_mark",
+    "mom_stream_wait_stream", "mom_stream_mark", "mom_stream_wait_mark", "mom_zero_async",
 ]
 
 

@@ -51,3 +51,10 @@ int mom_stream_wait_mark(mom_stream_t stream, int slot)
     if (!pd || !pd->marks[slot]) return MOM_EINVAL;          // never recorded
     return hipStreamWaitEvent((hipStream_t)stream, pd->marks[slot], 0) == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
+
+int mom_zero_async(void* ptr, size_t bytes, mom_stream_t stream)
+{
+    if (!bytes) return MOM_OK;
+    if (!ptr) return MOM_EINVAL;
+    return hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream) == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}

@@ -231,37 +231,38 @@ class FusedStep:
             self.side = torch.cuda.Stream(device=dev)
         if getattr(self, "regacc", None) is None:
             self.regacc = torch.zeros(1, dtype=torch.float32, device=dev)
-        if getattr(self, "_bucket_ready", None) is None:
-            self._bucket_ready = torch.cuda.Event()
         hy = self.hyper
         reg = None
-        self.side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.side):
-            self._dg_flat.zero_()
-            # the compositing backward's accumulator record too (MomRasterArgs.accum_cleared): its last reader, the previous
-            # step's projection backward, is behind this stream's wait above
-            gk = (P, W, H, self.geom.data_ptr())
-            if getattr(self, "_gacc_cache", (None,))[0] != gk:
-                self._gacc_cache = (gk, self._gacc_view(P, W, H))
-            self._gacc_cache[1].zero_()
-            if hy.time_smoothness_weight != 0:
-                rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, reg_scale)
-                if self._reg_arr is None or self._reg_arr[0] != rkey:
-                    arr = (N.MomRegPlane * len(planes))()
-                    for i, p in enumerate(planes):
-                        st, gs = ops.plane_storage(p.detach()), ops.plane_storage(self._dg_planes[i])
-                        arr[i].plane, arr[i].grad = st.data_ptr(), gs.data_ptr()
-                        arr[i].H, arr[i].W = st.shape[0], st.shape[1]
-                        tplane = (i % 6) in (2, 4, 5)
-                        arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
-                        arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
-                        arr[i].grad_scale = reg_scale      # identical on every rank: the sum over ranks restores it
-                    self._reg_arr = (rkey, arr)
-                arr = self._reg_arr[1]
-                self.regacc.zero_()
-                N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regacc.data_ptr(), N.current_stream()), "plane_reg")
-                reg = self.regacc
-            self._bucket_ready.record(self.side)
+        # (everything on the second stream goes there through its raw handle -- libmom4d's launches, mom_zero_async, the ordering
+        # calls of csrc/stream_order.hip: entering a torch stream context, a wait_stream and an event cost ~10 us of host time each,
+        # and at config 1 the host paces the step)
+        side = self.side.cuda_stream
+        ops.stream_wait_stream(side, s)
+        ops.zero_async(self._dg_flat, side)
+        # the compositing backward's accumulator record too (MomRasterArgs.accum_cleared): its last reader, the previous
+        # step's projection backward, is behind this stream's wait above
+        gk = (P, W, H, self.geom.data_ptr())
+        if getattr(self, "_gacc_cache", (None,))[0] != gk:
+            self._gacc_cache = (gk, self._gacc_view(P, W, H))
+        ops.zero_async(self._gacc_cache[1], side)
+        if hy.time_smoothness_weight != 0:
+            rkey = (hy.time_smoothness_weight, hy.plane_tv_weight, hy.l1_time_planes, reg_scale)
+            if self._reg_arr is None or self._reg_arr[0] != rkey:
+                arr = (N.MomRegPlane * len(planes))()
+                for i, p in enumerate(planes):
+                    st, gs = ops.plane_storage(p.detach()), ops.plane_storage(self._dg_planes[i])
+                    arr[i].plane, arr[i].grad = st.data_ptr(), gs.data_ptr()
+                    arr[i].H, arr[i].W = st.shape[0], st.shape[1]
+                    tplane = (i % 6) in (2, 4, 5)
+                    arr[i].w_smooth = hy.time_smoothness_weight if tplane else hy.plane_tv_weight
+                    arr[i].w_l1 = hy.l1_time_planes if tplane else 0.0
+                    arr[i].grad_scale = reg_scale      # identical on every rank: the sum over ranks restores it
+                self._reg_arr = (rkey, arr)
+            arr = self._reg_arr[1]
+            ops.zero_async(self.regacc, side)
+            N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regacc.data_ptr(), side), "plane_reg")
+            reg = self.regacc
+        ops.stream_mark(ops.MARK_BUCKET, side)
         # HexPlane lookup + MLP + the activations (exp / normalize / sigmoid) in one kernel (csrc/deform_field.hip)
         dc = self.dist
         sl = None
@@ -370,7 +371,7 @@ class FusedStep:
         if dc is not None and dc.mode == "camera":
             self.dimg.mul_(inv_world)
         # ---- rasterizer backward
-        torch.cuda.current_stream().wait_event(self._bucket_ready)      # the gradient bucket is cleared and holds the regulariser's share
+        ops.stream_wait_mark(s, ops.MARK_BUCKET)      # the gradient bucket is cleared and holds the regulariser's share
         gr = N.MomRasterGrads()
         gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = self.g2d.data_ptr(), self.gcol.data_ptr(), self.gop_act.data_ptr()
         gr.dL_dmeans3D, gr.dL_dcov3D = self.gxyz.data_ptr(), self.gcov.data_ptr()
@@ -435,9 +436,8 @@ class FusedStep:
             if dc is None or dc.mode == "tile-row":
                 # (a tile-row shard's gradients are already the full sums here: the ranks summed the compositing backward's record,
                 # and projection / activation backward ran replicated on it)
-                self.side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(self.side):
-                    early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity])
+                ops.stream_wait_stream(self.side.cuda_stream, s)
+                early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity], stream=self.side.cuda_stream)
             else:
                 # camera-batch shard: the launch needs the REDUCED bucket (and, for the densification statistics it carries, the
                 # reduced radii / screen-space gradients and the agreed overflow word).  The second stream waits for exactly those
@@ -483,11 +483,11 @@ class FusedStep:
                                                   None if spo is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
             dc.start_gather([self.gxyz_rows], S)
         if early_cam is not None:
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(self.side):          # (torch.distributed's wait() orders the CURRENT torch stream)
                 dc.wait_for(early_cam)
-                early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity])
+            early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity], stream=self.side.cuda_stream)
         if self.side is not None:
-            torch.cuda.current_stream().wait_stream(self.side)
+            ops.stream_wait_stream(s, self.side.cuda_stream)
         if dc is not None and dc.mode == "camera":
             dc.start(self._dg_flat, "sum")     # xyz + deformation field; the caller waits (DistContext.finish) before Adam
         elif sl is not None:

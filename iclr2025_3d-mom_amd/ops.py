@@ -318,7 +318,7 @@ def select_rows(mask, tensors):
 
 
 # --------------------------------------------------------------------------- densification statistics
-def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom, skip_flag=None):
+def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom, skip_flag=None, stream=None):
     """In place, for the Gaussians with radii > 0: running maximum radius, accumulated |dL/d mean2D| and its count
     (train_4DGS.py:266, scene/gaussian_model.py:713-715).  `skip_flag`: optional int32 device word; nonzero makes the
     launch a no-op (FusedAdam.skip_flag has the story)."""
@@ -334,7 +334,7 @@ def densify_stats(radii, viewspace_grad, max_radii2D, xyz_gradient_accum, denom,
         raise N.MomError("densify_stats: viewspace gradient must be a contiguous float32 [P,3] tensor")
     N.check(N.lib().mom_densify_stats(P, radii.data_ptr(), g.data_ptr(), max_radii2D.data_ptr(), xyz_gradient_accum.data_ptr(),
                                       denom.data_ptr(), None if skip_flag is None else skip_flag.data_ptr(),
-                                      N.current_stream()), "mom_densify_stats")
+                                      N.current_stream() if stream is None else stream), "mom_densify_stats")
 
 
 # --------------------------------------------------------------------------- SSIM
@@ -421,7 +421,7 @@ def side_stream(device):
 # Ordering goes through libmom4d's stream helpers (csrc/stream_order.hip), not torch's Stream / Event objects: a dozen of these per
 # iteration at 8-10 us each were a tenth of the path's host time.  Mark slots: 0 = the parameters as the last FusedAdam.step() left
 # them, 1 = the regulariser's gradient kernel on the second stream, 2.. = a ring for the backward's "appearance gradients final".
-MARK_PARAMS, MARK_REG, MARK_RING0, MARK_RING_N = 0, 1, 2, 62
+MARK_PARAMS, MARK_REG, MARK_BUCKET, MARK_RING0, MARK_RING_N = 0, 1, 2, 3, 61      # (2: the fused step's gradient bucket is cleared)
 _ring = [0]
 
 
@@ -435,6 +435,11 @@ def stream_mark(slot, stream):
 
 def stream_wait_mark(stream, slot):
     N.check(N.lib().mom_stream_wait_mark(stream, slot), "mom_stream_wait_mark")
+
+
+def zero_async(t, stream):
+    """t.zero_() on a raw stream handle (no torch stream context: entering and leaving one costs ~10 us of host time)."""
+    N.check(N.lib().mom_zero_async(t.data_ptr(), t.numel() * t.element_size(), stream), "mom_zero_async")
 
 
 def next_ring_mark(stream):

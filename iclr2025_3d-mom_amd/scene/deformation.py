@@ -85,9 +85,15 @@ class Deformation(nn.Module):
                 and not a.apply_rotation)
 
     def _fused_params(self):
+        """The 14 tensors of the trunk and the three heads, in the kernels' order.  Cached while the first and the last are the
+        objects they were (walking four nn.Sequential containers costs 33 us per call, and a training step asks once)."""
+        c = self.__dict__.get("_fused_params_cache")
+        if c is not None and c[0] is self.feature_out[0].weight and c[-1] is self.rotations_deform[3].bias:
+            return list(c)
         ps = [self.feature_out[0].weight, self.feature_out[0].bias]
         for head in (self.pos_deform, self.scales_deform, self.rotations_deform):
             ps += [head[1].weight, head[1].bias, head[3].weight, head[3].bias]
+        self.__dict__["_fused_params_cache"] = tuple(ps)
         return ps
 
     def forward_dynamic(self, rays_pts_emb, scales_emb, rotations_emb, opacity_emb, shs_emb, time_feature, time_emb,

@@ -394,17 +394,18 @@ class GaussianModel:
         new = inverse_sigmoid(torch.min(self.get_opacity, torch.ones_like(self.get_opacity) * 0.01))
         self._opacity = self.replace_tensor_to_optimizer(new, "opacity")["opacity"]
 
-    def update_densification_stats(self, radii, viewspace_grad, skip_flag=None):
+    def update_densification_stats(self, radii, viewspace_grad, skip_flag=None, stream=None):
         """The per-iteration bookkeeping of train_4DGS.py:266 and add_densification_stats (:713-715) for the Gaussians with
         radii > 0, in one backend call (one HIP kernel), in place.  skip_flag: see ops.densify_stats."""
         g = viewspace_grad.detach()
         if g.dim() != 2 or g.shape[1] != 3 or not g.is_contiguous():
             g = g.reshape(-1, 3).contiguous()
-        if skip_flag is None:
-            ops.BACKEND.densify_stats(radii.contiguous(), g.float(), self.max_radii2D, self.xyz_gradient_accum, self.denom)
-        else:
-            ops.BACKEND.densify_stats(radii.contiguous(), g.float(), self.max_radii2D, self.xyz_gradient_accum, self.denom,
-                                      skip_flag=skip_flag)
+        kw = {}
+        if skip_flag is not None:
+            kw["skip_flag"] = skip_flag
+        if stream is not None:             # (a raw stream handle: the fused step's second stream, HIP backend only)
+            kw["stream"] = stream
+        ops.BACKEND.densify_stats(radii.contiguous(), g.float(), self.max_radii2D, self.xyz_gradient_accum, self.denom, **kw)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
         # masked accumulate == the reference's boolean-mask indexing (:713-715) without nonzero()'s host sync

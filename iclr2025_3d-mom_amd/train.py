@@ -235,13 +235,14 @@ class Trainer:
         self._skip = None
         return loss
 
-    def _early_adam(self, params):
-        """Runs on the fused step's second stream, right after the activation backward: Adam for the appearance parameters and
-        -- it only needs the radii and the screen-space gradient, both final by then -- the densification statistics."""
+    def _early_adam(self, params, stream=None):
+        """Runs on the fused step's second stream (`stream`: its raw handle; None: the current stream), right after the activation
+        backward: Adam for the appearance parameters and -- it only needs the radii and the screen-space gradient, both final by
+        then -- the densification statistics."""
         self.g.optimizer.skip_flag = self.fused.flags
-        self.g.optimizer.step_partial(params)
+        self.g.optimizer.step_partial(params, stream=stream)
         if self._early_iter < self.opt.densify_until_iter:
-            self.g.update_densification_stats(self.fused.radii, self.fused.g2d, skip_flag=self.fused.flags)
+            self.g.update_densification_stats(self.fused.radii, self.fused.g2d, skip_flag=self.fused.flags, stream=stream)
             self._stats_done = True
 
     def _step_fused(self, iteration, cam, replay=False):

@@ -457,6 +457,8 @@ const char* mom_profile_name(int slot);
 int mom_stream_wait_stream(mom_stream_t waiter, mom_stream_t signaler);
 int mom_stream_mark(int slot, mom_stream_t stream);
 int mom_stream_wait_mark(mom_stream_t stream, int slot);
+/* bytes of zeros at ptr, stream-ordered (the gradient buckets a step clears on its second stream) */
+int mom_zero_async(void* ptr, size_t bytes, mom_stream_t stream);
 
 /* Self test of the wave64 DPP reduction used by the render backward:
  * out[w] = sum(in[64w .. 64w+63]). */
