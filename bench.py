@@ -362,6 +362,15 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
             z = torch.zeros(4, 3, 3, device=dev)
             torch.bmm(z, z)
             torch.normal(mean=torch.zeros(4, 3, device=dev), std=torch.ones(4, 3, device=dev))
+            # ... and the caching allocator in the state of a process that has been through a round before (at a 100-iteration
+            # cadence: every round but the first).  A round makes new parameter and moment tensors before it lets go of the old
+            # ones; in a process whose cache was just emptied (the leg before this one ends with empty_cache()) that is ~3 GB from
+            # the driver, 13 ms on one box and 130 on the next (profiles/r05_bench_full.json history), and it says nothing about the
+            # round itself.  One allocation of that size, freed again, leaves the cache what round two would find.
+            model_bytes = sum(p.numel() * p.element_size() for grp in g.optimizer.param_groups for p in grp["params"]
+                              if p.dim() and p.shape[0] == p_start)
+            prewarm = int(3.2 * model_bytes)
+            torch.empty(prewarm, dtype=torch.uint8, device=dev)
         trainer.drain()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -407,6 +416,9 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
         p_end = int(g.get_xyz.shape[0])
         out["densify_in_window"] = {"iterations": [it(warmup), it(warmup + steps - 1)], "gaussians_before": p_start,
                                     "gaussians_after": p_end, "pruning_interval": int(op.pruning_interval),
+                                    "allocator_prewarmed_bytes": prewarm,
+                                    "allocator_prewarm_is": "one allocation of ~3.2 x the Gaussian parameters' bytes made and freed before the window: "
+                                                            "the caching allocator as a process finds it in every round but its first",
                                     "segments": segs,
                                     "what": "the trainer's own round at iteration 5100 (train_4DGS.py:264-290 gates, pruning_interval "
                                             "100 = BASELINE configs[4]) is inside the timed window: `value` covers before + boundary + "
