@@ -92,7 +92,7 @@ class HexPlaneField(nn.Module):
         return ops.BACKEND.hexplane_features(pts, timestamps, self.aabb, levels, order=order,
                                              aabb_host=self.aabb_host() if self.aabb.is_cuda else None, **kw)
 
-    REORDER_EVERY = 64
+    REORDER_EVERY = int(__import__("os").environ.get("MOM_REORDER_EVERY", "64"))
 
     def _processing_order(self, pts):
         """Morton order of the points, refreshed when their number changes (densify / prune) and every
