@@ -49,7 +49,35 @@ def pinned_word():
         _state["pin_next"] = 0
     i = _state["pin_next"]
     _state["pin_next"] = (i + 1) % _PIN_RING
-    return ring[i:i + 1]
+    w = ring[i:i + 1]
+    w[0] = COUNT_PENDING       # (a host store: the geometry stage overwrites it with the frame's count, which wait_count() polls for)
+    return w
+
+
+COUNT_PENDING = -1             # no frame has 2^32 - 1 instances
+
+
+def wait_count(nr_host, ev=None, spin_s=float(__import__("os").environ.get("MOM_COUNT_SPIN_S", "0.02"))):
+    """The frame's instance count, as soon as the geometry stage has written it.  The count reaches the host without a copy command:
+    tile_scan stores it into this pinned, device-visible word (system scope), so the host can POLL the word instead of waiting for
+    an event behind the stage -- hipEventSynchronize parks the thread and is woken by the runtime's signal handler up to a
+    millisecond late (tools/probe/window20.py: a window ended by an event wait read 1100-1150 steps/s, the same window ended by a
+    spinning device synchronisation 1181, twice), and exact mode pays that wait in EVERY iteration.  After `spin_s` seconds of
+    polling the event (or the stream) is waited for the ordinary way."""
+    import time
+    v = int(nr_host[0])
+    if v != COUNT_PENDING:
+        return v
+    t_end = time.perf_counter() + spin_s
+    while time.perf_counter() < t_end:
+        v = int(nr_host[0])
+        if v != COUNT_PENDING:
+            return v
+    if ev is not None:
+        ev.synchronize()
+    else:
+        torch.cuda.current_stream().synchronize()
+    return int(nr_host[0])
 
 
 def overflow_flag(device):
@@ -157,10 +185,7 @@ def exact_render(lib, a, geom, img, out_color, out_depth, nr_host, P, W, H, dev,
         binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, guess),), dtype=torch.uint8, device=dev)
         N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), guess, img.data_ptr(),
                                               out_color.data_ptr(), out_depth.data_ptr(), None, stream), "mom_raster_forward_render")
-        ev.synchronize()
-    else:
-        torch.cuda.current_stream().synchronize()
-    count = int(nr_host[0])
+    count = wait_count(nr_host, ev)
     if count > guess or ev is None:
         # (ev is None: nothing was enqueued above -- also the case of a frame with NO instances before any guess exists; the
         # compositing still has to run, it writes the background image, as the reference does for num_rendered == 0)

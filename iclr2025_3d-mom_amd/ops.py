@@ -115,9 +115,11 @@ def hexplane_features(xyz, time, aabb, planes_by_level, order=None, aabb_host=No
     return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), order, aabb_host, plane_orders, *flat)
 
 
-def hexplane_orders(xyz, planes_by_level, aabb, aabb_host=None):
+def hexplane_orders(xyz, planes_by_level, aabb, aabb_host=None, stream=None, keep=None):
     """(order, inverse), int32 [3, levels, P] each: per space plane and level the permutation that sorts the points by that
-    level's texel cell, and its inverse (mom_hexplane_orders) -- what the two-pass HexPlane backward walks.  Speed only."""
+    level's texel cell, and its inverse (mom_hexplane_orders) -- what the two-pass HexPlane backward walks.  Speed only.
+    stream: a raw stream handle to launch on (default: the current stream); `keep`: a list that receives the scratch buffer, for a
+    caller that launches on another stream and must keep it alive until that work is done."""
     _need_cuda(xyz, "hexplane_orders")
     lib = N.lib()
     pts = xyz.detach().contiguous().float()
@@ -128,12 +130,15 @@ def hexplane_orders(xyz, planes_by_level, aabb, aabb_host=None):
     if P:
         scratch = torch.empty(lib.mom_hexplane_orders_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
         N.check(lib.mom_hexplane_orders(C.byref(d), P, pts.data_ptr(), order.data_ptr(), inverse.data_ptr(), scratch.data_ptr(),
-                                        N.current_stream()), "mom_hexplane_orders")
+                                        N.current_stream() if stream is None else stream), "mom_hexplane_orders")
+        if keep is not None:
+            keep += [scratch, pts]
     return order, inverse
 
 
-def morton_order(xyz):
-    """uint32 permutation that walks the points along a Morton curve (int32 tensor of the same bits)."""
+def morton_order(xyz, stream=None, keep=None):
+    """uint32 permutation that walks the points along a Morton curve (int32 tensor of the same bits).  stream / keep: as in
+    hexplane_orders."""
     _need_cuda(xyz, "morton_order")
     lib = N.lib()
     pts = xyz.detach().contiguous().float()
@@ -141,8 +146,10 @@ def morton_order(xyz):
     order = torch.empty(P, dtype=torch.int32, device=pts.device)
     if P:
         scratch = torch.empty(lib.mom_morton_order_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
-        N.check(lib.mom_morton_order(P, pts.data_ptr(), order.data_ptr(), scratch.data_ptr(), N.current_stream()),
-                "mom_morton_order")
+        N.check(lib.mom_morton_order(P, pts.data_ptr(), order.data_ptr(), scratch.data_ptr(),
+                                     N.current_stream() if stream is None else stream), "mom_morton_order")
+        if keep is not None:
+            keep += [scratch, pts]
     return order
 
 
@@ -421,7 +428,7 @@ def side_stream(device):
 # Ordering goes through libmom4d's stream helpers (csrc/stream_order.hip), not torch's Stream / Event objects: a dozen of these per
 # iteration at 8-10 us each were a tenth of the path's host time.  Mark slots: 0 = the parameters as the last FusedAdam.step() left
 # them, 1 = the regulariser's gradient kernel on the second stream, 2.. = a ring for the backward's "appearance gradients final".
-MARK_PARAMS, MARK_REG, MARK_BUCKET, MARK_RING0, MARK_RING_N = 0, 1, 2, 3, 61      # (2: the fused step's gradient bucket is cleared)
+MARK_PARAMS, MARK_REG, MARK_BUCKET, MARK_ORDERS, MARK_RING0, MARK_RING_N = 0, 1, 2, 3, 4, 60      # (2: the fused step's gradient bucket is cleared; 3: a field's refreshed processing orders)
 _ring = [0]
 
 

@@ -94,15 +94,64 @@ class HexPlaneField(nn.Module):
 
     REORDER_EVERY = int(__import__("os").environ.get("MOM_REORDER_EVERY", "64"))
 
+    # The refresh -- one Morton sort and six plane sorts, 0.8 ms of GPU time at 200 k points -- is PREFETCHED: REFRESH_AHEAD calls
+    # before it is due it is launched on a second stream into fresh buffers, beside the training steps (it reads the positions while
+    # Adam may be writing them: an order is a permutation whatever the keys were, and only speed depends on it), and when it is due
+    # the new orders are swapped in behind a mark.  On the step's own stream it was an 0.8 ms stall every 64 iterations, 1.4 % of
+    # the step (tools/probe/per_camera.py: the 1.6-1.7 ms steps).  MOM_ASYNC_ORDERS=0 keeps it on the caller's stream.
+    REFRESH_AHEAD = 8
+    ASYNC_REFRESH = __import__("os").environ.get("MOM_ASYNC_ORDERS", "1") != "0"
+
+    def _order_key(self, pts):
+        return (pts.data_ptr(), pts.shape[0], pts.device, tuple(self.aabb_host()) if pts.is_cuda else None)
+
+    def _prefetch_orders(self, pts):
+        """Launch the refresh on the second stream; the result waits in self._pending = (key, order, plane orders, kept buffers)."""
+        dev = pts.device
+        cur, side = ops.N.current_stream(), ops.side_stream(dev).cuda_stream
+        # the outputs and scratch come from the caller's stream's pool (their memory may have been in use there a moment ago), so
+        # the second stream starts behind the caller's stream's current tail
+        ops.stream_wait_stream(side, cur)
+        keep = []
+        order = ops.BACKEND.morton_order(pts, stream=side, keep=keep)
+        porders = ops.BACKEND.hexplane_orders(pts, [list(g) for g in self.grids], self.aabb, aabb_host=self.aabb_host(), stream=side,
+                                              keep=keep)
+        ops.stream_mark(ops.MARK_ORDERS, side)
+        self._pending = (self._order_key(pts), order, porders, keep)
+
+    def _drop_pending(self):
+        """Forget a prefetched refresh that no longer fits (the model was restructured under it).  Its buffers go back to the
+        allocator, which may hand them out again for work on the caller's stream: that stream is first put behind the second
+        stream's kernels, which may still be writing them."""
+        if getattr(self, "_pending", None) is not None:
+            ops.stream_wait_mark(ops.N.current_stream(), ops.MARK_ORDERS)
+            self._pending = None
+
     def _processing_order(self, pts):
         """Morton order of the points, refreshed when their number changes (densify / prune) and every
         REORDER_EVERY calls (positions drift slowly).  Only the speed of the fused kernels depends on it."""
         if not hasattr(ops.BACKEND, "morton_order") or pts.shape[0] == 0:
             return None
-        if self._order is None or self._order.shape[0] != pts.shape[0] or self._order.device != pts.device \
-                or self._order_age >= self.REORDER_EVERY:
+        self._porders_swapped = False
+        pending = getattr(self, "_pending", None)
+        if self._order is None or self._order.shape[0] != pts.shape[0] or self._order.device != pts.device:
+            self._drop_pending()
             self._order = ops.BACKEND.morton_order(pts)
             self._order_age = 0
+        elif self._order_age >= self.REORDER_EVERY:
+            if pending is not None and pending[0] == self._order_key(pts):
+                # the prefetched orders: this stream waits for the second stream's mark (long past, normally)
+                ops.stream_wait_mark(ops.N.current_stream(), ops.MARK_ORDERS)
+                self._order, self._porders, self._porders_key = pending[1], pending[2], tuple(self.aabb_host())
+                self._porders_swapped = True
+                self._pending = None
+            else:
+                self._drop_pending()
+                self._order = ops.BACKEND.morton_order(pts)
+            self._order_age = 0
+        elif (self.ASYNC_REFRESH and pts.is_cuda and pending is None and ops.BACKEND.name == "hip"
+              and self._order_age == self.REORDER_EVERY - self.REFRESH_AHEAD and getattr(self, "_porders", None) is not None):
+            self._prefetch_orders(pts)
         self._order_age += 1
         return self._order
 
@@ -112,7 +161,8 @@ class HexPlaneField(nn.Module):
         if not hasattr(ops.BACKEND, "hexplane_orders") or pts.shape[0] == 0 or not pts.is_cuda:
             return None
         po = getattr(self, "_porders", None)
-        if po is None or po[0].shape[-1] != pts.shape[0] or po[0].device != pts.device or self._order_age == 1 \
+        if po is None or po[0].shape[-1] != pts.shape[0] or po[0].device != pts.device \
+                or (self._order_age == 1 and not getattr(self, "_porders_swapped", False)) \
                 or getattr(self, "_porders_key", None) != tuple(self.aabb_host()):
             self._porders = ops.BACKEND.hexplane_orders(pts, [list(g) for g in self.grids], self.aabb, aabb_host=self.aabb_host())
             self._porders_key = tuple(self.aabb_host())
