@@ -125,11 +125,16 @@ class FusedRender:
             raise N.MomError(f"async render(): frames {late} overflowed the binning capacity and are incomplete; render them "
                              "again (the capacity has been raised), collect such frames with FusedRender.overflowed(), or use "
                              "set_sync_mode('exact')")
+        wait_for_count = RC._state["mode"] == "exact" or self.cap == 0
+        if wait_for_count:
+            self.nr_host[0] = RC.COUNT_PENDING       # (after prev_R was read: the geometry stage overwrites it with this frame's count)
         N.check(lib.mom_raster_forward_geometry(C.byref(a), self.geom.data_ptr(), self.img.data_ptr(), radii.data_ptr(),
                                                 self.nr_dev.data_ptr(), self.nr_host.data_ptr(), s), "raster_geometry")
-        if RC._state["mode"] == "exact" or self.cap == 0:
-            torch.cuda.current_stream().synchronize()
-            want = int(self.nr_host[0]) + (0 if RC._state["mode"] == "exact" else int(self.nr_host[0]) // 2 + 65536)
+        if wait_for_count:
+            # polled, not waited for with hipStreamSynchronize (RC.wait_count: that wait parks the thread and is woken up to a
+            # millisecond late -- four frames' worth at config 2)
+            count = RC.wait_count(self.nr_host)
+            want = count + (0 if RC._state["mode"] == "exact" else count // 2 + 65536)
         else:
             want = max(self.cap, int(prev_R * self.HEADROOM) + self.MARGIN, getattr(self, "cap_floor", 0))
         if self.binning is None or want > self.cap or want < self.cap // 4:

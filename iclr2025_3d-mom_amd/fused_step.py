@@ -263,6 +263,10 @@ class FusedStep:
             N.check(lib.mom_plane_regulation_acc(arr, len(planes), self.regacc.data_ptr(), side), "plane_reg")
             reg = self.regacc
         ops.stream_mark(ops.MARK_BUCKET, side)
+        # the field's processing orders, if their refresh is due within a few steps: sorted on the second stream from here on, beside
+        # this step's forward and backward (scene/hexplane.py: prefetch_if_due)
+        if dc is None or dc.mode == "camera":
+            field.prefetch_if_due(xyz, side)
         # HexPlane lookup + MLP + the activations (exp / normalize / sigmoid) in one kernel (csrc/deform_field.hip)
         dc = self.dist
         sl = None

@@ -115,11 +115,12 @@ def hexplane_features(xyz, time, aabb, planes_by_level, order=None, aabb_host=No
     return HexPlaneFunction.apply(xyz, time, aabb, len(planes_by_level), order, aabb_host, plane_orders, *flat)
 
 
-def hexplane_orders(xyz, planes_by_level, aabb, aabb_host=None, stream=None, keep=None):
+def hexplane_orders(xyz, planes_by_level, aabb, aabb_host=None, stream=None, keepalive=None):
     """(order, inverse), int32 [3, levels, P] each: per space plane and level the permutation that sorts the points by that
     level's texel cell, and its inverse (mom_hexplane_orders) -- what the two-pass HexPlane backward walks.  Speed only.
-    stream: a raw stream handle to launch on (default: the current stream); `keep`: a list that receives the scratch buffer, for a
-    caller that launches on another stream and must keep it alive until that work is done."""
+    stream: a raw stream handle to launch on (default: the current stream); `keepalive`: a list that receives everything the launch
+    refers to (scratch, the point tensor, the descriptor's tensors), for a caller that launches on another stream and must keep it
+    alive until that work is done."""
     _need_cuda(xyz, "hexplane_orders")
     lib = N.lib()
     pts = xyz.detach().contiguous().float()
@@ -131,13 +132,13 @@ def hexplane_orders(xyz, planes_by_level, aabb, aabb_host=None, stream=None, kee
         scratch = torch.empty(lib.mom_hexplane_orders_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
         N.check(lib.mom_hexplane_orders(C.byref(d), P, pts.data_ptr(), order.data_ptr(), inverse.data_ptr(), scratch.data_ptr(),
                                         N.current_stream() if stream is None else stream), "mom_hexplane_orders")
-        if keep is not None:
-            keep += [scratch, pts]
+        if keepalive is not None:
+            keepalive += [scratch, pts, keep]
     return order, inverse
 
 
-def morton_order(xyz, stream=None, keep=None):
-    """uint32 permutation that walks the points along a Morton curve (int32 tensor of the same bits).  stream / keep: as in
+def morton_order(xyz, stream=None, keepalive=None):
+    """uint32 permutation that walks the points along a Morton curve (int32 tensor of the same bits).  stream / keepalive: as in
     hexplane_orders."""
     _need_cuda(xyz, "morton_order")
     lib = N.lib()
@@ -148,8 +149,8 @@ def morton_order(xyz, stream=None, keep=None):
         scratch = torch.empty(lib.mom_morton_order_scratch_bytes(P), dtype=torch.uint8, device=pts.device)
         N.check(lib.mom_morton_order(P, pts.data_ptr(), order.data_ptr(), scratch.data_ptr(),
                                      N.current_stream() if stream is None else stream), "mom_morton_order")
-        if keep is not None:
-            keep += [scratch, pts]
+        if keepalive is not None:
+            keepalive += [scratch, pts]
     return order
 
 

@@ -94,28 +94,39 @@ class HexPlaneField(nn.Module):
 
     REORDER_EVERY = int(__import__("os").environ.get("MOM_REORDER_EVERY", "64"))
 
-    # The refresh -- one Morton sort and six plane sorts, 0.8 ms of GPU time at 200 k points -- is PREFETCHED: REFRESH_AHEAD calls
-    # before it is due it is launched on a second stream into fresh buffers, beside the training steps (it reads the positions while
-    # Adam may be writing them: an order is a permutation whatever the keys were, and only speed depends on it), and when it is due
-    # the new orders are swapped in behind a mark.  On the step's own stream it was an 0.8 ms stall every 64 iterations, 1.4 % of
-    # the step (tools/probe/per_camera.py: the 1.6-1.7 ms steps).  MOM_ASYNC_ORDERS=0 keeps it on the caller's stream.
+    # The refresh -- one Morton sort and six plane sorts, 0.8 ms of GPU time at 200 k points -- is PREFETCHED when the caller has a
+    # second stream to give it: REFRESH_AHEAD calls before it is due, _processing_order() notes that it is due soon, and the caller
+    # (the fused training step, right after it has queued its gradient-bucket clearing and the plane regularisers on its second
+    # stream) calls prefetch_if_due(): the sorts run there into fresh buffers, beside the step's forward and backward (they read the
+    # positions while Adam may be writing them: an order is a permutation whatever the keys were, and only speed depends on it), and
+    # when the refresh is due the new orders are swapped in behind a mark.  On the step's own stream it was an 0.8 ms stall every 64
+    # iterations, 1.4 % of the step (tools/probe/per_camera.py: the 1.6-1.7 ms steps).  The step's OWN second stream, not a third
+    # one: the device has four hardware queues, and a fifth stream in the process collided with the two of the forward-only render
+    # pool (5150 -> 3800 frames/s).  Callers without a second stream (render(), the autograd path) get the refresh on their own
+    # stream, as before.  MOM_ASYNC_ORDERS=0 switches the prefetch off.
     REFRESH_AHEAD = 8
     ASYNC_REFRESH = __import__("os").environ.get("MOM_ASYNC_ORDERS", "1") != "0"
 
     def _order_key(self, pts):
         return (pts.data_ptr(), pts.shape[0], pts.device, tuple(self.aabb_host()) if pts.is_cuda else None)
 
-    def _prefetch_orders(self, pts):
-        """Launch the refresh on the second stream; the result waits in self._pending = (key, order, plane orders, kept buffers)."""
-        dev = pts.device
-        cur, side = ops.N.current_stream(), ops.side_stream(dev).cuda_stream
+    def prefetch_if_due(self, pts, stream):
+        """Launch the refresh on `stream` (a raw handle of the caller's second stream) if _processing_order() found it due soon."""
+        if getattr(self, "_prefetch_due", False):
+            self._prefetch_due = False
+            if self.ASYNC_REFRESH and getattr(self, "_pending", None) is None and getattr(self, "_porders", None) is not None:
+                self._prefetch_orders(pts, stream)
+
+    def _prefetch_orders(self, pts, side):
+        """The refresh on the stream `side`; the result waits in self._pending = (key, order, plane orders, kept buffers)."""
+        cur = ops.N.current_stream()
         # the outputs and scratch come from the caller's stream's pool (their memory may have been in use there a moment ago), so
         # the second stream starts behind the caller's stream's current tail
         ops.stream_wait_stream(side, cur)
         keep = []
-        order = ops.BACKEND.morton_order(pts, stream=side, keep=keep)
+        order = ops.BACKEND.morton_order(pts, stream=side, keepalive=keep)
         porders = ops.BACKEND.hexplane_orders(pts, [list(g) for g in self.grids], self.aabb, aabb_host=self.aabb_host(), stream=side,
-                                              keep=keep)
+                                              keepalive=keep)
         ops.stream_mark(ops.MARK_ORDERS, side)
         self._pending = (self._order_key(pts), order, porders, keep)
 
@@ -149,9 +160,8 @@ class HexPlaneField(nn.Module):
                 self._drop_pending()
                 self._order = ops.BACKEND.morton_order(pts)
             self._order_age = 0
-        elif (self.ASYNC_REFRESH and pts.is_cuda and pending is None and ops.BACKEND.name == "hip"
-              and self._order_age == self.REORDER_EVERY - self.REFRESH_AHEAD and getattr(self, "_porders", None) is not None):
-            self._prefetch_orders(pts)
+        elif pts.is_cuda and pending is None and ops.BACKEND.name == "hip" and self._order_age == self.REORDER_EVERY - self.REFRESH_AHEAD:
+            self._prefetch_due = True        # (a caller with a second stream picks it up: prefetch_if_due)
         self._order_age += 1
         return self._order
 

@@ -329,12 +329,17 @@ def test_processing_orders_are_refreshed_beside_the_steps_and_stay_permutations(
             for it in range(40):
                 before = field._order
                 trainer.step(5001 + it, cams=[trainer.cams[it % len(trainer.cams)]])
+                # churn the caller's stream's allocator: whatever the refresh on the second stream still uses must be kept alive by
+                # the field, or these fills land in its scratch (a dropped reference here once gave garbage orders and a GPU fault)
+                junk = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for n in (6000, 24000, 6000 * 3 * 2, 40000, 100000)]
+                del junk
                 seen_pending += getattr(field, "_pending", None) is not None
                 swaps += field._order is not before
                 if it == 20:
                     # restructure the model -- in the async run under a pending refresh: the next call must not swap the stale orders in
                     if async_refresh:
-                        field._prefetch_orders(g._xyz.detach()) if getattr(field, "_pending", None) is None else None
+                        if getattr(field, "_pending", None) is None:
+                            field._prefetch_orders(g._xyz.detach(), trainer.fused.side.cuda_stream)
                         assert field._pending is not None
                     keep = torch.ones(g._xyz.shape[0], dtype=torch.bool, device="cuda")
                     keep[::7] = False
