@@ -278,13 +278,28 @@ class FusedStep:
             g0 = min(P, dc.rank * S)
             g1 = min(P, g0 + S)
             sl = (S, g0, g1)
+            # ONE all-gather for the five tensors of the deformed state, not five: every torch.distributed call costs a rank's host
+            # 40-50 us (and a latency-bound collective its ~20 us on the wire), and the host paces a rank.  The slice's outputs go
+            # straight into this rank's slab of a packed buffer -- [world][pts 3S | scales 3S | rotations 4S | opacity S | raw
+            # rotations 4S], each array contiguous inside its slab, which is all the field kernel needs -- and five strided copies
+            # spread the gathered slabs into the [world * S, k] arrays the replicated projection reads.
+            W_ = dc.world
+            pack = getattr(self, "_tr_pack", None)
+            if pack is None or pack.shape != (W_ * S, 15) or pack.device != dev:
+                pack = self._tr_pack = torch.empty((W_ * S, 15), dtype=torch.float32, device=dev)
+            slabs = pack.view(W_, 15 * S)
+            cuts = ((self.pts, 0, 3), (self.sc, 3, 3), (self.rot, 6, 4), (self.op, 10, 1), (self.rot_d, 11, 4))
             if g1 > g0:
                 v = lambda t: t[g0:g1]
+                own = slabs[dc.rank]
+                loc = [own[S * o:S * (o + k)].view(S, k)[:g1 - g0] for _, o, k in cuts]
                 so = field._slice_order(xyz, g0, g1)
-                lines_kept = ops.field_forward(hp, md, g1 - g0, v(xyz), time, so, v(scal), v(rot), v(flow), coef, v(self.pts), v(self.sc_d),
-                                  v(self.rot_d), v(self.feat), v(self.a0), v(opac), v(self.sc), v(self.rot), v(self.op), s)
-            dc.start_gather([self.pts, self.sc, self.rot, self.op, self.rot_d], S)
+                lines_kept = ops.field_forward(hp, md, g1 - g0, v(xyz), time, so, v(scal), v(rot), v(flow), coef, loc[0], v(self.sc_d),
+                                  loc[4], v(self.feat), v(self.a0), v(opac), loc[1], loc[2], loc[3], s)
+            dc.start_gather([pack], S)
             dc.finish()
+            for t, o, k in cuts:
+                t.view(W_, S, k).copy_(slabs[:, S * o:S * (o + k)].view(W_, S, k))
         else:
             lines_kept = ops.field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, self.pts, self.sc_d, self.rot_d, self.feat, self.a0,
                               opac, self.sc, self.rot, self.op, s)
