@@ -411,8 +411,8 @@ def ssim(img1, img2):
 # faster host); MOM_API_OVERLAP=1 or ops.API_OVERLAP = True switches it on.
 API_OVERLAP = _os.environ.get("MOM_API_OVERLAP", "0") == "1"
 _side_streams = {}
-_reg_pending = {}      # device -> event: the regulariser's gradient kernel on the second stream; the next writer of plane gradients waits
-_params_ready = {}     # device -> (event recorded at the end of the last FusedAdam.step(), ((id, version) of every plane it updated))
+_reg_pending = {}      # device -> True while the regulariser's gradient kernel may still run on the second stream (mark MARK_REG): the next writer of plane gradients waits
+_params_ready = {}     # device -> (stream the last FusedAdam.step() ended on -- mark MARK_PARAMS --, {(id, version)} of every plane it updated)
 
 
 def side_stream(device):
@@ -427,9 +427,10 @@ def side_stream(device):
 
 
 # Ordering goes through libmom4d's stream helpers (csrc/stream_order.hip), not torch's Stream / Event objects: a dozen of these per
-# iteration at 8-10 us each were a tenth of the path's host time.  Mark slots: 0 = the parameters as the last FusedAdam.step() left
-# them, 1 = the regulariser's gradient kernel on the second stream, 2.. = a ring for the backward's "appearance gradients final".
-MARK_PARAMS, MARK_REG, MARK_BUCKET, MARK_ORDERS, MARK_RING0, MARK_RING_N = 0, 1, 2, 3, 4, 60      # (2: the fused step's gradient bucket is cleared; 3: a field's refreshed processing orders)
+# iteration at 8-10 us each were a tenth of the path's host time.  Mark slots (per device): 0 = the parameters as the last
+# FusedAdam.step() left them, 1 = the regulariser's gradient kernel on the second stream, 2 = the fused step's gradient bucket is cleared,
+# 3 = a field's prefetched processing orders, 4.. = a ring of 60 for the backward's "appearance gradients final".
+MARK_PARAMS, MARK_REG, MARK_BUCKET, MARK_ORDERS, MARK_RING0, MARK_RING_N = 0, 1, 2, 3, 4, 60
 _ring = [0]
 
 
@@ -451,7 +452,7 @@ def zero_async(t, stream):
 
 
 def next_ring_mark(stream):
-    """Record the tail of `stream` under the next slot of the ring; returns the slot (valid until 62 more have been taken)."""
+    """Record the tail of `stream` under the next slot of the ring; returns the slot (valid until MARK_RING_N more have been taken)."""
     _ring[0] = (_ring[0] + 1) % MARK_RING_N
     slot = MARK_RING0 + _ring[0]
     stream_mark(slot, stream)
