@@ -74,8 +74,17 @@ def _run_async_buckets(rank, world, port, out):
     radii = torch.randint(0, 50, (257,), generator=g, dtype=torch.int32)
     early, late = torch.randn(56 * 257, generator=g), torch.randn(4099, generator=g)
     mine = {"radii": radii.numpy().copy(), "early": early.numpy().copy(), "late": late.numpy().copy()}
-    dc.start(radii, "max")          # the order fused_step.py issues them in
-    dc.start(early, "sum")
+    # the order fused_step.py issues them in -- the integer bucket is a VIEW of a larger store ([radii (P) | overflow word] of a
+    # capacity-sized buffer), as the step hands it over; start() returns the work handles and wait_for() waits for exactly those
+    # (what the step's second stream does before the early Adam launch) while they stay pending for finish()
+    store = torch.full((300,), -5, dtype=torch.int32)
+    store[:257] = radii
+    store[257] = rank                                   # the "overflow word": the max over the ranks must come back
+    w0 = dc.start(store[:258], "max")
+    w1 = dc.start(early, "sum")
+    dc.wait_for([w0, w1])
+    assert int(store[257]) == world - 1 and int(store[258]) == -5      # reduced, and nothing beyond the view was touched
+    radii.copy_(store[:257])
     early_view_ok = True
     try:
         dc.start(early.view(257, 56).t(), "sum")      # not a whole contiguous buffer: refused, nothing enqueued
