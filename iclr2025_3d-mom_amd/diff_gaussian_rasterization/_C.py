@@ -129,7 +129,10 @@ def set_keep_all_tiles(on: bool) -> None:
 def last_num_rendered():
     """Instance count of the most recent forward (async mode: synchronises nothing, may lag by one call)."""
     r = _state["last_R"]
-    return None if r is None else int(r[0])
+    if r is None:
+        return None
+    v = int(r[0])
+    return None if v == COUNT_PENDING else v        # (async mode: the geometry stage of that forward has not written it yet)
 
 
 def _args(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
@@ -247,7 +250,7 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
         flag = overflow_flag(dev)
         _check_overflow(_FLAG_LAG)
         prev = _state["last_R"]
-        if prev is not None:      # an earlier call's count (a sizing hint; whichever copy has landed)
+        if prev is not None and int(prev[0]) != COUNT_PENDING:      # an earlier call's count (a sizing hint; whichever copy has landed)
             _state["cap_hint"] = max(_state["cap_hint"], int(int(prev[0]) * 1.5) + 4096)
         cap = max(_state["cap_hint"], 4096)
     _state["last_R"] = nr_host

@@ -153,7 +153,7 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
         flag = RC.overflow_flag(dev)
         RC._check_overflow(RC._FLAG_LAG)
         prev = state["last_R"]
-        if prev is not None:
+        if prev is not None and int(prev[0]) != RC.COUNT_PENDING:
             state["cap_hint"] = max(state["cap_hint"], int(int(prev[0]) * 1.5) + 4096)
         cap = max(state["cap_hint"], 4096)
         state["last_R"] = nr_host
