@@ -28,6 +28,7 @@ tot = {k: 0 for k in ("inst", "px_valid", "s16x4", "s8x4", "s8x8", "s4x4")}
 # the backward's executed (wave, splat) pairs -- a 16x4 strip with at least one lane that passes every test, occlusion included
 # (position in the list < the pixel's last contributor) -- by the number of such lanes
 lane_hist = np.zeros(65, np.int64)
+quarter = {}
 rng = np.random.default_rng(0)
 for t in rng.choice(tiles, 200, replace=False):
     a, e = ranges[t]
@@ -66,7 +67,43 @@ for t in rng.choice(tiles, 200, replace=False):
         tot.setdefault("halfpairs_" + name, 0)
         tot["it_" + name] += int(np.maximum(A.sum(axis=0), B.sum(axis=0)).sum())
         tot["halfpairs_" + name] += int(A.sum() + B.sum())
+    # quarter-wave lists: the rows of a wave are 16x1 pixel rows of a 16x4 strip (today's lane layout), 4x4 blocks side by side in a
+    # 16x4 strip, or the 2x2 4x4 blocks of an 8x8 area.  A list holds the splats that can reach the row's pixels (v) in front of
+    # the row's last contributor; today's list: the same test on the whole wave footprint
+    pos = np.arange(n)[:, None, None]
+    def lists(rows_of_wave):            # rows_of_wave: [waves][4] boolean pixel masks [16,16]
+        out = dict(cur_list=0, cur_exec=0, it=0, rows=0, rows_exec=0)
+        for rows in rows_of_wave:
+            foot = np.any(rows, axis=0)
+            wlast = nc[foot].max() if foot.any() else 0
+            cur = v[:, foot].any(axis=1) & (np.arange(n) < wlast)
+            out["cur_list"] += int(cur.sum())
+            out["cur_exec"] += int(vb[:, foot].any(axis=1).sum())
+            lens = []
+            for m in rows:
+                rlast = nc[m].max()
+                L = v[:, m].any(axis=1) & (np.arange(n) < rlast)
+                lens.append(int(L.sum()))
+                out["rows"] += int(L.sum())
+                out["rows_exec"] += int(vb[:, m].any(axis=1).sum())
+            out["it"] += max(lens)
+        return out
+    yy, xx = np.mgrid[0:16, 0:16]
+    layouts = {
+        "16x1 rows of a 16x4 strip": [[(yy == 4 * w + r) for r in range(4)] for w in range(4)],
+        "4x4 blocks of a 16x4 strip": [[(yy // 4 == w) & (xx // 4 == r) for r in range(4)] for w in range(4)],
+        "4x4 blocks of an 8x8 area": [[(yy // 4 == 2 * (w // 2) + r // 2) & (xx // 4 == 2 * (w % 2) + r % 2) for r in range(4)] for w in range(4)],
+    }
+    for name, rw in layouts.items():
+        d = lists(rw)
+        q = quarter.setdefault(name, dict(cur_list=0, cur_exec=0, it=0, rows=0, rows_exec=0))
+        for k2 in d: q[k2] += d[k2]
 print(tot)
+print("quarter-wave lists (one list per 16-lane row; a wave iteration serves one entry of each of its four rows):")
+for name, d in quarter.items():
+    print(f"  {name}: list entries walked now {d['cur_list']} (executed {d['cur_exec']}); iterations with row lists {d['it']} "
+          f"({d['it'] / d['cur_list']:.3f} of the entries walked now, {d['it'] / d['cur_exec']:.3f} of the executed pairs); "
+          f"(row, splat) list entries {d['rows']}, of them with a valid lane {d['rows_exec']} = {d['rows_exec'] / d['cur_exec']:.2f} atomic rows per executed pair now")
 i = tot["inst"]
 print("valid pixels per instance", tot["px_valid"] / i)
 for k, lanes in (("s16x4", 64), ("s8x4", 32), ("s8x8", 64), ("s4x4", 16)):
