@@ -21,7 +21,7 @@ class MomError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
+ABI_VERSION = 6          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
 
 
 class MomRasterArgs(C.Structure):
@@ -37,7 +37,8 @@ class MomRasterArgs(C.Structure):
                 ("overflow_tag", C.c_uint),                         # what an overflow of this call leaves in *status_dev
                 ("keep_all_tiles", C.c_int),                        # !=0: bin the whole rectangle like the reference (tests)
                 ("l1_target", C.c_void_p), ("l1_grad", C.c_void_p), ("l1_sums", C.c_void_p),   # optional L1 epilogue of the forward
-                ("accum_cleared", C.c_int)]
+                ("accum_cleared", C.c_int),
+                ("l1_partials", C.c_void_p)]                        # per-tile sums of the L1 epilogue instead of two contended atomics
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)

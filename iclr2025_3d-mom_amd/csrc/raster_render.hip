@@ -119,6 +119,7 @@ struct L1Epilogue {
     float* grad;
     float* sums;
     float inv_n;
+    float* partials;        // null, or [tiles][2]: the tile's two sums are stored here instead of being added to `sums`
 };
 // Splats staged per round (a multiple of 256; each thread stages kRound / 256 of them).
 // The backward stages 512 (297 against 307 us: fewer rounds, each with two barriers and a list build, for tiles that still hold
@@ -342,8 +343,15 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
         if (lane == 0) { s_sum[2 * wv] = a1; s_sum[2 * wv + 1] = a2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&l1.sums[0], (s_sum[0] + s_sum[2]) + (s_sum[4] + s_sum[6]));
-            atomicAdd(&l1.sums[1], (s_sum[1] + s_sum[3]) + (s_sum[5] + s_sum[7]));
+            const float t1 = (s_sum[0] + s_sum[2]) + (s_sum[4] + s_sum[6]), t2 = (s_sum[1] + s_sum[3]) + (s_sum[5] + s_sum[7]);
+            if (l1.partials) {
+                // one plain store per tile: 2040 workgroups adding into ONE line are serialised by the device, ~8 ns each (6 us at the
+                // tail of the launch; tools/probe/lds_row_atomic.hip has the same-line rate), and the value is rarely read at all
+                reinterpret_cast<float2*>(l1.partials)[tile] = make_float2(t1, t2);
+            } else {
+                atomicAdd(&l1.sums[0], t1);
+                atomicAdd(&l1.sums[1], t2);
+            }
         }
     }
 }
@@ -708,8 +716,8 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     mom_tile_rows(a, gy, &ry0, &ry1);
     const int nt = gx * (ry1 - ry0);
     if (nt == 0) return MOM_OK;
-    L1Epilogue l1 = {a->l1_target, a->l1_grad, a->l1_sums, 1.0f / (3.0f * (float)a->W * (float)a->H)};
-    if (!l1.grad || !l1.sums) l1.target = nullptr;
+    L1Epilogue l1 = {a->l1_target, a->l1_grad, a->l1_sums, 1.0f / (3.0f * (float)a->W * (float)a->H), a->l1_partials};
+    if (!l1.grad || (!l1.sums && !l1.partials)) l1.target = nullptr;
 #if defined(MOM_FWD_ROWS) && MOM_FWD_ROWS
     hipLaunchKernelGGL(render_fwd_rows_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,

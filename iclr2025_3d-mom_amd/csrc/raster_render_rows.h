@@ -226,8 +226,13 @@ render_fwd_rows_kernel(const uint2* __restrict__ ranges, uint32_t* point_list, i
         if (lane == 0) { s_sum[2 * wv] = a1; s_sum[2 * wv + 1] = a2; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(&l1.sums[0], (s_sum[0] + s_sum[2]) + (s_sum[4] + s_sum[6]));
-            atomicAdd(&l1.sums[1], (s_sum[1] + s_sum[3]) + (s_sum[5] + s_sum[7]));
+            const float t1 = (s_sum[0] + s_sum[2]) + (s_sum[4] + s_sum[6]), t2 = (s_sum[1] + s_sum[3]) + (s_sum[5] + s_sum[7]);
+            if (l1.partials) {
+                reinterpret_cast<float2*>(l1.partials)[tile] = make_float2(t1, t2);
+            } else {
+                atomicAdd(&l1.sums[0], t1);
+                atomicAdd(&l1.sums[1], t2);
+            }
         }
     }
 }

@@ -19,6 +19,10 @@ from . import _native as N
 from . import ops
 from .diff_gaussian_rasterization import _C as RC
 
+# The L1 epilogue of the compositing forward leaves one pair of sums per tile (MomRasterArgs.l1_partials) instead of adding 2040
+# workgroups' pairs into one line; MOM_L1_PARTIALS=0 is the A/B switch (render_fwd 135 -> 127 us with HIP events around it).
+L1_PARTIALS = os.environ.get("MOM_L1_PARTIALS", "1") != "0"
+
 
 class FusedStep:
     def __init__(self, gaussians, opt, hyper, background):
@@ -73,6 +77,9 @@ class FusedStep:
             # start of every step together with its tile counters: no memset of their own (mom_l1_loss_acc / mom_plane_regulation_acc)
             hdr_f = self.img[(-self.img.data_ptr()) % 256:][:256].view(torch.float32)
             self.sums, self.regval = hdr_f[8:10], hdr_f[10:11]
+            # the compositing forward's L1 epilogue leaves one pair of sums per TILE here (MomRasterArgs.l1_partials) instead of 2040
+            # workgroups adding into self.sums: added up only when somebody reads the loss (LazyLoss / _TileSums)
+            self.l1_part = torch.empty(((W + 15) // 16) * ((H + 15) // 16), 2, dtype=torch.float32, device=dev)
             self.ssim_dm = None                  # SSIM term: made on first use (lambda_dssim may be switched on later)
             self.binning = None
         if not same_frame or pad > cap or 2 * pad < cap:
@@ -318,7 +325,11 @@ class FusedStep:
         a.keep_all_tiles = int(self.keep_all_tiles)
         fuse_l1 = not (self.dist is not None and self.dist.mode == "tile-row")
         if fuse_l1:      # L1 (its gradient image and its sums) in the compositing kernel's epilogue; a row shard forms it per slab below
-            a.l1_target, a.l1_grad, a.l1_sums = gt.data_ptr(), self.dimg.data_ptr(), self.sums.data_ptr()
+            a.l1_target, a.l1_grad = gt.data_ptr(), self.dimg.data_ptr()
+            if L1_PARTIALS:
+                a.l1_partials = self.l1_part.data_ptr()
+            else:
+                a.l1_sums = self.sums.data_ptr()
         a.overflow_tag = self.next_tag          # what this step leaves in the sticky word if its binning overflows (Trainer numbers the steps)
         rows = fwd_rows = None
         if dc is not None and dc.mode == "tile-row":
@@ -540,9 +551,37 @@ class FusedStep:
             if lam != 0:
                 self.ssim_sum[0] = tot[2].double()
             l1 = tot[0] / n
-        loss = LazyLoss(self.sums if l1 is None else None, l1, reg, self.ssim_sum if lam != 0 else None, lam, n)
-        self.last = {"loss": loss, "mse_sum": self.sums[1], "n": n}
+        sums = _TileSums(self.l1_part) if (fuse_l1 and L1_PARTIALS) else self.sums
+        loss = LazyLoss(sums if l1 is None else None, l1, reg, self.ssim_sum if lam != 0 else None, lam, n)
+        self.last = {"loss": loss, "mse_sum": _Lazy(sums, 1), "n": n}       # float(last["mse_sum"]): formed when read
         return loss, self.radii, self.g2d
+
+
+class _TileSums:
+    """[sum |image - target|, sum (image - target)^2] of the last step from the per-tile pairs the compositing forward left: sums[k] is a
+    device scalar formed on demand (one torch reduction, in a fixed order: the same bits for the same image).  Like LazyLoss it must be
+    read before the next step overwrites the pairs."""
+
+    def __init__(self, part):
+        self._part, self._t = part, None
+
+    def __getitem__(self, k):
+        if self._t is None:
+            self._t = self._part.sum(0)
+        return self._t[k]
+
+
+class _Lazy:
+    """float(x) / x.tensor() = sums[k], looked up when asked for."""
+
+    def __init__(self, sums, k):
+        self._sums, self._k = sums, k
+
+    def tensor(self):
+        return self._sums[self._k]
+
+    def __float__(self):
+        return float(self.tensor())
 
 
 class LazyLoss:

@@ -51,7 +51,7 @@ typedef void* mom_stream_t; /* hipStream_t */
  *   - MomRasterArgs, the struct that changes most often, additionally starts with `struct_size`: every entry point that
  *     takes it returns MOM_EINVAL unless struct_size == sizeof(MomRasterArgs) of the library.
  * (The reference's counterpart is a C++ static-method signature, rasterizer.h:19-87: there the compiler checks it.) */
-#define MOM_ABI_VERSION 5
+#define MOM_ABI_VERSION 6
 int mom_abi_version(void);
 enum {
     MOM_STRUCT_RASTER_ARGS = 0, MOM_STRUCT_RASTER_GRADS, MOM_STRUCT_RASTER_LAYOUT, MOM_STRUCT_HEXPLANE, MOM_STRUCT_ADAM_TENSOR,
@@ -119,6 +119,12 @@ typedef struct MomRasterArgs {
      * RasterizeGaussiansBackwardCUDA, rasterize_points.cu:154-163; the fused training step does this fill on its second stream
      * during the forward.) */
     int accum_cleared;
+    /* null, or [tiles of the whole image][2] floats (with l1_target set): every workgroup of the compositing forward then STORES its tile's
+     * two sums at entry 2 * (ty * tiles_x + tx) instead of adding them to l1_sums (which may be null): 2040 workgroups adding into one
+     * 64-byte line are serialised by the device (about 8 ns each; 6 us at the tail of the launch at 960x540), and nobody may ever read the
+     * value.  Whoever wants it adds the entries up -- in a fixed order, so the loss value is reproducible to the bit, which the
+     * atomic sums are not.  A tile-row shard writes the entries of its own rows only. */
+    float* l1_partials;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
