@@ -855,7 +855,7 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
         // one event per call: record + wait capture the state at the record, and hipEventDestroy of a recorded event is deferred
         // until it has completed, so nothing is shared between the calls of different threads or streams
         hipEvent_t main_done = nullptr;
-        if (hipEventCreateWithFlags(&main_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
+        if (hipEventCreateWithFlags(&main_done, mom_order_event_flags()) != hipSuccess) return MOM_ELAUNCH;
         const bool ok = hipEventRecord(main_done, s) == hipSuccess && hipStreamWaitEvent(dw_stream, main_done, 0) == hipSuccess;
         (void)hipEventDestroy(main_done);
         if (!ok) return MOM_ELAUNCH;

@@ -753,7 +753,7 @@ static int deform_backward_fused(const MomDeformMLP* w, int P, const float* feat
     hipStream_t ws = (hipStream_t)dw_stream;
     if (ws != (hipStream_t)stream) {
         static hipEvent_t dx_done = nullptr;
-        if (!dx_done && hipEventCreateWithFlags(&dx_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
+        if (!dx_done && hipEventCreateWithFlags(&dx_done, mom_order_event_flags()) != hipSuccess) return MOM_ELAUNCH;
         if (hipEventRecord(dx_done, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
         if (hipStreamWaitEvent(ws, dx_done, 0) != hipSuccess) return MOM_ELAUNCH;
     }
@@ -833,7 +833,7 @@ extern "C" int mom_deform_backward_split(const MomDeformMLP* w, int P, const flo
         // the weight-gradient kernel reads what dx wrote (dH) and nothing behind it on `stream` depends on it: it goes to the
         // caller's second stream, behind an event, and overlaps whatever the caller enqueues on `stream` next
         static hipEvent_t dx_done = nullptr;
-        if (!dx_done && hipEventCreateWithFlags(&dx_done, hipEventDisableTiming) != hipSuccess) return MOM_ELAUNCH;
+        if (!dx_done && hipEventCreateWithFlags(&dx_done, mom_order_event_flags()) != hipSuccess) return MOM_ELAUNCH;
         if (hipEventRecord(dx_done, (hipStream_t)stream) != hipSuccess) return MOM_ELAUNCH;
         if (hipStreamWaitEvent(ws, dx_done, 0) != hipSuccess) return MOM_ELAUNCH;
     }

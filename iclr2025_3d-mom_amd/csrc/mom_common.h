@@ -98,6 +98,9 @@ static inline char* mom_align_ptr(void* p)
     return (char*)(((uintptr_t)p + MOM_ALIGN - 1) & ~(uintptr_t)(MOM_ALIGN - 1));
 }
 
+// flags of the events that order two streams of one device (stream_order.hip)
+unsigned mom_order_event_flags();
+
 // Local tile rows of a (possibly tile-row sharded) launch: [r0, r1) within [0, gy).
 static inline void mom_tile_rows(const MomRasterArgs* a, int gy, int* r0, int* r1)
 {

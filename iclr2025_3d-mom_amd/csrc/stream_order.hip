@@ -4,6 +4,7 @@
 // path's host budget (tools/host_profile.py); a ctypes call into hipEventRecord + hipStreamWaitEvent costs about 1.5 us.
 #include "mom_common.h"
 #include <mutex>
+#include <stdlib.h>
 
 namespace {
 constexpr int kDevices = 64;
@@ -20,7 +21,24 @@ PerDevice* current_device()
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kDevices) return nullptr;
     return &g_dev[d];
 }
-bool ensure(hipEvent_t* e) { return *e || hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess; }
+}  // namespace
+
+// Flags of every event this library orders streams with.  These events are only ever waited for by another stream of the SAME device
+// (hipStreamWaitEvent), never by the host, so the marker needs no system-scope release of its own: the kernels on either side carry
+// their own agent-scope fences, which is all two streams of one device need (and all two consecutive kernels of one stream get).
+// tools/probe/marker_cost.hip: an event record between two kernels costs the recording stream 6.2 us with the default fence and 3.4 us
+// without -- the fused step's main stream carries three per iteration.  MOM_EVENT_SYSTEM_FENCE=1 restores the default.
+unsigned mom_order_event_flags()
+{
+    static const unsigned flags = [] {
+        const char* e = getenv("MOM_EVENT_SYSTEM_FENCE");
+        return (unsigned)hipEventDisableTiming | ((e && e[0] == '1') ? 0u : (unsigned)hipEventDisableSystemFence);
+    }();
+    return flags;
+}
+
+namespace {
+bool ensure(hipEvent_t* e) { return *e || hipEventCreateWithFlags(e, mom_order_event_flags()) == hipSuccess; }
 }  // namespace
 
 int mom_stream_wait_stream(mom_stream_t waiter, mom_stream_t signaler)
