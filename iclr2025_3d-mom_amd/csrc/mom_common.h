@@ -11,7 +11,7 @@
 // ---- private scratch layouts -------------------------------------------------
 // geom (per Gaussian):
 //   rec[P][3] float4 : {x, y, depth, tiles_touched bits} {conic.x, conic.y, conic.z, opacity} {r, g, b, radius bits}
-//   cov3D[P][6] float, clamped[P] uchar4, gacc[P][12] float (backward accumulators), reach[P] u64 (tile cull: bit i =
+//   cov3D[P][6] float, clamped[P] uchar4, gacc[P][MOM_GACC_FLOATS] float (backward accumulators), reach[P] u64 (tile cull: bit i =
 //   tile i of the splat's rectangle is binned; written by tile_hist, read by tile_scatter)
 // image: hdr[64] u32, tile_counts[tiles] u32, tile_cursor[tiles] u32, ranges[tiles] uint2, n_contrib[H*W] u32,
 //        final_T[H*W] f32, tile_order[tiles] u32
@@ -45,7 +45,7 @@ static inline size_t geom_view(char* base, int P, GeomView* v)
     size_t o_rec = off; off = mom_align_up(off + (size_t)P * 48);
     size_t o_cov = off; off = mom_align_up(off + (size_t)P * 24);
     size_t o_cl = off; off = mom_align_up(off + (size_t)P * 4);
-    size_t o_ga = off; off = mom_align_up(off + (size_t)P * 48);
+    size_t o_ga = off; off = mom_align_up(off + (size_t)P * MOM_GACC_FLOATS * 4);
     size_t o_re = off; off = mom_align_up(off + (size_t)P * 8);
     if (v) {
         v->rec = (float4*)(base + o_rec);

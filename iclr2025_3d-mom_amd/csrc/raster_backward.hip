@@ -2,7 +2,7 @@
 //
 // Replaces computeCov2DCUDA + preprocessCUDA(backward) + computeColorFromSH(backward)
 // + computeCov3D(backward) (reference backward.cu:20-412) as ONE kernel: it consumes
-// the per-Gaussian accumulator record gacc[P][12] written by the render backward
+// the per-Gaussian accumulator record gacc[P][MOM_GACC_FLOATS] written by the render backward
 // ({dmean2D.x, .y, dconic.x, .y, .w, dopacity, dcolor r, g, b, ddepth}) and writes
 // every output gradient exactly once (zeros for culled Gaussians), so none of the
 // ten gradient tensors needs a memset (the reference zero-fills them first:
@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
 
     float ga[10];
 #pragma unroll
-    for (int i = 0; i < 10; i++) ga[i] = vis ? a.gacc[(size_t)idx * 12 + i] : 0.f;
+    for (int i = 0; i < 10; i++) ga[i] = vis ? a.gacc[(size_t)idx * MOM_GACC_FLOATS + i] : 0.f;
     // the compositing backward leaves raw sums (raster_render.hip): for the mean, S_x = sum a dx and S_y = sum a dy -- the conic
     // matrix that turns them into dL/d mean (backward.cu:573-579: a (conic (dx, dy))) is the Gaussian's own, so it is applied here,
     // once per Gaussian, instead of there, once per (pixel, splat) pair -- then d(pixel)/d(ndc) with the sign; -1/2 for the conic

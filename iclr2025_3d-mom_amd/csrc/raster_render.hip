@@ -11,7 +11,7 @@
 // (a packed DPP reduce-scatter inside the 16-lane rows, row_totals; the four rows
 // of four consecutive splats are summed by one transposition, rows_transpose_sum)
 // and issues ONE atomic instruction per four (wave, splat) pairs into the
-// per-Gaussian accumulator record gacc[P][12].
+// per-Gaussian accumulator record gacc[P][MOM_GACC_FLOATS].
 #include "mom_common.h"
 #include "raster_bin_dev.h"
 
@@ -457,7 +457,7 @@ __device__ __forceinline__ float swap_add32(float a, float b)
 }
 
 // DEPTH: a gradient arrives for the depth image too (dL_dpixel_depths != null; never in training).
-// The record this kernel leaves per Gaussian (gacc, 12 floats) holds RAW sums: slots 0-1 sum a dx and sum a dy (a = opacity G
+// The record this kernel leaves per Gaussian (gacc, MOM_GACC_FLOATS = 12 floats, ten used) holds RAW sums: slots 0-1 sum a dx and sum a dy (a = opacity G
 // dL/dalpha), i.e. the mean's gradient before the splat's conic matrix, the factors -W/2 and -H/2 of d(pixel)/d(ndc) and the sign
 // are applied; slots 2-4 the conic's, without their -1/2.  The projection backward (raster_backward.hip) applies the matrix and
 // those constants once per Gaussian instead of this loop once per (pixel, splat) pair.  The record stays linear in dL/dpixel, so
@@ -537,7 +537,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             } else {
                 const float tot = swap_add32(h1, t);                   // row q: the totals of the group's splat q
                 const uint32_t jq = (((lane & 32) ? (uint32_t)(jp >> 32) : (uint32_t)jp) >> row_shift) & 0xFFFFu;     // two 32-bit halves: no 64-bit vector shift
-                if (vslot < kVals && (lane >> 4) < n_real) atomicAdd(&gacc[(size_t)s_id[jq] * 12 + vslot], tot);
+                if (vslot < kVals && (lane >> 4) < n_real) atomicAdd(&gacc[(size_t)s_id[jq] * MOM_GACC_FLOATS + vslot], tot);
                 npend = 0;
             }
         }
@@ -735,7 +735,7 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
 {
     const int gx = (a->W + MOM_TILE - 1) / MOM_TILE, gy = (a->H + MOM_TILE - 1) / MOM_TILE;
     const uint32_t cap = capacity > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)capacity;
-    if (!a->accum_cleared && hipMemsetAsync(g.gacc, 0, (size_t)a->P * 48, s) != hipSuccess) return MOM_ELAUNCH;
+    if (!a->accum_cleared && hipMemsetAsync(g.gacc, 0, (size_t)a->P * MOM_GACC_FLOATS * 4, s) != hipSuccess) return MOM_ELAUNCH;
     MomProfScope ps(MOM_P_RENDER_BWD, s);
     int ry0, ry1;
     mom_tile_rows(a, gy, &ry0, &ry1);

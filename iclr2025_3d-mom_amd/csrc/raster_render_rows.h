@@ -3,7 +3,8 @@
 // -DMOM_BWD_ROWS=1 / -DMOM_FWD_ROWS=1 (tools/variants.sh), both OFF in the shipped library:
 //   backward: the loop is faster (147 us against 190 with the accumulation compiled out, -DMOM_ROWS_NOATOMIC) but it emits 2.4 x the
 //             accumulator rows, and the device accepts about 20 G atomic 64-byte lines per second whatever the number of lanes or compute
-//             units (tools/probe/lds_row_atomic.hip): 340 us as is, 228 us with 64-byte records (-DMOM_ROWS_STRIDE16, timing only);
+//             units (tools/probe/lds_row_atomic.hip): 340 us with the 48-byte records the library had when this was measured, 228 us with
+//             64-byte ones (-DMOM_GACC_FLOATS=16);
 //             LDS float atomics cost 2.7 cycles per active lane, so a tile-level pre-reduction in LDS is no way out either;
 //   forward:  bit-identical images, 142 us against 135: the shorter loop (-12 us) does not pay for sixteen lists per tile.
 // ---- the backward with one splat list per 16-lane ROW -------------------------------------------------------------------------------
@@ -406,10 +407,8 @@ render_bwd_rows_kernel(const uint2* __restrict__ ranges, const uint32_t* __restr
             // lane k of a row holds the row's total of value k: one accumulator row per (row, splat) pair
 #ifdef MOM_ROWS_NOATOMIC
             if (v == 123.456f) gacc[0] = v;
-#elif defined(MOM_ROWS_STRIDE16)
-            if (vslot < kVals && act) atomicAdd(&gacc[(size_t)(__float_as_uint(r2.w) & 0x1FFFFu) * 16 + vslot], v);
 #else
-            if (vslot < kVals && act) atomicAdd(&gacc[(size_t)__float_as_uint(r2.w) * 12 + vslot], v);
+            if (vslot < kVals && act) atomicAdd(&gacc[(size_t)__float_as_uint(r2.w) * MOM_GACC_FLOATS + vslot], v);
 #endif
         }
     }

@@ -160,7 +160,7 @@ class FusedStep:
         lay = N.MomRasterLayout()
         self.lib.mom_raster_layout(P, W, H, 0, C.byref(lay))
         base = self.geom[(-self.geom.data_ptr()) % 256:]
-        return base[lay.geom_gacc:lay.geom_gacc + P * 48].view(torch.float32)
+        return base[lay.geom_gacc:lay.geom_gacc + P * 4 * N.GACC_FLOATS].view(torch.float32)
 
     def _deform_grads(self):
         """Flat zero-able gradient storage for the deformation field (planes channel-last + live MLP tensors)."""

@@ -52,6 +52,13 @@ typedef void* mom_stream_t; /* hipStream_t */
  *     takes it returns MOM_EINVAL unless struct_size == sizeof(MomRasterArgs) of the library.
  * (The reference's counterpart is a C++ static-method signature, rasterizer.h:19-87: there the compiler checks it.) */
 #define MOM_ABI_VERSION 6
+/* floats per Gaussian of the compositing backward's accumulator record (mom_raster_layout().geom_gacc); ten are used.  (A build with
+ * -DMOM_GACC_FLOATS=16 pads the record to one 64-byte line: a device-scope atomic costs the device by the LINES an instruction
+ * touches and 48-byte records straddle 1.5 on average -- but the shipped kernel's atomics hide under its arithmetic, and the larger
+ * record measured 3 us SLOWER in render_bwd and 5 us per step, three alternating pairs in one call: DESIGN.md section 3.1.) */
+#ifndef MOM_GACC_FLOATS
+#define MOM_GACC_FLOATS 12
+#endif
 int mom_abi_version(void);
 enum {
     MOM_STRUCT_RASTER_ARGS = 0, MOM_STRUCT_RASTER_GRADS, MOM_STRUCT_RASTER_LAYOUT, MOM_STRUCT_HEXPLANE, MOM_STRUCT_ADAM_TENSOR,
@@ -114,7 +121,7 @@ typedef struct MomRasterArgs {
     float* l1_grad;
     float* l1_sums;
     /* !=0: the caller has already cleared the backward's per-Gaussian accumulator record in the geometry scratch
-     * (mom_raster_layout().geom_gacc, 48 bytes per Gaussian) since the last backward read it; mom_raster_backward /
+     * (mom_raster_layout().geom_gacc, MOM_GACC_FLOATS floats = 48 bytes per Gaussian) since the last backward read it; mom_raster_backward /
      * _backward_render then skip their own fill command.  (The reference zeroes its ten gradient tensors in
      * RasterizeGaussiansBackwardCUDA, rasterize_points.cu:154-163; the fused training step does this fill on its second stream
      * during the forward.) */
@@ -184,7 +191,7 @@ int mom_raster_backward(const MomRasterArgs* a, const int* radii, void* geom, vo
 
 /* The two halves of mom_raster_backward, for callers that must exchange between them (tile-row shard):
  * _render runs the compositing backward over this rank's tile rows and leaves, in the geometry scratch at
- * mom_raster_layout().geom_gacc, one record of 12 floats per Gaussian: the sums over the local pixels of the raw terms of
+ * mom_raster_layout().geom_gacc, one record of MOM_GACC_FLOATS floats per Gaussian (ten used): the sums over the local pixels of the raw terms of
  * dL/d{mean2D.x, mean2D.y (before the Gaussian's conic matrix and the pixel-to-NDC factors are applied), conic.x, conic.y, conic.z
  * (before their -1/2), opacity, r, g, b, depth} and two zeros.  The
  * projection backward is linear in that record, so ranks sum it (an all-reduce of 48 bytes per Gaussian) and

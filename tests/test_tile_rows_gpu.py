@@ -59,7 +59,7 @@ def _run(s, rows=None, dcol=None, ddep=None):
 
 def _gacc(run, P):
     off = run["lay"].geom_gacc
-    return _aligned(run["geom"])[off:off + P * 48].view(torch.float32).view(P, 12)
+    return _aligned(run["geom"])[off:off + P * 4 * N.GACC_FLOATS].view(torch.float32).view(P, N.GACC_FLOATS)
 
 
 def _geometry_backward(run, P):
