@@ -22,7 +22,7 @@ class MomError(RuntimeError):
 
 
 GACC_FLOATS = int(os.environ.get("MOM_GACC_FLOATS", "12"))         # (the override: only for A/B builds with -DMOM_GACC_FLOATS=16)
-# MOM_GACC_FLOATS: floats per Gaussian of the backward's accumulator record (one 64-byte line)
+# MOM_GACC_FLOATS: floats per Gaussian of the backward's accumulator record
 ABI_VERSION = 6          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
 
 
