@@ -40,7 +40,8 @@ class MomRasterArgs(C.Structure):
                 ("keep_all_tiles", C.c_int),                        # !=0: bin the whole rectangle like the reference (tests)
                 ("l1_target", C.c_void_p), ("l1_grad", C.c_void_p), ("l1_sums", C.c_void_p),   # optional L1 epilogue of the forward
                 ("accum_cleared", C.c_int),
-                ("l1_partials", C.c_void_p)]                        # per-tile sums of the L1 epilogue instead of two contended atomics
+                ("l1_partials", C.c_void_p),                        # per-tile sums of the L1 epilogue instead of two contended atomics
+                ("status_post", C.c_void_p), ("status_serial", C.c_uint)]   # the frame's status bits, posted to pinned host memory
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)

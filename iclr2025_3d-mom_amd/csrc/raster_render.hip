@@ -156,7 +156,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FW
 render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read AND, for the tiles sorted here, written: no restrict */, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                   uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-                  uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys, uint32_t* __restrict__ tile_walked)
+                  uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys, uint32_t* __restrict__ tile_walked,
+                  unsigned long long* status_post, uint32_t status_serial)
 {
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
@@ -307,6 +308,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     // 256 like the reference's (forward.cu:305-327), and a round is entered unless every pixel of the tile is done.  One plain
     // store per tile into the scatter's cursor array, which nothing reads after the binning.
     if (threadIdx.x == 0) tile_walked[tile] = (uint32_t)min(list_len, walked_rounds * kRound);
+    // MomRasterArgs.status_post: the frame's status bits (header word 1, final since the binning) go to a pinned host word with the
+    // caller's serial number -- one store by one thread of the launch instead of a copy kernel and a marker behind every frame
+    if (status_post && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(status_post, ((unsigned long long)status_serial << 32) | order_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (inside) {
         const int pix = py * W + px;
         if (final_T) final_T[pix] = T;                      // null in forward-only rendering: nothing will read them
@@ -721,12 +726,12 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
 #if defined(MOM_FWD_ROWS) && MOM_FWD_ROWS
     hipLaunchKernelGGL(render_fwd_rows_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
-                       out_depth, cap, l1, sort_small ? b.keys : nullptr, im.tile_cursor);
+                       out_depth, cap, l1, sort_small ? b.keys : nullptr, im.tile_cursor, a->status_post, a->status_serial);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 #endif
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
-                       out_depth, cap, l1, sort_small ? b.keys : nullptr, im.tile_cursor);
+                       out_depth, cap, l1, sort_small ? b.keys : nullptr, im.tile_cursor, a->status_post, a->status_serial);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
 

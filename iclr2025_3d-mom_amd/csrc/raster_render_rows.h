@@ -65,7 +65,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FW
 render_fwd_rows_kernel(const uint2* __restrict__ ranges, uint32_t* point_list, int W, int H, int gx, int nt, int t0, int run,
                        const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
                        uint32_t* __restrict__ n_contrib, float* __restrict__ out_color, float* __restrict__ out_depth,
-                       uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys, uint32_t* __restrict__ tile_walked)
+                       uint32_t capacity, L1Epilogue l1, const uint64_t* __restrict__ sort_keys, uint32_t* __restrict__ tile_walked,
+                       unsigned long long* status_post, uint32_t status_serial)
 {
     static_assert(kRound == 256, "8-bit slot numbers; one staged splat per thread");
     __shared__ float4 s_rec[kRound * 3];
@@ -193,6 +194,8 @@ render_fwd_rows_kernel(const uint2* __restrict__ ranges, uint32_t* point_list, i
         }
     }
     if (threadIdx.x == 0) tile_walked[tile] = (uint32_t)min(list_len, walked_rounds * kRound);
+    if (status_post && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(status_post, ((unsigned long long)status_serial << 32) | order_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (inside) {
         const int pix = py * W + px;
         if (final_T) final_T[pix] = T;

@@ -57,6 +57,34 @@ def pinned_word():
 COUNT_PENDING = -1             # no frame has 2^32 - 1 instances
 
 
+def post_slot(serial):
+    """(address, slot) of the pinned 64-bit word async-mode forward number `serial` posts its status bits into
+    (MomRasterArgs.status_post: the compositing kernel stores (serial << 32) | bits there itself -- no copy command and no event behind
+    the forward; they were 15 us of host time per call on a path the host paces).  A slot comes round again 256 forwards later."""
+    ring = _state.get("post_ring")
+    if ring is None:
+        ring = _state["post_ring"] = torch.zeros(_PIN_RING, dtype=torch.int64).pin_memory()
+        _state["post_np"] = ring.numpy()
+    slot = serial % _PIN_RING
+    return ring.data_ptr() + 8 * slot, slot
+
+
+def posted(slot, serial, timeout_s=60.0):
+    """The status bits forward `serial` posted into `slot`; polled until they are there (wait_count explains why not an event)."""
+    import time
+    ring, want = _state["post_np"], serial & 0xFFFFFFFF
+    v = int(ring[slot])
+    if (v >> 32) & 0xFFFFFFFF != want:
+        t0 = time.perf_counter()
+        while True:
+            v = int(ring[slot])
+            if (v >> 32) & 0xFFFFFFFF == want:
+                break
+            if time.perf_counter() - t0 > timeout_s:
+                raise N.MomError(f"async forward {serial} never posted its status (slot {slot} holds {v:#x})")
+    return v & 0xFFFFFFFF
+
+
 def wait_count(nr_host, ev=None, spin_s=float(__import__("os").environ.get("MOM_COUNT_SPIN_S", "0.02"))):
     """The frame's instance count, as soon as the geometry stage has written it.  The count reaches the host without a copy command:
     tile_scan stores it into this pinned, device-visible word (system scope), so the host can POLL the word instead of waiting for
@@ -93,9 +121,8 @@ def overflow_flag(device):
 def _check_overflow(lag):
     q = _state["pending"]
     while len(q) > lag:
-        ev, host, count, serial = q.popleft()
-        ev.synchronize()
-        if not (int(host[0]) & 1):
+        slot, count, serial = q.popleft()
+        if not (posted(slot, serial) & 1):
             _state["verified"] = serial
             continue
         q.clear()
@@ -255,17 +282,18 @@ def rasterize_gaussians(bg, means3D, colors, opacity, scales, rotations, scale_m
         cap = max(_state["cap_hint"], 4096)
     _state["last_R"] = nr_host
     binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, cap),), dtype=torch.uint8, device=dev)
-    N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
-                                          out_color.data_ptr(), out_depth.data_ptr(),
-                                          flag.data_ptr() if (_state["mode"] == "async" and not blind) else None, stream),
-            "mom_raster_forward_render")
-    if _state["mode"] == "async" and not blind:
-        status_host = pinned_word()
-        status_host.copy_(flag, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+    tracked = _state["mode"] == "async" and not blind
+    if tracked:
+        # the frame's own status bits come back through a pinned word the compositing kernel writes (post_slot); the sticky device
+        # word (flag) is what gates the optimizer on the device
         _state["serial"] += 1
-        _state["pending"].append((ev, status_host, nr_host, _state["serial"]))
+        a.status_post, slot = post_slot(_state["serial"])
+        a.status_serial = _state["serial"] & 0xFFFFFFFF
+    N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(),
+                                          out_color.data_ptr(), out_depth.data_ptr(), flag.data_ptr() if tracked else None, stream),
+            "mom_raster_forward_render")
+    if tracked:
+        _state["pending"].append((slot, nr_host, _state["serial"]))
     del keep
     return cap, out_color, out_depth, radii, geom, binning, img
 

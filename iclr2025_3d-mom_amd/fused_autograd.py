@@ -159,15 +159,13 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
         state["last_R"] = nr_host
         st.cap = cap
         st.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
+        # the frame's status bits come back through a pinned word the compositing kernel writes (RC.post_slot): no copy, no event
+        state["serial"] += 1
+        a.status_post, slot = RC.post_slot(state["serial"])
+        a.status_serial = state["serial"] & 0xFFFFFFFF
         N.check(lib.mom_raster_forward_render(C.byref(a), st.geom.data_ptr(), st.binning.data_ptr(), cap, st.img.data_ptr(),
                                               st.color.data_ptr(), st.depth.data_ptr(), flag.data_ptr(), s), "raster_render")
-    if flag is not None:
-        status_host = RC.pinned_word()
-        status_host.copy_(flag, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        state["serial"] += 1
-        state["pending"].append((ev, status_host, nr_host, state["serial"]))
+        state["pending"].append((slot, nr_host, state["serial"]))
     return st
 
 

@@ -41,11 +41,13 @@ class FusedRender:
         self.img = torch.empty(self.lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
         self.nr_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        # per-frame status word of the image scratch (header word 1: bit 0 = this frame's binning overflowed), copied to a
-        # pinned ring behind an event after every async-mode frame
+        # per-frame status word of the image scratch (header word 1: bit 0 = this frame's binning overflowed): the compositing kernel
+        # posts it, with the frame's serial number, into a slot of this pinned ring (MomRasterArgs.status_post) -- no copy command and
+        # no event behind an async-mode frame (a blit kernel and a marker were 12 us of the stream per frame)
         self.hdr = self.img[(-self.img.data_ptr()) % 256:][:8].view(torch.int32)
-        self.flag_ring = torch.zeros(self.RING, dtype=torch.int32).pin_memory()
-        self.pending = deque()               # (frame serial, ring slot, event), oldest first
+        self.flag_ring = torch.zeros(self.RING, dtype=torch.int64).pin_memory()
+        self._ring_np = self.flag_ring.numpy()      # (a view of the same pinned words: reading one costs 0.1 us, indexing the tensor 2)
+        self.pending = deque()               # (frame serial, ring slot), oldest first
         self.cap, self.binning = 0, None
 
     RING, FLAG_LAG = 64, 8
@@ -57,13 +59,29 @@ class FusedRender:
         everything rendered so far.  The capacity is raised so that a repeat fits."""
         bad = []
         while len(self.pending) > lag:
-            serial, slot, ev = self.pending.popleft()
-            ev.synchronize()
-            if int(self.flag_ring[slot]) & 1:
+            serial, slot = self.pending.popleft()
+            if self._posted(serial, slot) & 1:
                 bad.append(serial)
         if bad:
             self.cap_floor = max(getattr(self, "cap_floor", 0), 2 * self.cap)
         return bad
+
+    def _posted(self, serial, slot, timeout_s=60.0):
+        """The status bits frame `serial` left in ring slot `slot`: polled until the slot's upper half carries that serial (the frames
+        that are asked about are FLAG_LAG frames old: it is there)."""
+        import time
+        want = serial & 0xFFFFFFFF
+        ring = self._ring_np
+        v = int(ring[slot])
+        if (v >> 32) & 0xFFFFFFFF != want:
+            t0 = time.perf_counter()
+            while True:
+                v = int(ring[slot])
+                if (v >> 32) & 0xFFFFFFFF == want:
+                    break
+                if time.perf_counter() - t0 > timeout_s:
+                    raise N.MomError(f"async render(): frame {serial} never posted its status (slot {slot} holds {v:#x})")
+        return v & 0xFFFFFFFF
 
     def render(self, cam, bg, delta_scale, scaling_modifier=1.0, debug=False, order=False):
         """order: the field's processing order if the caller already has it (FusedRenderPool takes it on the caller's stream)."""
@@ -140,16 +158,18 @@ class FusedRender:
         if self.binning is None or want > self.cap or want < self.cap // 4:
             self.cap = want
             self.binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, self.cap), dtype=torch.uint8, device=dev)
+        self.serial += 1
+        post = RC._state["mode"] != "exact"
+        if post:
+            # (the slot is reused RING frames later, long after overflowed() has looked at it FLAG_LAG frames behind; serial 0 is never
+            # posted, so a fresh ring matches nothing)
+            slot = self.serial % self.RING
+            a.status_post, a.status_serial = self.flag_ring.data_ptr() + 8 * slot, self.serial & 0xFFFFFFFF
         N.check(lib.mom_raster_forward_render(C.byref(a), self.geom.data_ptr(), self.binning.data_ptr(), self.cap,
                                               self.img.data_ptr(), color.data_ptr(), depth.data_ptr(),
                                               None, s), "raster_render")
-        self.serial += 1
-        if RC._state["mode"] != "exact":
-            slot = self.serial % self.RING
-            self.flag_ring[slot:slot + 1].copy_(self.hdr[1:2], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self.pending.append((self.serial, slot, ev))
+        if post:
+            self.pending.append((self.serial, slot))
         return color, depth, radii
 
 
