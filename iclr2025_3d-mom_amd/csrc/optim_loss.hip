@@ -32,6 +32,40 @@ __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a)
     const float w1 = a.w1, w2 = a.w2;
     const float step_size = T.lr / T.bias_correction1;
     const float inv_bc2_sqrt = 1.f / T.bias_correction2_sqrt;
+#ifndef MOM_ADAM_SCALAR
+    // 16 bytes per lane where the four arrays allow it (the parameters and the moments are allocations of their own; a gradient may be
+    // a view into a bucket at any 4-byte offset) and the workgroup's eight rows of 256 are all inside the tensor: the same
+    // arithmetic per element, a quarter of the memory instructions -- what matters when the launch has an eighth of the chip (the
+    // early launch beside the MLP backward) and the stream is bound by how much each CU keeps in flight
+    const bool vec = (((uintptr_t)T.param | (uintptr_t)T.grad | (uintptr_t)T.exp_avg | (uintptr_t)T.exp_avg_sq) & 15) == 0 &&
+                     base + kAdamPerBlock <= T.n;
+    if (vec) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const size_t i4 = base / 4 + (size_t)k * 256 + threadIdx.x;
+            const float4 g4 = reinterpret_cast<const float4*>(T.grad)[i4];
+            float4 m4 = reinterpret_cast<float4*>(T.exp_avg)[i4], v4 = reinterpret_cast<float4*>(T.exp_avg_sq)[i4];
+            float4 p4 = reinterpret_cast<float4*>(T.param)[i4];
+            float* gp = const_cast<float*>(reinterpret_cast<const float*>(&g4));
+            float *mp = reinterpret_cast<float*>(&m4), *vp = reinterpret_cast<float*>(&v4), *pp = reinterpret_cast<float*>(&p4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float g = gp[e];
+                float m = mp[e], v = vp[e];
+                m = m + (g - m) * w1;
+                v = v * a.beta2 + w2 * g * g;
+                const float denom = sqrtf(v) * inv_bc2_sqrt + a.eps;
+                pp[e] = pp[e] - step_size * (m / denom);
+                mp[e] = m;
+                vp[e] = v;
+            }
+            reinterpret_cast<float4*>(T.param)[i4] = p4;
+            reinterpret_cast<float4*>(T.exp_avg)[i4] = m4;
+            reinterpret_cast<float4*>(T.exp_avg_sq)[i4] = v4;
+        }
+        return;
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const size_t i = base + (size_t)k * 256 + threadIdx.x;
