@@ -492,6 +492,49 @@ def test_l1_epilogue_of_the_forward_equals_the_l1_kernel():
     np.testing.assert_allclose(s1.cpu().numpy(), [float(ref.abs().sum()), float((ref * ref).sum())], rtol=2e-6)
 
 
+def test_status_post_reports_the_frames_own_overflow_with_its_serial():
+    """MomRasterArgs.status_post: the compositing forward leaves (serial << 32) | status bits in a pinned host word -- bit 0 set
+    exactly when this frame's instances did not fit `capacity` -- so that a host running ahead needs no copy and no event per frame."""
+    from hip_helpers import N, t
+    s = random_gaussians(3000, seed=5, W=160, H=96)
+    W, H, P = s["W"], s["H"], 3000
+    lib, st = N.lib(), N.current_stream()
+    dev = "cuda"
+    keep = {k: t(s[k]) for k in ("bg", "means3D", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "campos", "shs")}
+    a = N.MomRasterArgs()
+    a.P, a.D, a.M, a.W, a.H = P, 3, 16, W, H
+    a.background, a.means3D, a.shs, a.opacities = keep["bg"].data_ptr(), keep["means3D"].data_ptr(), keep["shs"].data_ptr(), keep["opacities"].data_ptr()
+    a.scales, a.rotations = keep["scales"].data_ptr(), keep["rotations"].data_ptr()
+    a.viewmatrix, a.projmatrix, a.campos = keep["viewmatrix"].data_ptr(), keep["projmatrix"].data_ptr(), keep["campos"].data_ptr()
+    a.scale_modifier, a.tan_fovx, a.tan_fovy = 1.0, s["tanfovx"], s["tanfovy"]
+    geom = torch.empty(lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
+    img = torch.empty(lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    nr_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    nr_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    word = torch.zeros(2, dtype=torch.int64).pin_memory()
+    color, depth = torch.empty(3, H, W, device=dev), torch.empty(1, H, W, device=dev)
+
+    def frame(serial, capacity, slot):
+        a.status_post, a.status_serial = word.data_ptr() + 8 * slot, serial
+        N.check(lib.mom_raster_forward_geometry(C.byref(a), geom.data_ptr(), img.data_ptr(), radii.data_ptr(), nr_dev.data_ptr(),
+                                                nr_host.data_ptr(), st), "geometry")
+        torch.cuda.synchronize()
+        R = int(nr_host[0])
+        cap = R if capacity is None else capacity
+        binning = torch.empty(lib.mom_raster_binning_bytes(P, W, H, cap), dtype=torch.uint8, device=dev)
+        N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), cap, img.data_ptr(), color.data_ptr(),
+                                              depth.data_ptr(), None, st), "render")
+        torch.cuda.synchronize()
+        return R, int(word[slot])
+
+    R, v = frame(7, None, 0)
+    assert R > 1000 and (v >> 32) & 0xFFFFFFFF == 7 and (v & 1) == 0
+    R, v = frame(0xFFFFFFF0, R // 4, 1)                      # a quarter of what the frame needs: flagged, under its own serial
+    assert (v >> 32) & 0xFFFFFFFF == 0xFFFFFFF0 and (v & 1) == 1
+    assert (int(word[0]) >> 32) & 0xFFFFFFFF == 7             # the other slot is untouched
+
+
 def test_tile_cull_with_degenerate_splats():
     """Opacity 0, negative, NaN, above 1; needle-thin and huge splats; a NaN position: whatever the compositing kernels make of
     them, they make the same of them with and without the tile cull (bit patterns compared, NaNs included)."""
