@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--by-cum", action="store_true", help="sort by cumulative time")
     ap.add_argument("--async-mode", action="store_true", help="autograd path in the async sync mode (bench.py via_render_api)")
     ap.add_argument("--autograd", action="store_true", help="the render() + loss.backward() path instead of the fused step")
+    ap.add_argument("--freeze", action="store_true", help="gc.collect(); gc.freeze() after setup, as bench.py's legs do")
     a = ap.parse_args()
     import torch
     if a.autograd:
@@ -38,6 +39,9 @@ def main():
         import importlib
         DGR = importlib.import_module("iclr2025_3d-mom_amd.diff_gaussian_rasterization")
         DGR.set_sync_mode("async", capacity_hint=2_000_000)
+        import gc; gc.collect(); gc.freeze()
+
+    if a.freeze:
         import gc; gc.collect(); gc.freeze()
 
     def one(i):
