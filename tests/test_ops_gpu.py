@@ -99,7 +99,13 @@ def test_fused_adam_matches_torch_adam_incl_tiny_eps():
             if it == 2 and gr["params"][0].shape == (7,):
                 continue                                                           # a param without grad is skipped
             gr["params"][0].grad = g.clone()
-            gh["params"][0].grad = g.clone().cuda()
+            # (the device gradients are views at 4-, 8- and 12-byte offsets of a larger buffer in turn -- as the fused step's buckets
+            # hand them out when P is odd: the kernel's 16-byte path must step aside for them, tensor by tensor)
+            k = (it + gr["params"][0].numel()) % 4
+            buf = torch.empty(g.numel() + 4, device="cuda")
+            view = buf[k:k + g.numel()].view(g.shape) if g.is_contiguous() else g.clone().cuda()
+            view.copy_(g)
+            gh["params"][0].grad = view
         ref.step()
         hip.step()
         ref.zero_grad(set_to_none=True)
