@@ -78,6 +78,7 @@ def cpu_baseline(cfg, budget_s=45.0):
         times.sort()
         dt = times[len(times) // 2]
     return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample_short": f"median of {len(times)} steps of the same scene after 3 warm-up, {dt:.2f} s/step",
             "sample": f"median of {len(times)} fine-stage steps of the same scene after 3 warm-up ({dt:.2f} s/step; "
                       f"min {times[0]:.2f}, max {times[-1]:.2f})",
             "protocol": "BASELINE.md section 2: median of >= 20 steps after 3 warm-up" + ("" if len(times) >= 20 else
@@ -202,6 +203,120 @@ Q_IS = ("SURVEY 8d: evaluated pixel-Gaussian pairs = sum over tiles of 256 x (li
         "walks every entry); alpha_pairs: sum of n_contrib over the pixels.  *_ref: on the reference's lists (keep_all_tiles)")
 
 
+EXPLAIN = {
+    "value": "training steps per second over exactly --steps steps after --warmup, whole job (camera-batch shard: summed over ranks); full "
+             "iteration in the timed region: LR -> render (field, projection, binning, compositing) -> L1 (+ plane regularisers) -> backward "
+             "-> densification statistics -> Adam; inputs resident in HBM; verified applied by Trainer.drain() before the clock stops",
+    "config.instances_R": "the reference's instance count (every tile of every splat's rectangle), mean over the cameras of the timed steps",
+    "config.instances_binned": "what the default binning keeps: instances that can reach alpha >= 1/255 in their tile",
+    "config.pairs_Q": Q_IS,
+    "config.legs": "numbers only; every leg is a reading of the same metric.  steady: 200 steps after 50 (SURVEY 8d); with_ssim: lambda_dssim 0.2; "
+                   "keep_all_tiles: the reference-identical binning (integer indices bit-exact); via_render_api / _exact: gaussian_renderer.render() "
+                   "+ torch loss + loss.backward() + optimizer.step() as train_4DGS.py:189-297 drives the modules, in async and in the drop-in's "
+                   "default exact sync mode (host_ms = wall time of the Python loop that enqueues the window); c1 / c3 / c5: BASELINE configs "
+                   "[0] / [2] / [4]'s per-GPU model (c5 with the trainer's own prune round at iteration 5100 inside the window: before / boundary / "
+                   "after; c5_cold_allocator: the same without the allocator prewarm, i.e. a process's first round); frac = step-level HBM roofline "
+                   "on processed instances",
+    "config.legs.render_fps": "no-grad render() over the 59-pose side trajectory (render_4DGS.py:60-71): two_streams / one_stream (async sizing) / "
+                              "one_stream_exact (the drop-in's default sync mode), images left on the device; as_scripted = render_set with every "
+                              "frame written as PNG through the asynchronous writer, FPS = (frames - 1) / seconds as render_4DGS.py:71 prints it; "
+                              "blocking = the reference's order (each PNG encoded inside the loop, render_4DGS.py:64)",
+    "roofline": "dominant kernel (render_bwd).  bound valu: achieved = SQ_INSTS_VALU per launch (committed --pmc pass of the same workload and "
+                "library build) / live launch duration (HIP events on the launch stream, a leg of its own after the headline region); peak = 1024 "
+                "SIMDs x clock / 2 cycles (the issue rate behind the 157 TFLOP/s fp32 vector peak).  hbm_*: 84 R' + 24 N algorithmic bytes per "
+                "launch against 8 TB/s; traffic = HBM bytes per launch from the committed PMC summary (null when collected on another build); "
+                "useful_flop_frac = 70 FLOP x q_bwd / duration / 157 TFLOP/s (SURVEY 8d); alpha_pair_flop_frac on the pairs that reach the exponent",
+    "roofline.step": "whole step: algorithmic bytes (SURVEY 8d per-unit figures x units, profiling.step_bytes) / ms_per_step against 8 TB/s; "
+                     "frac_on_reference_R prices the reference's instance count instead of the processed one",
+    "cpu_baseline": "oracle Trainer (C restatement of the rasterizer + the reference's torch-op sequence) on this host's cores: median of up to 20 "
+                    "fine-stage steps after 3 warm-up; threads = the fastest setting measured on 2 x EPYC 9575F (8: 2.4, 16: 1.4, 32: 1.6, 64: 2.5, "
+                    "128: 4.5 s per step -- float `omp atomic` and torch's small ops stop scaling), not the core count",
+    "full record": "the complete document with every sub-field goes to stderr behind the tag BENCH_FULL and, when MOM_BENCH_FULL names a path, "
+                   "into that file (profiles/r06_bench_full.json is such a file)",
+}
+
+
+def _r(x, n=4):
+    """Numbers of the compact line: n significant digits are what a bench figure carries."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+    return x
+
+
+def compact_line(full):
+    """The ONE JSON line of stdout: < 4 KB, numbers only below `config.legs`, so that the driver's record (which keeps `config`,
+    `roofline` and `cpu_baseline` whole and truncates strings) carries every figure BASELINE.md's table quotes.  Prose lives in
+    EXPLAIN (`bench.py --explain`); the complete document goes to stderr / MOM_BENCH_FULL."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+    out = {k: full[k] for k in keep}
+    c = full["config"]
+    cfg = {k: c[k] for k in ("workload", "gaussians", "frames", "width", "height", "step_path", "lambda_dssim", "parallelism",
+                             "ranks_seen", "host_sync", "gaussians_at_end", "steps_replayed_after_overflow") if k in c}
+    cfg["instances_R"] = _r(c.get("instances_R"), 6)
+    cfg["instances_binned"] = _r(c.get("instances_binned"), 6)
+    cfg["final_loss"] = _r(c.get("final_loss"), 5)
+    q = (c.get("pairs_Q") or {}).get("processed")
+    if q:
+        cfg["pairs_Q"] = {k: _r(v, 4) for k, v in q.items()}
+
+    def leg(d):
+        o = {"value": _r(d["value"]), "ms": _r(d["ms_per_step"])}
+        if "host_enqueue_ms_per_step" in d:
+            o["host_ms"] = _r(d["host_enqueue_ms_per_step"])
+        rs = d.get("roofline_step")
+        if rs:
+            o["frac"] = _r(rs["frac"], 3)
+        dw = d.get("densify_in_window")
+        if dw:
+            sg = dw["segments"]
+            o.update(gaussians_before=dw["gaussians_before"], gaussians_after=dw["gaussians_after"],
+                     boundary_ms=_r(sg["boundary"]["ms"]), before=_r(sg["before"]["steps_per_s"]), after=_r(sg["after"]["steps_per_s"]),
+                     prewarmed=bool(dw.get("allocator_prewarmed_bytes")))
+        return o
+
+    legs = {}
+    for k in ("steady", "with_ssim", "keep_all_tiles", "via_render_api", "via_render_api_exact"):
+        if full.get(k):
+            legs[k] = leg(full[k])
+    for k, d in (full.get("other_configs") or {}).items():
+        legs[k] = leg(d)
+    rf = full.get("render_fps")
+    if rf:
+        legs["render_fps"] = {"two_streams": _r(rf["value"]), "one_stream": _r(rf["one_stream"]["value"]),
+                              "one_stream_exact": _r(rf["one_stream_exact"]["value"])}
+        if "as_scripted" in rf:
+            legs["render_fps"].update(as_scripted=_r(rf["as_scripted"]["value"]), blocking=_r(rf["as_scripted_blocking"]["value"]))
+    if legs:
+        cfg["legs"] = legs
+    out["config"] = cfg
+    rl = full.get("roofline")
+    if rl:
+        o = {k: _r(rl.get(k), 5) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches",
+                                            "wave_insts_per_launch", "useful_flop_frac", "alpha_pair_flop_frac")}
+        if o["unit"] and len(o["unit"]) > 20:
+            o["unit"] = "Ginst/s"
+        hb = rl.get("hbm") or {}
+        o.update(hbm_achieved=_r(hb.get("achieved")), hbm_peak=hb.get("peak"), hbm_frac=_r(hb.get("frac"), 3),
+                 hbm_bytes_per_launch=_r(hb.get("algorithmic_bytes_per_launch"), 5))
+        o["counters_live"] = not (rl.get("sq_stale") or rl.get("traffic_stale"))
+        o["counters_from"] = rl.get("sq_source")
+        out["roofline"] = o
+    else:
+        out["roofline"] = None
+    rs = full.get("roofline_step")
+    if rs and out["roofline"] is not None:
+        out["roofline"]["step"] = {"bound": "hbm", "achieved": _r(rs["achieved"]), "peak": rs["peak"], "unit": rs["unit"], "frac": _r(rs["frac"], 3),
+                                   "frac_on_reference_R": _r(rs["frac_on_reference_R"], 3), "bytes_per_step": _r(rs["algorithmic_bytes_per_step"], 5)}
+    elif rs:
+        out["roofline_step"] = {"bound": "hbm", "achieved": _r(rs["achieved"]), "peak": rs["peak"], "unit": rs["unit"], "frac": _r(rs["frac"], 3)}
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                               "sample": cb.get("sample_short") or cb["sample"][:110], "host": (cb.get("host") or {}).get("Model name")}
+    return out
+
+
 def mean_q(rows):
     return {k: sum(r[k] for r in rows) / len(rows) for k in rows[0]} if rows else None
 
@@ -313,7 +428,7 @@ def render_fps(scene, g, pp, background, delta_scale, passes=8):
     return res
 
 
-def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=False, with_densify=False):
+def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=False, with_densify=False, prewarm_allocator=True):
     """One more reading of the metric on a fresh model: `path` fused | autograd on workload `cfg`, `steps` timed steps after
     `warmup`, with the step-level roofline on the instances the steps process and, beside it, on the reference's count (both
     sampled on eight cameras in exact mode).
@@ -395,8 +510,9 @@ def side_leg(cfg, dev, path, steps, warmup, sync_mode="async", keep_all_tiles=Fa
             # round itself.  One allocation of that size, freed again, leaves the cache what round two would find.
             model_bytes = sum(p.numel() * p.element_size() for grp in g.optimizer.param_groups for p in grp["params"]
                               if p.dim() and p.shape[0] == p_start)
-            prewarm = int(3.2 * model_bytes)
-            torch.empty(prewarm, dtype=torch.uint8, device=dev)
+            prewarm = int(3.2 * model_bytes) if prewarm_allocator else 0
+            if prewarm:
+                torch.empty(prewarm, dtype=torch.uint8, device=dev)
         trainer.drain()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -482,6 +598,7 @@ def parse_args(argv=None):
                     help="skip via_render_api and other_configs (profiling runs: their kernels would mix into the per-kernel averages)")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state leg (SURVEY 8d: >= 200)")
     ap.add_argument("--steady-warmup", type=int, default=50, help="warm-up of the steady-state leg (SURVEY 8d: 50)")
+    ap.add_argument("--explain", action="store_true", help="print what every key of the JSON line means, and exit")
     ap.add_argument("--path", default="fused", choices=["fused", "autograd", "autograd-per-op"],
                     help="fused: explicit launch sequence (fused_step.py); autograd: render() + loss.backward(), the way the "
                          "reference's own loop drives the modules (render() is one autograd node, fused_autograd.py); "
@@ -491,6 +608,10 @@ def parse_args(argv=None):
 
 def main():
     a = parse_args()
+    if a.explain:
+        for k, v in EXPLAIN.items():
+            print(f"{k}:\n    {v}\n")
+        return
     # N ranks wanted and no launcher started us: become the launcher -- before anything touches the GPU (launch.py).
     # MOM_BENCH_SPAWN=1 forces that route with one rank too (the only way to exercise it on a one-GPU box).
     launch = importlib.import_module("iclr2025_3d-mom_amd.launch")
@@ -729,10 +850,21 @@ def main():
                 out["other_configs"] = {k: side_leg(CONFIGS[k], dev, "fused", 20, 5) for k in ("c1", "c3")}
                 # BASELINE configs[4]: "densify/prune every 100 iters" -- the round at iteration 5100 is inside the window
                 out["other_configs"]["c5"] = side_leg(CONFIGS["c5"], dev, "fused", 121, 10, with_densify=True)
+                # ... and the same leg as a process's FIRST round finds the allocator (no prewarm): the boundary then includes
+                # whatever the driver takes to hand out ~3 GB of fresh memory on this box
+                out["other_configs"]["c5_cold_allocator"] = side_leg(CONFIGS["c5"], dev, "fused", 121, 10, with_densify=True,
+                                                                     prewarm_allocator=False)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        full = json.dumps(out)
+        print("BENCH_FULL " + full, file=sys.stderr)
+        if os.environ.get("MOM_BENCH_FULL"):
+            with open(os.environ["MOM_BENCH_FULL"], "w") as fh:
+                fh.write(full + "\n")
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        assert len(line) < 4096, f"the bench line grew to {len(line)} bytes: the driver's tail would cut it"
+        os.write(json_fd, (line + "\n").encode())
     if world > 1 or force_dist:
         dist.destroy_process_group()
 

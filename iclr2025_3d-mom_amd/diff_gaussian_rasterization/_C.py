@@ -105,7 +105,13 @@ def wait_count(nr_host, ev=None, spin_s=float(__import__("os").environ.get("MOM_
         ev.synchronize()
     else:
         torch.cuda.current_stream().synchronize()
-    return int(nr_host[0])
+    v = int(nr_host[0])
+    if v == COUNT_PENDING:
+        # the stream has drained and nobody wrote the word: the geometry stage never ran (a launch failed after its arguments were
+        # accepted).  Sizing the binning buffer from the sentinel (-1) would follow; fail here instead.
+        raise N.MomError("the geometry stage finished without writing this frame's instance count (the word still holds "
+                         "COUNT_PENDING): a launch of the stage failed")
+    return v
 
 
 def overflow_flag(device):
