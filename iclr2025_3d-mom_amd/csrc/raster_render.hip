@@ -704,10 +704,12 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     drain();
 }
 
-// the row-list experiment of round 5 (-DMOM_BWD_ROWS=1 / -DMOM_FWD_ROWS=1 through tools/variants.sh): measured, not shipped
-#if defined(MOM_BWD_ROWS) || defined(MOM_FWD_ROWS)
-#include "raster_render_rows.h"
-#endif
+// A launch over no tiles (a tile-row shard whose rows are empty) still owes the caller the frame's status word: whoever polls
+// MomRasterArgs.status_post for this serial number would otherwise spin until its timeout.
+__global__ void status_post_kernel(const uint32_t* __restrict__ order_hdr, unsigned long long* status_post, uint32_t status_serial)
+{
+    __hip_atomic_store(status_post, ((unsigned long long)status_serial << 32) | order_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 }  // namespace
 
@@ -720,15 +722,12 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     int ry0, ry1;
     mom_tile_rows(a, gy, &ry0, &ry1);
     const int nt = gx * (ry1 - ry0);
-    if (nt == 0) return MOM_OK;
+    if (nt == 0) {
+        if (a->status_post) hipLaunchKernelGGL(status_post_kernel, dim3(1), dim3(1), 0, s, im.hdr, a->status_post, a->status_serial);
+        return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+    }
     L1Epilogue l1 = {a->l1_target, a->l1_grad, a->l1_sums, 1.0f / (3.0f * (float)a->W * (float)a->H), a->l1_partials};
     if (!l1.grad || (!l1.sums && !l1.partials)) l1.target = nullptr;
-#if defined(MOM_FWD_ROWS) && MOM_FWD_ROWS
-    hipLaunchKernelGGL(render_fwd_rows_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
-                       g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
-                       out_depth, cap, l1, sort_small ? b.keys : nullptr, im.tile_cursor, a->status_post, a->status_serial);
-    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
-#endif
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,
                        out_depth, cap, l1, sort_small ? b.keys : nullptr, im.tile_cursor, a->status_post, a->status_serial);
@@ -746,15 +745,6 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
     mom_tile_rows(a, gy, &ry0, &ry1);
     const int nt = gx * (ry1 - ry0);
     if (nt == 0) return MOM_OK;
-#if defined(MOM_BWD_ROWS) && MOM_BWD_ROWS
-    if (dL_ddepth)
-        hipLaunchKernelGGL(render_bwd_rows_kernel<true>, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
-                           g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
-    else
-        hipLaunchKernelGGL(render_bwd_rows_kernel<false>, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
-                           g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
-    return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
-#endif
     if (dL_ddepth)
         hipLaunchKernelGGL(render_bwd_kernel<true>, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                            g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);

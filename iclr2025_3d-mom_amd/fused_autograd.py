@@ -281,6 +281,8 @@ class FusedRenderFunction(torch.autograd.Function):
                 *field):
         st = _forward(pc, cam, bg, delta_scale, scaling_modifier, debug)
         ctx.st, ctx.pc = st, pc
+        dev = st.color.device
+        ops._render_pending[dev] = ops._render_pending.get(dev, 0) + 1       # (ops.PlaneRegFunction.backward: who joins its kernel)
         ctx.mark_non_differentiable(st.radii)
         return st.color, st.depth, st.radii
 
@@ -291,6 +293,8 @@ class FusedRenderFunction(torch.autograd.Function):
             raise RuntimeError("render(): a second backward through the same call -- its buffers were released after the first "
                                "(render again, or set pipe.per_op_autograd = True for retain_graph use)")
         ctx.st = None                                  # the call's buffers go back to the allocator after this backward
+        dev = st.color.device
+        ops._render_pending[dev] = max(0, ops._render_pending.get(dev, 0) - 1)
         pc = ctx.pc
         params = (pc._xyz, pc._features_dc, pc._features_rest, pc._scaling, pc._rotation, pc._opacity, *st.planes, *st.mlp)
         needs = ctx.needs_input_grad[7:]

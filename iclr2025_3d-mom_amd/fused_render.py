@@ -145,7 +145,15 @@ class FusedRender:
                              "set_sync_mode('exact')")
         wait_for_count = RC._state["mode"] == "exact" or self.cap == 0
         if wait_for_count:
+            if getattr(self, "_unwaited", False):
+                # frames whose count nobody waited for (async mode) may still be queued: their geometry stage would overwrite the
+                # sentinel below with THEIR count, and this frame's binning would be sized from it.  Once, on the switch to a
+                # waiting frame: let the stream drain.
+                torch.cuda.current_stream(dev).synchronize()
+                self._unwaited = False
             self.nr_host[0] = RC.COUNT_PENDING       # (after prev_R was read: the geometry stage overwrites it with this frame's count)
+        else:
+            self._unwaited = True
         N.check(lib.mom_raster_forward_geometry(C.byref(a), self.geom.data_ptr(), self.img.data_ptr(), radii.data_ptr(),
                                                 self.nr_dev.data_ptr(), self.nr_host.data_ptr(), s), "raster_geometry")
         if wait_for_count:

@@ -89,6 +89,7 @@ class HexPlaneFunction(torch.autograd.Function):
     def backward(ctx, dfeat):
         xyz_c, aabb, *planes = ctx.saved_tensors
         n_levels = ctx.n_levels
+        wait_reg_pending_all()         # (AccumulateGrad adds what this returns to plane gradients the second stream may be writing)
         lv = [list(planes[6 * l:6 * l + 6]) for l in range(n_levels)]
         grads = [[torch.zeros_like(p) for p in level] for level in lv]   # preserves the channel-last strides
         d, keep = _hexplane_desc(lv, aabb, grads, aabb_host=ctx.aabb_host)
@@ -466,6 +467,22 @@ def wait_reg_pending(device):
         stream_wait_mark(N.current_stream(), MARK_REG)
 
 
+def wait_reg_pending_all():
+    """The same for every device that has such a kernel in flight: what FusedAdam.step() / zero_grad() and the per-op HexPlane
+    backward call before they read or write plane gradients.  The autograd engine knows nothing of the raw second stream, so every
+    consumer of the plane gradients that is not render()'s own backward joins here (the dict is empty unless API_OVERLAP is on)."""
+    if _reg_pending:
+        for dev in list(_reg_pending):
+            with torch.cuda.device(dev):
+                wait_reg_pending(dev)
+
+
+# device -> number of fused render() nodes whose backward has not run yet.  The regulariser's gradient kernel may stay un-joined on
+# the second stream only while such a node is still to come (its backward joins before it touches the plane gradients); with none
+# pending -- the regulariser node runs last, the loss is regulariser-only, render() took the per-op path -- it joins at once.
+_render_pending = {}
+
+
 # --------------------------------------------------------------------------- plane regularisers
 def direct_grads_ok(params, needs):
     """May a backward hand these parameters their gradients itself (p.grad = ...) instead of returning them to the engine?  Only
@@ -580,8 +597,11 @@ class PlaneRegFunction(torch.autograd.Function):
             stream_wait_stream(side, cur)              # the upstream weight, and the clearing of the buffer above
             N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), side), "mom_plane_regulation")
             up.record_stream(side_t)                   # (the engine frees it when this node returns; the second stream still reads it)
-            stream_mark(MARK_REG, side)
-            _reg_pending[dev] = True
+            if _render_pending.get(dev, 0) > 0:
+                stream_mark(MARK_REG, side)
+                _reg_pending[dev] = True
+            else:
+                stream_wait_stream(cur, side)          # nobody downstream is known to join: the caller's stream does, now
         else:
             N.check(N.lib().mom_plane_regulation_grad(arr, len(planes), val.data_ptr(), up.data_ptr(), N.current_stream()),
                     "mom_plane_regulation")
@@ -674,6 +694,7 @@ class FusedAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=True):
         """torch.optim.Optimizer.zero_grad without its dynamo guard, foreach grouping and profiler range (30 us per call on the
         API path's host, which sets the pace there): the same effect for dense gradients."""
+        wait_reg_pending_all()         # a regulariser gradient kernel on the second stream may still be adding into what is dropped here
         for group in self.param_groups:
             for p in group["params"]:
                 g = p.grad
@@ -775,13 +796,18 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def ensure_state(self, params):
         """Create the Adam state of `params` now, on the current stream (torch.optim.Adam creates it in the first step() that sees
-        a gradient; a step_partial() on a second stream would otherwise allocate the moments from that stream's pool)."""
+        a gradient; a step_partial() on a second stream would otherwise allocate the moments from that stream's pool).
+        Returns True if any state was created: its zero fill is queued on the current stream, and a second stream that is to
+        read the moments must first wait for THAT stream, not only for an earlier mark."""
+        created = False
         for p in params:
             st = self.state[p]
             if len(st) == 0:
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                created = True
+        return created
 
     @torch.no_grad()
     def step_partial(self, params, stream=None):
@@ -803,6 +829,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         hint, self.early_hint = self.early_hint, None
+        wait_reg_pending_all()         # the plane gradients this step reads are complete (a regulariser kernel on the second stream)
         joined = None
         if hint is not None and self._early is None:
             # render()'s backward (fused_autograd.py) recorded an event when the appearance parameters' gradients -- SH, scaling,
@@ -815,7 +842,10 @@ class FusedAdam(torch.optim.Optimizer):
             mine = {id(p) for group in self.param_groups for p in group["params"]}
             if all(id(p) in mine and p.grad is g and g._version == v for p, g, v in entries):
                 ps = [p for p, _, _ in entries]
-                self.ensure_state(ps)
+                if self.ensure_state(ps):
+                    # first step (or state made lazily after densify): the moments' zero fill sits on the caller's stream BEHIND the
+                    # whole backward, the mark half-way through it -- the second stream waits for the fill itself this once
+                    stream_wait_stream(side, N.current_stream())
                 stream_wait_mark(side, slot)
                 self.step_partial(ps, stream=side)
                 joined = side

@@ -127,15 +127,17 @@ class HexPlaneField(nn.Module):
         order = ops.BACKEND.morton_order(pts, stream=side, keepalive=keep)
         porders = ops.BACKEND.hexplane_orders(pts, [list(g) for g in self.grids], self.aabb, aabb_host=self.aabb_host(), stream=side,
                                               keepalive=keep)
-        ops.stream_mark(ops.MARK_ORDERS, side)
-        self._pending = (self._order_key(pts), order, porders, keep)
+        # no process-wide mark slot: several fields (or fused steps) of one device prefetch on different second streams, and a
+        # shared slot re-recorded by another field would make this one wait for the wrong stream -- the stream handle itself is kept,
+        # and whoever takes or drops the result waits for that stream's tail (once per REORDER_EVERY calls)
+        self._pending = (self._order_key(pts), order, porders, keep, side)
 
     def _drop_pending(self):
         """Forget a prefetched refresh that no longer fits (the model was restructured under it).  Its buffers go back to the
         allocator, which may hand them out again for work on the caller's stream: that stream is first put behind the second
         stream's kernels, which may still be writing them."""
         if getattr(self, "_pending", None) is not None:
-            ops.stream_wait_mark(ops.N.current_stream(), ops.MARK_ORDERS)
+            ops.stream_wait_stream(ops.N.current_stream(), self._pending[4])
             self._pending = None
 
     def _processing_order(self, pts):
@@ -151,8 +153,8 @@ class HexPlaneField(nn.Module):
             self._order_age = 0
         elif self._order_age >= self.REORDER_EVERY:
             if pending is not None and pending[0] == self._order_key(pts):
-                # the prefetched orders: this stream waits for the second stream's mark (long past, normally)
-                ops.stream_wait_mark(ops.N.current_stream(), ops.MARK_ORDERS)
+                # the prefetched orders: this stream waits for the tail of the stream that sorted them (long past, normally)
+                ops.stream_wait_stream(ops.N.current_stream(), pending[4])
                 self._order, self._porders, self._porders_key = pending[1], pending[2], tuple(self.aabb_host())
                 self._porders_swapped = True
                 self._pending = None
