@@ -13,8 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MOM4D_LIB") or os.path.join(_HERE, "lib", "libmom4d.so")
 _lib = None
 
-MOM_OK, MOM_EINVAL, MOM_ELAUNCH, MOM_ECAPACITY = 0, -1, -2, -3
-_ERR = {MOM_EINVAL: "invalid argument", MOM_ELAUNCH: "HIP launch/runtime failure", MOM_ECAPACITY: "scratch too small"}
+MOM_OK, MOM_EINVAL, MOM_ELAUNCH, MOM_ECAPACITY, MOM_EUNAVAILABLE = 0, -1, -2, -3, -4
+_ERR = {MOM_EINVAL: "invalid argument", MOM_ELAUNCH: "HIP launch/runtime failure", MOM_ECAPACITY: "scratch too small",
+        MOM_EUNAVAILABLE: "run-time dependency missing (librccl)"}
+COMM_F32, COMM_I32, COMM_SUM, COMM_MAX = 0, 1, 0, 1
 
 
 class MomError(RuntimeError):
@@ -138,6 +140,20 @@ def _sig(lib):
     lib.mom_stream_mark.argtypes = [i32, vp]
     lib.mom_stream_wait_mark.argtypes = [vp, i32]
     lib.mom_zero_async.argtypes = [vp, sz, vp]
+    lib.mom_comm_available.argtypes = []
+    lib.mom_comm_last_error.restype = C.c_char_p
+    lib.mom_comm_last_error.argtypes = []
+    lib.mom_comm_unique_id.argtypes = [vp]
+    lib.mom_comm_create.argtypes = [C.POINTER(vp), vp, i32, i32]
+    lib.mom_comm_destroy.argtypes = [vp]
+    lib.mom_comm_abort.argtypes = [vp]
+    lib.mom_comm_world.argtypes = [vp]
+    lib.mom_comm_rank.argtypes = [vp]
+    lib.mom_comm_group_start.argtypes = []
+    lib.mom_comm_group_end.argtypes = []
+    lib.mom_comm_all_reduce.argtypes = [vp, vp, sz, i32, i32, vp]
+    lib.mom_comm_all_gather.argtypes = [vp, vp, sz, i32, vp]
+    lib.mom_comm_reduce_scatter.argtypes = [vp, vp, sz, i32, i32, vp]
     lib.mom_raster_forward_geometry.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, vp, vp, vp]
     lib.mom_raster_forward_render.argtypes = [C.POINTER(MomRasterArgs), vp, vp, sz, vp, vp, vp, vp, vp]
     lib.mom_raster_backward.argtypes = [C.POINTER(MomRasterArgs), vp, vp, vp, sz, vp, vp, vp, C.POINTER(MomRasterGrads), vp]
@@ -220,6 +236,9 @@ EXPORTS = [
     "mom_l1_loss_acc", "mom_plane_regulation_acc", "mom_plane_regulation_grad",
     "mom_deform_field_supported", "mom_deform_field_scratch_bytes", "mom_deform_field_forward",
     "mom_stream_wait_stream", "mom_stream_mark", "mom_stream_wait_mark", "mom_zero_async",
+    "mom_comm_available", "mom_comm_last_error", "mom_comm_unique_id", "mom_comm_create", "mom_comm_destroy", "mom_comm_abort",
+    "mom_comm_world", "mom_comm_rank", "mom_comm_group_start", "mom_comm_group_end", "mom_comm_all_reduce", "mom_comm_all_gather",
+    "mom_comm_reduce_scatter",
 ]
 
 

@@ -152,6 +152,30 @@ __device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* 
     return n;
 }
 
+// -DFWD_STAMPS (tools/variants.sh; tools/probe/fwd_stamps.py reads them): where a workgroup of render_fwd / render_bwd spends its life.
+// Thread 0 of every workgroup leaves s_memtime at its phase boundaries (words 0-7), s_memrealtime at entry and exit (8, 9: one clock
+// for the chip), XCC_ID | HW_ID (10) and tile | list length (11).  Compiled out of the shipped library.
+#ifdef FWD_STAMPS
+constexpr int kStampWords = 12, kStampGroups = 16384;
+__device__ unsigned long long g_fwd_stamps[kStampGroups * kStampWords];
+__device__ unsigned long long g_bwd_stamps[kStampGroups * kStampWords];
+#define FWD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) g_fwd_stamps[blockIdx.x * kStampWords + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BWD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) g_bwd_stamps[blockIdx.x * kStampWords + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_ID(arr) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) { \
+        arr[blockIdx.x * kStampWords + 8] = __builtin_amdgcn_s_memrealtime(); \
+        arr[blockIdx.x * kStampWords + 10] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | __builtin_amdgcn_s_getreg(63492); } } while (0)
+#define STAMP_LIST(arr, tile, n) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) arr[blockIdx.x * kStampWords + 11] = ((unsigned long long)(uint32_t)(tile) << 32) | (uint32_t)(n); } while (0)
+#define STAMP_EXIT(arr) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) arr[blockIdx.x * kStampWords + 9] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define FWD_STAMP(k) do { } while (0)
+#define BWD_STAMP(k) do { } while (0)
+#define STAMP_ID(arr) do { } while (0)
+#define STAMP_LIST(arr, tile, n) do { } while (0)
+#define STAMP_EXIT(arr) do { } while (0)
+#define STAMP_WAIT() do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FWD_WAVES, MOM_FWD_WAVES)))
 render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read AND, for the tiles sorted here, written: no restrict */, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, float* __restrict__ final_T,
@@ -162,6 +186,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
     __shared__ uint16_t s_lists[4][kRound];
+    FWD_STAMP(0);
+    STAMP_ID(g_fwd_stamps);
     // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
     // (the order was made for the rows of the forward's geometry stage, kept in header words 3 and 4; a launch over other rows -- the
     // backward of a tile-row shard that rendered a halo -- falls back to the positional mapping)
@@ -179,6 +205,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     if (range.y > capacity) range.y = capacity;
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
+    STAMP_WAIT();
+    FWD_STAMP(1);                                             // the tile's range is here
+    STAMP_LIST(g_fwd_stamps, tile, toDo);
     const int rounds = (toDo + kRound - 1) / kRound;
     const int list_len = toDo;
     int walked_rounds = rounds;                               // rounds of the list this workgroup walks before every pixel is done
@@ -202,6 +231,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
         __syncthreads();
     }
 
+    FWD_STAMP(2);                                             // sorted (or nothing to sort)
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
@@ -227,6 +257,8 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     };
     fetch(0);
 #endif
+    STAMP_WAIT();
+    FWD_STAMP(3);                                             // round 0's records are in registers
     for (int i = 0; i < rounds; i++, toDo -= kRound) {
         if (__syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256) { walked_rounds = i; break; }
 #if MOM_FWD_PREFETCH
@@ -307,6 +339,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     // "entries processed before block exit" (SURVEY 8d's Q = 256 x the sum of this over the tiles): the list is walked in rounds of
     // 256 like the reference's (forward.cu:305-327), and a round is entered unless every pixel of the tile is done.  One plain
     // store per tile into the scatter's cursor array, which nothing reads after the binning.
+    FWD_STAMP(4);                                             // wave 0 has left the loop
     if (threadIdx.x == 0) tile_walked[tile] = (uint32_t)min(list_len, walked_rounds * kRound);
     // MomRasterArgs.status_post: the frame's status bits (header word 1, final since the binning) go to a pinned host word with the
     // caller's serial number -- one store by one thread of the launch instead of a copy kernel and a marker behind every frame
@@ -325,6 +358,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
         out_color[2 * HW + pix] = C2;
         out_depth[pix] = D;
     }
+    FWD_STAMP(5);                                             // the pixel's stores are issued
     if (l1.target) {
         // L1 loss against a target image, its sums and its gradient, while the pixel is still in registers: what
         // mom_l1_loss_acc computes from the stored image (same expressions; the sums' order of addition differs)
@@ -359,6 +393,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
             }
         }
     }
+    FWD_STAMP(6);                                             // wave 0 at the end of the L1 epilogue (it waited for the other waves' loops there)
+    STAMP_WAIT();
+    FWD_STAMP(7);                                             // ... with its stores acknowledged
+    STAMP_EXIT(g_fwd_stamps);
 }
 
 // ---- the backward's reduction, priced by instruction class -----------------------------------------------------------------
@@ -478,6 +516,8 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     __shared__ uint32_t s_id[kRoundB];
     __shared__ uint8_t s_mask[kRoundB];
     __shared__ uint16_t s_lists[4][kRoundB];
+    BWD_STAMP(0);
+    STAMP_ID(g_bwd_stamps);
     // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
     // (the order was made for the rows of the forward's geometry stage, kept in header words 3 and 4; a launch over other rows -- the
     // backward of a tile-row shard that rendered a halo -- falls back to the positional mapping)
@@ -575,6 +615,8 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     }
     const int rounds = (toDo + kRoundB - 1) / kRoundB;
 #endif
+    BWD_STAMP(1);                                             // pixel state loaded, the list cut at the tile's last contributor
+    STAMP_LIST(g_bwd_stamps, tile, toDo);
 
     // (Asking for the next round's records a round ahead, as render_fwd does, does not pay here: 26 more live registers spill at
     // five waves per SIMD -- 201.8 against 195.3 us; with 256-splat rounds 211; the indices alone 196.6.)
@@ -701,7 +743,12 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
           }
         }
     }
+    BWD_STAMP(2);                                             // wave 0 has left the loop
     drain();
+    BWD_STAMP(3);
+    STAMP_WAIT();
+    BWD_STAMP(4);                                             // its atomics acknowledged
+    STAMP_EXIT(g_bwd_stamps);
 }
 
 // A launch over no tiles (a tile-row shard whose rows are empty) still owes the caller the frame's status word: whoever polls
@@ -753,6 +800,19 @@ int mom_launch_render_bwd(const MomRasterArgs* a, const GeomView& g, const BinVi
                            g.rec, a->background, im.final_T, im.n_contrib, dL_dpix, dL_ddepth, g.gacc, cap);
     return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
 }
+
+#ifdef FWD_STAMPS
+extern "C" int mom_debug_fwd_stamps(unsigned long long* host_dst, int groups)
+{
+    if (groups > kStampGroups) groups = kStampGroups;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_fwd_stamps), (size_t)groups * kStampWords * 8) == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+extern "C" int mom_debug_bwd_stamps(unsigned long long* host_dst, int groups)
+{
+    if (groups > kStampGroups) groups = kStampGroups;
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_bwd_stamps), (size_t)groups * kStampWords * 8) == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+#endif
 
 // wave_sum self test: out[w] = sum of in[64*w .. 64*w+63]
 namespace {

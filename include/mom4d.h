@@ -36,6 +36,7 @@ extern "C" {
 #define MOM_EINVAL (-1)   /* bad argument (shape, null pointer, unsupported channel count) */
 #define MOM_ELAUNCH (-2)  /* a HIP launch / runtime call failed (hipGetLastError) */
 #define MOM_ECAPACITY (-3)/* scratch buffer too small */
+#define MOM_EUNAVAILABLE (-4) /* an optional run-time dependency is missing (librccl for mom_comm_*): mom_comm_last_error() says which */
 
 #define MOM_TILE 16       /* config.h:14-16 BLOCK_X == BLOCK_Y == 16 */
 
@@ -482,6 +483,40 @@ int mom_stream_mark(int slot, mom_stream_t stream);
 int mom_stream_wait_mark(mom_stream_t stream, int slot);
 /* bytes of zeros at ptr, stream-ordered (the gradient buckets a step clears on its second stream) */
 int mom_zero_async(void* ptr, size_t bytes, mom_stream_t stream);
+
+/* ---- collectives of a multi-GPU step, over librccl (RCCL on xGMI), one process per GPU.
+ * No counterpart in the reference, which is single-GPU: its batch axis (train_4DGS.py:172-229, `batch_size` cameras rendered one after
+ * the other, loss averaged) is what the camera-batch shard spreads over ranks, and these are the exchanges of that shard and of the
+ * tile-row shard.  They exist as C entry points because a torch.distributed call costs the rank's host 40-50 us
+ * and the host paces a rank; here a collective is one ncclXxx call on a raw stream handle (~2 us), ordered against the compute
+ * streams with mom_stream_mark / mom_stream_wait_mark.
+ *   mom_comm_available     1 if librccl could be resolved (dlopen at first use; a process that has imported torch gets torch's copy)
+ *   mom_comm_unique_id     rank 0 makes the 128-byte id and hands it to the other ranks through the launcher's own rendezvous
+ *   mom_comm_create        ncclCommInitRank on the calling thread's CURRENT device; collective over all `world` ranks
+ *   mom_comm_all_reduce    in place over `count` elements
+ *   mom_comm_all_gather    in place: buf holds world x count_per_rank elements, this rank's slab at rank x count_per_rank going in
+ *   mom_comm_reduce_scatter in place: buf holds world x count_per_rank elements; this rank's reduced block lands at rank x count_per_rank,
+ *                          the rest of buf is left in an unspecified state
+ *   mom_comm_group_start / _end   ncclGroupStart / ncclGroupEnd: the calls in between are submitted as one launch
+ * dtype: MOM_COMM_F32 | MOM_COMM_I32 (4-byte elements); op: MOM_COMM_SUM | MOM_COMM_MAX.  Every rank must issue the same sequence. */
+typedef struct MomComm MomComm;
+#define MOM_COMM_F32 0
+#define MOM_COMM_I32 1
+#define MOM_COMM_SUM 0
+#define MOM_COMM_MAX 1
+int mom_comm_available(void);
+const char* mom_comm_last_error(void);
+int mom_comm_unique_id(void* id128);
+int mom_comm_create(MomComm** out, const void* id128, int world, int rank);
+int mom_comm_destroy(MomComm* comm);
+int mom_comm_abort(MomComm* comm);
+int mom_comm_world(const MomComm* comm);
+int mom_comm_rank(const MomComm* comm);
+int mom_comm_group_start(void);
+int mom_comm_group_end(void);
+int mom_comm_all_reduce(MomComm* comm, void* buf, size_t count, int dtype, int op, mom_stream_t stream);
+int mom_comm_all_gather(MomComm* comm, void* buf, size_t count_per_rank, int dtype, mom_stream_t stream);
+int mom_comm_reduce_scatter(MomComm* comm, void* buf, size_t count_per_rank, int dtype, int op, mom_stream_t stream);
 
 /* Self test of the wave64 DPP reduction used by the render backward:
  * out[w] = sum(in[64w .. 64w+63]). */

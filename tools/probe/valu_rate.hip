@@ -87,6 +87,82 @@ __global__ void __launch_bounds__(256) k_rate(int iters, unsigned long long* cyc
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// Packed fp32 (two floats per lane in a 64-bit register pair): what does one v_pk_* wave64 instruction cost beside the plain forms?
+// (No MFMAs in the compositing kernels, so the packed-fp32 / MFMA observation of deform_field.hip does not apply there.)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define PBODY8(INS) asm volatile(INS(0) INS(1) INS(2) INS(3) INS(4) INS(5) INS(6) INS(7) \
+                                : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]) \
+                                : "v"(c), "v"(c2), "s"(sc))
+#define PBODY64(INS) PBODY8(INS); PBODY8(INS); PBODY8(INS); PBODY8(INS); PBODY8(INS); PBODY8(INS); PBODY8(INS); PBODY8(INS)
+#define P_FMA(n) "v_pk_fma_f32 %" #n ", %" #n ", %8, %8\n"
+#define P_FMA3(n) "v_pk_fma_f32 %" #n ", %8, %9, %" #n "\n"
+#define P_MUL(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
+#define P_ADD(n) "v_pk_add_f32 %" #n ", %" #n ", %8\n"
+#define P_MULB(n) "v_pk_mul_f32 %" #n ", %" #n ", %8 op_sel_hi:[1,0]\n"      // second operand's low half broadcast to both
+#define P_FMAS(n) "v_pk_fma_f32 %" #n ", %" #n ", %10, %10\n"               // SGPR-pair operand
+#define P_MOV(n) "v_pk_mov_b32 %" #n ", %8, %8\n"
+template <int KIND>
+__global__ void __launch_bounds__(256) k_rate_pk(int iters, unsigned long long* cyc, float* out)
+{
+    v2f x[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x[j] = v2f{1.0f + 1e-3f * (threadIdx.x + j), 1.0f - 1e-3f * j};
+    const v2f c = {1.0001f, 0.9999f}, c2 = {0.999f + 1e-6f * threadIdx.x, 1.001f};
+    const unsigned long long sc = 0x3f8003473f800347ull;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) {
+        if (KIND == 0) { PBODY64(P_FMA); }
+        if (KIND == 1) { PBODY64(P_FMA3); }
+        if (KIND == 2) { PBODY64(P_MUL); }
+        if (KIND == 3) { PBODY64(P_ADD); }
+        if (KIND == 4) { PBODY64(P_MULB); }
+        if (KIND == 5) { PBODY64(P_FMAS); }
+        if (KIND == 6) { PBODY64(P_MOV); }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r += x[j].x + x[j].y;
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+// A mix as the compositing loops have it: of every 8 instructions, `NPK` packed and the rest plain v_fma_f32 -- is a packed
+// instruction's price the same inside a stream of plain ones?
+template <int KIND>
+__global__ void __launch_bounds__(256) k_rate_mix(int iters, unsigned long long* cyc, float* out)
+{
+    v2f x[4];
+    float y[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { x[j] = v2f{1.0f + 1e-3f * (threadIdx.x + j), 1.0f - 1e-3f * j}; y[j] = 1.0f + 1e-4f * j; }
+    const v2f c = {1.0001f, 0.9999f};
+    const float d = 1.0001f;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (KIND == 0)      // 4 packed fma + 4 plain fma
+                asm volatile("v_pk_fma_f32 %0, %0, %8, %8\nv_fma_f32 %4, %4, %9, %9\nv_pk_fma_f32 %1, %1, %8, %8\nv_fma_f32 %5, %5, %9, %9\n"
+                             "v_pk_fma_f32 %2, %2, %8, %8\nv_fma_f32 %6, %6, %9, %9\nv_pk_fma_f32 %3, %3, %8, %8\nv_fma_f32 %7, %7, %9, %9\n"
+                             : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : "v"(c), "v"(d));
+            else                // 8 plain fma on the same 12 registers (the unpacked equivalent of the 4 packed: 8 + 4 = 12 plain)
+                asm volatile("v_fma_f32 %0, %0, %8, %8\nv_fma_f32 %4, %4, %8, %8\nv_fma_f32 %1, %1, %8, %8\nv_fma_f32 %5, %5, %8, %8\n"
+                             "v_fma_f32 %2, %2, %8, %8\nv_fma_f32 %6, %6, %8, %8\nv_fma_f32 %3, %3, %8, %8\nv_fma_f32 %7, %7, %8, %8\n"
+                             : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(x[0].x), "+v"(x[1].x), "+v"(x[2].x), "+v"(x[3].x) : "v"(d));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) r += x[j].x + x[j].y + y[j];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 // LDS broadcast reads (every lane the same address): the compositing loops read their splat records this way
 template <int WIDTH>
 __global__ void __launch_bounds__(256) k_lds(int iters, unsigned long long* cyc, float* out)
@@ -167,6 +243,16 @@ int main()
     RUNK("v_sub_f32", 20);
     RUNK("v_mul_f32 literal", 21);
     RUNK("v_and_b32", 22);
+#define RUNP(name, K) run(name, [&](int blocks, int it) { hipLaunchKernelGGL(k_rate_pk<K>, dim3(blocks), dim3(256), 0, 0, it, cyc, out); }, cyc, iters)
+    RUNP("v_pk_fma_f32 (x,c,c)", 0);
+    RUNP("v_pk_fma_f32 3 distinct", 1);
+    RUNP("v_pk_mul_f32", 2);
+    RUNP("v_pk_add_f32", 3);
+    RUNP("v_pk_mul_f32 op_sel_hi bcast", 4);
+    RUNP("v_pk_fma_f32 sgpr pair", 5);
+    RUNP("v_pk_mov_b32", 6);
+    run("mix 4 pk_fma + 4 fma (per 8)", [&](int blocks, int it) { hipLaunchKernelGGL(k_rate_mix<0>, dim3(blocks), dim3(256), 0, 0, it, cyc, out); }, cyc, iters);
+    run("8 plain fma (per 8)", [&](int blocks, int it) { hipLaunchKernelGGL(k_rate_mix<1>, dim3(blocks), dim3(256), 0, 0, it, cyc, out); }, cyc, iters);
     run("ds_read_b128 broadcast", [&](int blocks, int it) { hipLaunchKernelGGL(k_lds<16>, dim3(blocks), dim3(256), 0, 0, it, cyc, out); }, cyc, iters);
     run("ds_read_b32 broadcast", [&](int blocks, int it) { hipLaunchKernelGGL(k_lds<4>, dim3(blocks), dim3(256), 0, 0, it, cyc, out); }, cyc, iters);
     return 0;
