@@ -587,6 +587,9 @@ def parse_args(argv=None):
     ap.add_argument("--shard", default="camera", choices=["camera", "tile-row"],
                     help="N > 1: camera = one camera per GPU per step (weak scaling, the reference's batch axis); "
                          "tile-row = one camera per step split over the GPUs by rows of 16-pixel tiles (strong scaling)")
+    ap.add_argument("--shard-adam", action="store_true",
+                    help="camera-batch shard: reduce-scatter the appearance gradients, run Adam on this rank's 1/N slice, all-gather the "
+                         "updated parameters (SURVEY 8e's second design: same bytes, 1/N of the Adam pass -- what pays at 4 M Gaussians)")
     ap.add_argument("--with-densify", action="store_true",
                     help="walk consecutive iteration numbers so that the trainer's own densification (every 100 iterations) "
                          "fires inside the timed region; not the headline configuration (SURVEY 8d excludes it)")
@@ -655,7 +658,7 @@ def main():
     ranks_seen = 1
     if world > 1 or force_dist:
         par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
-        par.attach(trainer, rank, world, mode=a.shard)
+        par.attach(trainer, rank, world, mode=a.shard, shard_adam=a.shard_adam or None)
         one_t = torch.ones(1, device=dev)
         dist.all_reduce(one_t)
         ranks_seen = int(one_t[0])
@@ -791,7 +794,9 @@ def main():
                    "instances_binned_is": "what the default binning keeps: instances that can reach alpha >= 1/255 in their tile",
                    "pairs_Q": {"processed": headline_q[False], "reference_lists": headline_q[True], "what": Q_IS},
                    "sh_degree": 3, "step_path": a.path, "batch_size": 1,
-                   "lambda_dssim": a.lambda_dssim, "parallelism": (f"camera-batch x{world}" if a.shard == "camera" else f"tile-row x{world}") if world > 1 else "single",
+                   "lambda_dssim": a.lambda_dssim, "parallelism": ((f"camera-batch x{world}" + (" sharded-adam" if getattr(trainer.dist, "shard_adam", False) else "")
+                                    if a.shard == "camera" else f"tile-row x{world}")
+                                   + (" rccl-direct" if getattr(trainer.dist, "direct", None) is not None else " torch.distributed")) if (world > 1 or force_dist) else "single",
                    "ranks_seen": ranks_seen, "host_sync": a.sync_mode, "final_loss": float(loss), "densify_in_window": bool(a.with_densify),
                    "gaussians_at_end": int(g.get_xyz.shape[0]), "steps_replayed_after_overflow": int(trainer.replayed),
                    "inputs": "camera matrices and ground-truth images pre-staged in HBM before the timed region"},

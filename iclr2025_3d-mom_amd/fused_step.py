@@ -87,7 +87,8 @@ class FusedStep:
             cap = self._rows_cap = pad + pad // 4 if grew else pad
             st = self._store = {name: e(cap, cols) for name, cols, _ in self._ROW_BUFFERS}
             st["radii"] = torch.zeros(cap + 1, dtype=torch.int32, device=dev)      # + the sticky overflow word behind the P radii
-            st["early"] = e(59 * cap)                                              # + the screen-space gradients behind the 56 P
+            st["early"] = e(59 * cap + 4 * self._world())                          # + the screen-space gradients behind the 56 P (sharded Adam: behind world x chunk)
+            st["pflat"] = None                                                     # sharded Adam: the appearance parameters' flat home (_rehome)
             st["loc"] = (e(cap, 3), e(cap, 4))
             self.geom = torch.empty(self.lib.mom_raster_geom_bytes(cap), dtype=torch.uint8, device=dev)
             self.dh_scratch = torch.empty(self.lib.mom_deform_backward_scratch_bytes(cap), dtype=torch.uint8, device=dev)
@@ -113,10 +114,17 @@ class FusedStep:
         # after the HexPlane backward; made in _deform_grads).
         # (behind the 56 P: the screen-space gradients, 3 P -- the densification statistics' input, summed over a camera-batch
         # shard's ranks in the same all-reduce)
-        self.early_bucket = st["early"][:59 * P]
+        # sharded Adam (DistContext.shard_adam): the 56 P appearance gradients are cut into world chunks of `_chunk` elements for the
+        # reduce-scatter, so the bucket's appearance part is padded to world x chunk and the screen-space gradients sit behind THAT
+        dc = self.dist
+        self._chunk = dc.chunk(56 * P) if (dc is not None and getattr(dc, "shard_adam", False)) else 0
+        app = self._world() * self._chunk if self._chunk else 56 * P
+        self.early_bucket = st["early"][:app + 3 * P]
+        self.app_flat = self.early_bucket[:app]
         self.early = self.early_bucket[:56 * P]
-        self.g2d = self.early_bucket[56 * P:].view(P, 3)
-        cut = [0, 3 * P, 48 * P, 51 * P, 55 * P, 56 * P]
+        self.g2d_flat = self.early_bucket[app:]
+        self.g2d = self.g2d_flat.view(P, 3)
+        self._cut = cut = [0, 3 * P, 48 * P, 51 * P, 55 * P, 56 * P]
         seg = lambda i: self.early[cut[i]:cut[i + 1]]
         self.gdc, self.grest = seg(0).view(P, 1, 3), seg(1).view(P, 15, 3)
         self.gsc, self.grot, self.gop = seg(2).view(P, 3), seg(3).view(P, 4), seg(4).view(P, 1)
@@ -126,6 +134,42 @@ class FusedStep:
     _ROW_BUFFERS = (("feat", 64, False), ("a0", 64, False), ("dfeat", 64, False), ("pts", 3, True), ("sc_d", 3, False),
                     ("rot_d", 4, True), ("sc", 3, True), ("rot", 4, True), ("op", 1, True), ("gcol", 3, False),
                     ("gop_act", 1, False), ("gcov", 6, False), ("gsc_act", 3, False), ("grot_act", 4, False))
+
+    def _world(self):
+        return self.dist.world if self.dist is not None else 1
+
+    _APP_SHAPES = ((1, 3), (15, 3), (3,), (4,), (1,))
+
+    def _app_params(self):
+        g = self.g
+        return [g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity]
+
+    def _rehome(self):
+        """Sharded Adam: the five appearance parameters live in ONE flat buffer laid out like their gradient bucket
+        ([f_dc 3P | f_rest 45P | scaling 3P | rotation 4P | opacity P], padded to world x chunk), so that the all-gather of the
+        updated parameters is in place.  A parameter that is not there (first step, after a densify / prune round replaced it) is
+        copied in and its .data pointed at its slice; the Parameter objects -- and with them the optimizer's state -- stay."""
+        P, st = self.P, self._store
+        need = self._world() * self._chunk
+        flat = st.get("pflat")
+        if flat is None or flat.numel() < need or flat.device != self.early.device:
+            flat = st["pflat"] = torch.empty(56 * self._rows_cap + 4 * self._world(), dtype=torch.float32, device=self.early.device)
+        self.pflat = flat[:need]
+        for p, a, b, shp in zip(self._app_params(), self._cut[:-1], self._cut[1:], self._APP_SHAPES):
+            v = self.pflat[a:b].view((P,) + shp)
+            if p.data_ptr() != v.data_ptr():
+                v.copy_(p.data)
+                p.data = v
+
+    def gather_moments(self):
+        """Before an iteration that reads or restructures the optimizer state: every rank gets the moments of every slice (sharded
+        Adam keeps only its own up to date)."""
+        dc = self.dist
+        if dc is None or not getattr(dc, "shard_adam", False) or self.P <= 0 or not self._chunk:
+            return
+        if self.g._xyz.shape[0] != self.P:
+            return                       # the model was restructured since the last step: its state is whole (the round gathered first)
+        dc.gather_moments(self.g.optimizer, self._app_params(), self._cut, self._chunk)
 
     RING = 64
     OVERLAP_DW = os.environ.get("MOM_OVERLAP_DW", "1") != "0"     # the MLP weight-gradient kernel on a second stream, beside the HexPlane backward
@@ -197,6 +241,9 @@ class FusedStep:
         P = g._xyz.shape[0]
         W, H = int(cam.image_width), int(cam.image_height)
         self._ensure(P, W, H, dev)
+        sharded = bool(self._chunk) and early_adam is not None and self.EARLY_ADAM     # this iteration takes the sharded-Adam path
+        if self._chunk:
+            self._rehome()
         if self._resize_next:                   # after a tile-row re-split, an overflow, or on request (exact_next)
             self.cap, self._resize_next = 0, False
         view, proj, campos, gt = cam.device_tensors(dev)
@@ -450,7 +497,19 @@ class FusedStep:
             d_sc, d_rot = self._loc
             d_sc.copy_(self.gsc)
             d_rot.copy_(self.grot)
-            early_works.append(dc.start(self.early_bucket, "sum"))     # appearance gradients + mean 2-D gradients
+            if sharded:
+                # reduce-scatter of the appearance gradients (this rank keeps the sum of ITS chunk) + the small all-reduce of the
+                # screen-space gradients every rank's statistics need in full: one launch on the direct path
+                with dc.group() as grp:
+                    w_rs = dc.start_reduce_scatter(self.app_flat, self._chunk, "sum")
+                    w_g2 = dc.start(self.g2d_flat, "sum")
+                if grp.work is not None:
+                    dc._pending.append(grp.work)
+                    early_works.append(grp.work)
+                else:
+                    early_works += [w_rs, w_g2]
+            else:
+                early_works.append(dc.start(self.early_bucket, "sum"))     # appearance gradients + mean 2-D gradients
         # ---- deformation backward: pts = xyz + dx(...) so d xyz starts as d pts (already in gxyz); the HexPlane adds its share
         # the MLP's weight-gradient kernel (matrix pipe) runs on a second stream beside the HexPlane backward (vector issue,
         # memory latency); joined below, before anything reads the weight gradients
@@ -513,9 +572,24 @@ class FusedStep:
                                                   None if spo is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
             dc.start_gather([self.gxyz_rows], S)
         if early_cam is not None:
+            app = [g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity]
+            if getattr(dc, "direct", None) is not None and not sharded:
+                # direct RCCL path: a wait is one hipStreamWaitEvent on the second stream's raw handle (no torch stream context: ~10 us)
+                dc.wait_for(early_cam, stream=self.side.cuda_stream)
+                early_adam(app, stream=self.side.cuda_stream)
+                early_cam = None
+        if early_cam is not None:
             with torch.cuda.stream(self.side):          # (torch.distributed's wait() orders the CURRENT torch stream)
                 dc.wait_for(early_cam)
-            early_adam([g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity], stream=self.side.cuda_stream)
+                if sharded:
+                    # this rank's 1/world of Adam, then the all-gather of the UPDATED parameters (in place in their flat home) behind
+                    # it -- begun from inside the second stream's context, so it is ordered behind that stream's Adam launch; the
+                    # caller's DistContext.finish() makes the main stream wait for it before anything reads a parameter
+                    ranges = {id(p_): r for p_, r in zip(app, dc.shard_ranges(self._cut, self._chunk))}
+                    early_adam(app, stream=self.side.cuda_stream, ranges=ranges)
+                    dc.start_gather_flat(self.pflat, self._chunk)
+            if not sharded:
+                early_adam(app, stream=self.side.cuda_stream)
         if self.side is not None:
             ops.stream_wait_stream(s, self.side.cuda_stream)
         if dc is not None and dc.mode == "camera":

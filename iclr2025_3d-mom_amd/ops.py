@@ -715,7 +715,7 @@ class FusedAdam(torch.optim.Optimizer):
             if "step" in st:
                 st["step"] -= float(n)
 
-    def _build_plan(self, live, key):
+    def _build_plan(self, live, key, ranges=None):
         """Validate every (param, state) once and lay the MomAdamTensor arrays out; reused until a parameter or a moment moves
         (densify / prune / reset_opacity replace parameters and state, load_state_dict replaces state).  The gradient pointers
         are NOT part of the plan's identity: under autograd the gradients are fresh tensors every iteration, and a plan keyed on
@@ -730,9 +730,15 @@ class FusedAdam(torch.optim.Optimizer):
             cfg = (b1, b2, group["eps"])
             slot = by_cfg.setdefault(cfg, [])
             t = N.MomAdamTensor()
-            t.param = p.data_ptr()
-            t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
-            t.n = p.numel()
+            # ranges (a rank's share of a sharded step, FusedAdam.step_partial): elements [off, off + n) of the tensor in storage
+            # order -- Adam is element-wise, so a slice of the parameter, its gradient and its moments is a step of its own; an empty
+            # slice stays in the plan with n = 0 (no work) so that the parameter's step counter advances on every rank alike
+            off, cnt = (0, p.numel()) if ranges is None else ranges[id(p)]
+            if ranges is not None and (not p.is_contiguous() or not st["exp_avg"].is_contiguous() or not st["exp_avg_sq"].is_contiguous()):
+                raise N.MomError("FusedAdam: a sharded step needs contiguous parameters and moments")
+            t.param = p.data_ptr() + 4 * off
+            t.exp_avg, t.exp_avg_sq = st["exp_avg"].data_ptr() + 4 * off, st["exp_avg_sq"].data_ptr() + 4 * off
+            t.n = cnt
             entries.append((group, b1, b2, cfg, len(slot)))
             slot.append(t)
             steps.append(st["step"])
@@ -745,13 +751,14 @@ class FusedAdam(torch.optim.Optimizer):
         buf = torch.tensor([float(t) for t in steps], dtype=torch.float32)
         for j, (_, p) in enumerate(live):
             self.state[p]["step"] = buf[j]
-        return {"key": self._plan_key(live), "entries": entries, "step_buf": buf, "arrs": arrs, "params": params}
+        return {"key": self._plan_key(live) + (() if ranges is None else (tuple(ranges[id(p)] for _, p in live),)), "entries": entries,
+                "step_buf": buf, "arrs": arrs, "params": params, "offs": [0 if ranges is None else ranges[id(p)][0] for _, p in live]}
 
     def _plan_key(self, live):
         return tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
                       self.state[p]["step"].data_ptr(), p.numel()) for _, p in live)
 
-    def _launch(self, live, which, stream=None):
+    def _launch(self, live, which, stream=None, ranges=None):
         state, key = self.state, []
         for _, p in live:               # one pass: create missing state, and read the pointers the plan is keyed on
             st = state[p]
@@ -761,20 +768,22 @@ class FusedAdam(torch.optim.Optimizer):
                 st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             key.append((p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(), p.numel()))
         key = tuple(key)
+        if ranges is not None:
+            key = key + (tuple(ranges[id(p)] for _, p in live),)
         plan = self._plans.get(which)
         if plan is None or plan["key"] != key:
-            plan = self._plans[which] = self._build_plan(live, key)
+            plan = self._plans[which] = self._build_plan(live, key, ranges)
         if which is None:
             self._plan = plan
         # this step's gradients: pointers refreshed and strides checked every step.  (Shape, device and dtype need no check here:
         # torch refuses a .grad assignment whose size, device or dtype differs from the parameter's -- THPVariable_set_grad --
         # but it accepts any strides.)
         arrs = plan["arrs"]
-        for (group, b1, b2, cfg, i), p in zip(plan["entries"], plan["params"]):
+        for (group, b1, b2, cfg, i), p, off in zip(plan["entries"], plan["params"], plan["offs"]):
             g = p.grad
             if g.stride() != p.stride() and not _same_layout(g, p):
                 raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
-            arrs[cfg][i].grad = g.data_ptr()
+            arrs[cfg][i].grad = g.data_ptr() + 4 * off
         plan["step_buf"] += 1
         arrs = plan["arrs"]
         # the step counters are host tensors the state surgery and rewind() may have touched: read them all in one go, and form
@@ -810,16 +819,18 @@ class FusedAdam(torch.optim.Optimizer):
         return created
 
     @torch.no_grad()
-    def step_partial(self, params, stream=None):
+    def step_partial(self, params, stream=None, ranges=None):
         """Advance only `params` (their gradients are final) on the CURRENT stream; the step() that follows in the same iteration
         advances the rest.  The fused training step uses it to put the Gaussians' appearance parameters -- 56 of their 59 floats,
         four fifths of Adam's bytes -- on its second stream underneath the deformation backward (fused_step.py).  Element for
-        element the same update as one step(): Adam is element-wise."""
+        element the same update as one step(): Adam is element-wise.
+        ranges: {id(p): (first element, count)} -- only that slice of each parameter (storage order) is advanced: this rank's share
+        of a camera-batch shard whose ranks reduce-scatter the gradients and all-gather the updated parameters (parallel.py)."""
         ids = {id(p) for p in params}
         live = [(group, p) for group in self.param_groups for p in group["params"] if id(p) in ids and p.grad is not None]
         if not live:
             return
-        self._launch(live, "early", stream=stream)
+        self._launch(live, "early" if ranges is None else "early-sharded", stream=stream, ranges=ranges)
         self._early = {id(p) for _, p in live}
 
     @torch.no_grad()

@@ -94,6 +94,8 @@ class Trainer:
         overflow until the host replays them -- anything that reads the model between steps (checkpoints, evaluation renders)
         drains first.  Trainer.step() does so itself at every iteration that restructures the model."""
         self.drain()
+        if self.fused is not None:
+            self.fused.gather_moments()
         self.scene.save(iteration, stage or self.stage)
 
     def _recover(self, tag):
@@ -128,6 +130,7 @@ class Trainer:
             if self._boundary(iteration):
                 self.drain()
                 self.fused.exact_next()
+                self.fused.gather_moments()        # (sharded Adam: the round below reads / restructures every slice's moments)
             else:
                 if len(self._log) and len(self._log) % self.CHECK_EVERY == 0:
                     self._post_check()
@@ -235,12 +238,12 @@ class Trainer:
         self._skip = None
         return loss
 
-    def _early_adam(self, params, stream=None):
+    def _early_adam(self, params, stream=None, ranges=None):
         """Runs on the fused step's second stream (`stream`: its raw handle; None: the current stream), right after the activation
         backward: Adam for the appearance parameters and -- it only needs the radii and the screen-space gradient, both final by
         then -- the densification statistics."""
         self.g.optimizer.skip_flag = self.fused.flags
-        self.g.optimizer.step_partial(params, stream=stream)
+        self.g.optimizer.step_partial(params, stream=stream, ranges=ranges)       # ranges: this rank's slice (sharded Adam, parallel.py)
         if self._early_iter < self.opt.densify_until_iter:
             self.g.update_densification_stats(self.fused.radii, self.fused.g2d, skip_flag=self.fused.flags, stream=stream)
             self._stats_done = True
@@ -266,7 +269,18 @@ class Trainer:
                 # the step began its all-reduces as each bucket became final (fused_step.py); radii and vsp_grad come
                 # back reduced in place (largest radius over the ranks, mean screen-space gradient)
                 self.dist.finish()
-                self.dist.seed_for(iteration)
+                if self._boundary(iteration):
+                    # (the one random draw a step can make is densify_and_split's, at a boundary iteration: two torch calls -- 25 us
+                    # of a rank's host time -- spared on the others)
+                    self.dist.seed_for(iteration)
+                if not getattr(self.dist, "verified", True):
+                    # first step of a world > 1: what the collectives should have made identical on every rank IS identical, or the job stops
+                    fs = self.fused
+                    torch.cuda.synchronize()
+                    chk = [fs.ibucket, fs._dg_flat] + ([fs.pflat, fs.g2d_flat] if (fs._chunk and early is not None) else [fs.early_bucket])
+                    if self.dist.mode == "tile-row" and getattr(fs, "_tr_pack", None) is not None:
+                        chk.append(fs._tr_pack)
+                    self.dist.verify_replicas(chk)
             visibility = None          # the statistics kernel derives it from the radii (update_densification_stats)
             if self.sync_every_step:
                 if torch.isnan(loss.tensor()).any():

@@ -368,3 +368,54 @@ def test_processing_orders_are_refreshed_beside_the_steps_and_stay_permutations(
     for k in a:
         scale = max(1e-12, float(b[k].abs().max()))
         assert float(((a[k] - b[k]).abs() > 1e-3 * scale + 1e-6).float().mean()) <= 2e-3, k
+
+
+@pytest.mark.parametrize("P,world", [(20_003, 2), (20_003, 8), (4_000_000, 8)])
+def test_sharded_adam_slices_of_every_rank_together_are_one_full_step_to_the_bit(P, world):
+    """Sharded Adam (parallel.py; SURVEY 8e's "reduce-scatter + sharded Adam + all-gather of updated params"): with the gradients held
+    fixed, the `world` ranks' FusedAdam.step_partial(ranges=DistContext.shard_ranges(...)) launches -- each on its own chunk of the
+    flat appearance bucket [f_dc 3P | f_rest 45P | scaling 3P | rotation 4P | opacity P] -- leave parameters and both moments
+    exactly where ONE replicated step leaves them: same bits, two steps in a row (the second with non-zero moments), chunks that
+    cut tensors at unaligned offsets (P odd) and BASELINE configs[4]'s per-GPU model (4 M Gaussians, 8 ranks)."""
+    ops = importlib.import_module("iclr2025_3d-mom_amd.ops")
+    par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    dev = torch.device("cuda")
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    shapes = ((1, 3), (15, 3), (3,), (4,), (1,))
+    lrs = (2.5e-3, 1.25e-4, 5e-3, 1e-3, 5e-2)
+    cuts = [0]
+    for shp in shapes:
+        cuts.append(cuts[-1] + P * int(np.prod(shp)))
+
+    def make():
+        g0 = torch.Generator(device="cuda").manual_seed(11)
+        ps = [torch.nn.Parameter(torch.randn((P,) + shp, device=dev, generator=g0)) for shp in shapes]
+        return ps, ops.FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(ps, lrs)], eps=1e-15)
+
+    pa, oa = make()
+    pb, ob = make()
+    ranks = [par.DistContext(r, world, shard_adam=True) for r in range(world)]
+    chunk = ranks[0].chunk(cuts[-1])
+    assert chunk % 4 == 0 and world * chunk >= cuts[-1]
+    covered = 0
+    for step in range(2):
+        grads = [torch.randn((P,) + shp, device=dev, generator=gen) * (10.0 ** -step) for shp in shapes]
+        for p, q, g in zip(pa, pb, grads):
+            p.grad, q.grad = g, g.clone()
+        oa.step_partial(pa)                                        # the replicated step
+        oa.step()
+        for r, dc in enumerate(ranks):                             # every rank's slice, one after the other, on the second copy
+            rg = dc.shard_ranges(cuts, chunk)
+            if step == 0:
+                covered += sum(n for _, n in rg)
+            ob.step_partial(pb, ranges={id(p): x for p, x in zip(pb, rg)})
+            ob._early = None
+            if r + 1 < world:
+                ob.rewind(1)                                       # (one optimizer stands in for `world` of them: one step, not eight)
+        torch.cuda.synchronize()
+        for k, (p, q) in enumerate(zip(pa, pb)):
+            assert torch.equal(p.data, q.data), (step, k)
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(oa.state[p][key], ob.state[q][key]), (step, k, key)
+            assert float(oa.state[p]["step"]) == float(ob.state[q]["step"]) == step + 1
+    assert covered == cuts[-1]                                     # the chunks cover every element exactly once

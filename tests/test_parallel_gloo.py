@@ -241,3 +241,103 @@ def test_tile_row_rebalance_agrees_across_ranks(tmp_path):
     for k, r in enumerate(res):
         assert list(r["due"]) == [False] * 15 + [True]
         assert tuple(r["other"]) == ((0, 2), (2, 4), (4, 7))[k]          # 7 rows: no weights for that height, plain split
+
+
+def _adam_ref(p, g, m, v, step, lr=1e-2, b1=0.9, b2=0.999, eps=1e-15):
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    p.sub_(lr / (1 - b1 ** step) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps))
+
+
+def _run_sharded(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    dc = P.DistContext(rank, world, shard_adam=True)
+    n_g = 1001                                                 # "Gaussians": five tensors of 3, 45, 3, 4, 1 floats each, as the bucket
+    widths = (3, 45, 3, 4, 1)
+    cuts = [0]
+    for w in widths:
+        cuts.append(cuts[-1] + w * n_g)
+    chunk = dc.chunk(cuts[-1])
+    assert chunk % 4 == 0 and world * chunk >= cuts[-1] > (world - 1) * chunk
+    gen = torch.Generator().manual_seed(7)
+    params0 = torch.randn(world * chunk, generator=gen)
+    res = {}
+    for path in ("all_reduce", "sharded"):
+        pflat = params0.clone()
+        m, v = torch.zeros_like(pflat), torch.zeros_like(pflat)
+        for step in (1, 2, 3):
+            g = torch.Generator().manual_seed(1000 * step + rank)
+            grad = torch.zeros(world * chunk)
+            grad[:cuts[-1]] = torch.randn(cuts[-1], generator=g) / world
+            if path == "all_reduce":
+                dc.start(grad, "sum")
+                dc.finish()
+                _adam_ref(pflat[:cuts[-1]], grad[:cuts[-1]], m[:cuts[-1]], v[:cuts[-1]], step)
+            else:
+                dc.start_reduce_scatter(grad, chunk, "sum")
+                dc.finish()
+                for a, (off, n) in zip(cuts, dc.shard_ranges(cuts, chunk)):       # this rank's slice of each of the five tensors
+                    if n:
+                        sl = slice(a + off, a + off + n)
+                        _adam_ref(pflat[sl], grad[sl], m[sl], v[sl], step)
+                dc.start_gather_flat(pflat, chunk)
+                dc.finish()
+        if path == "sharded":
+            # the moments of the other ranks' slices are stale until gathered (as before a densify / prune round or a checkpoint)
+            class _Opt:
+                state = {}
+            tensors = [pflat[a:b].clone() for a, b in zip(cuts[:-1], cuts[1:])]
+            opt = _Opt()
+            opt.state = {t: {"exp_avg": m[a:b].clone(), "exp_avg_sq": v[a:b].clone()} for t, a, b in zip(tensors, cuts[:-1], cuts[1:])}
+            dc.gather_moments(opt, tensors, cuts, chunk)
+            m = torch.cat([opt.state[t]["exp_avg"] for t in tensors])
+            v = torch.cat([opt.state[t]["exp_avg_sq"] for t in tensors])
+        res[path] = (pflat[:cuts[-1]].clone(), m[:cuts[-1]].clone(), v[:cuts[-1]].clone())
+    ranges = dc.shard_ranges(cuts, chunk)
+    # first-step replica check: passes on identical buffers, raises on every rank when one rank's copy differs
+    dc.verified = False
+    dc.verify_replicas([res["sharded"][0], torch.arange(5, dtype=torch.int32)])
+    dc.verified = False
+    bad = res["sharded"][0].clone()
+    if rank == world - 1:
+        bad[17] += 1e-3
+    raised = False
+    try:
+        dc.verify_replicas([torch.arange(5, dtype=torch.int32), bad])
+    except RuntimeError as e:
+        raised = "buffers [1]" in str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+    np.savez(out, p_ar=res["all_reduce"][0].numpy(), m_ar=res["all_reduce"][1].numpy(), v_ar=res["all_reduce"][2].numpy(),
+             p_sh=res["sharded"][0].numpy(), m_sh=res["sharded"][1].numpy(), v_sh=res["sharded"][2].numpy(),
+             covered=np.array(sum(n for _, n in ranges)), raised=np.array(raised))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_adam_protocol_equals_all_reduce_plus_replicated_adam(world, tmp_path):
+    """DistContext.start_reduce_scatter / shard_ranges / start_gather_flat / gather_moments ("reduce-scatter + sharded Adam +
+    all-gather of updated params"): three Adam steps on a five-tensor flat bucket, each rank updating only its chunk, end with the
+    same parameters AND moments, to the bit, as the all-reduce + replicated Adam on every rank; the chunks cover every element
+    exactly once; verify_replicas passes on agreeing replicas and raises on every rank when one differs."""
+    port = 34500 + os.getpid() % 2000 + world
+    outs = [str(tmp_path / f"s{r}.npz") for r in range(world)]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run_sharded, args=(r, world, port, outs[r])) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=250)
+        assert p.exitcode == 0
+    res = [np.load(o) for o in outs]
+    assert sum(int(r["covered"]) for r in res) == 56 * 1001
+    for r in res:
+        assert bool(r["raised"])
+        for k in ("p", "m", "v"):
+            np.testing.assert_array_equal(r[k + "_sh"], res[0][k + "_sh"])          # replicas agree
+            np.testing.assert_array_equal(r[k + "_sh"], r[k + "_ar"])               # and equal the all-reduce path, bit for bit
+    assert np.abs(res[0]["p_sh"]).max() > 0 and np.abs(res[0]["m_sh"]).max() > 0

@@ -67,3 +67,36 @@ def test_two_processes_on_one_gpu_end_with_identical_replicas_and_the_single_pro
     assert torch.equal(a["maxr"], want["maxr"])
     for k in ("xyz", "opacity", "f_dc", "scaling", "plane_xy", "plane_xt", "w0", "accum"):
         _close_enough(a[k], want[k], k)
+
+
+def _run_pair(mode, prefix):
+    argv = [sys.executable, os.path.join(ROOT, "tests", "two_process_rank.py"), mode, prefix]
+    rc, out = launch.spawn_ranks(2, argv, timeout=float(os.environ.get("MOM_TEST_SPAWN_TIMEOUT", "240")))
+    logs = ""
+    for r in (0, 1):
+        try:
+            with open(f"{prefix}_{r}.log") as fh:
+                logs += f"\n--- rank {r} ---\n" + fh.read()
+        except OSError:
+            logs += f"\n--- rank {r}: no log ---\n"
+    assert rc == 0, f"{mode}: rank pair ended with {rc}{logs}\n{out}"
+    return torch.load(prefix + "_0.pt"), torch.load(prefix + "_1.pt")
+
+
+def test_sharded_adam_pair_agrees_with_itself_to_the_bit_and_with_the_all_reduce_pair(tmp_path):
+    """SURVEY 8e's second camera-batch design -- reduce-scatter of the appearance bucket, each rank's Adam on its 1/world slice,
+    all-gather of the updated parameters -- against the all-reduce + replicated Adam it replaces, two real processes each, three
+    steps.  The replicas of the sharded pair agree with each other to the bit, parameters and (after gather_moments) Adam's
+    moments alike; against the all-reduce pair -- ANOTHER run, whose float atomics added in another order -- they agree within
+    the bound two runs of the same path keep (what is bit-exact between the two designs is checked where the gradients can be
+    held fixed: tests/test_parallel_gloo.py, test_fused_step_gpu.py::test_sharded_adam_slices...)."""
+    a0, a1 = _run_pair("camera", str(tmp_path / "ar"))
+    s0, s1 = _run_pair("camera-sharded", str(tmp_path / "rs"))
+    assert "m_f_rest" in s0 and "v_opacity" in s0
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), f"sharded replicas differ in {k}"
+        if s0[k].dtype.is_floating_point:
+            _close_enough(s0[k].float(), a0[k].float(), k)
+        else:
+            assert torch.equal(s0[k], a0[k]), k
+    assert float(s0["m_f_rest"].abs().max()) > 0 and float((s0["f_rest"] != 0).float().mean()) > 0

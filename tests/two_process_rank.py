@@ -1,7 +1,8 @@
 """One rank of tests/test_two_process_gpu.py: TWO real processes share GPU 0, rendezvous over gloo (which moves device tensors in
 this torch build; RCCL refuses two ranks on one device) and run three fused training steps through parallel.DistContext --
 start() / finish() with in-place asynchronous all-reduces of device buffers across a process boundary.
-usage: two_process_rank.py <camera|tile-row> <out prefix>"""
+usage: two_process_rank.py <camera|camera-sharded|tile-row> <out prefix>
+camera-sharded: the camera-batch shard with sharded Adam (reduce-scatter + 1/world of Adam + all-gather of the parameters)."""
 import importlib
 import os
 import sys
@@ -19,9 +20,14 @@ CFG = dict(P=20000, F=6, W=320, H=192, time_res=12, name="small")
 def snapshot(g):
     dn = g._deformation.deformation_net
     planes = [p for lv in dn.grid.grids for p in lv]
-    return {"xyz": g._xyz, "opacity": g._opacity, "f_dc": g._features_dc, "scaling": g._scaling, "plane_xy": planes[0],
-            "plane_xt": planes[2], "w0": dn._fused_params()[0], "accum": g.xyz_gradient_accum, "denom": g.denom,
-            "maxr": g.max_radii2D}
+    out = {"xyz": g._xyz, "opacity": g._opacity, "f_dc": g._features_dc, "scaling": g._scaling, "plane_xy": planes[0],
+           "plane_xt": planes[2], "w0": dn._fused_params()[0], "accum": g.xyz_gradient_accum, "denom": g.denom,
+           "maxr": g.max_radii2D, "f_rest": g._features_rest, "rotation": g._rotation}
+    st = getattr(g, "optimizer", None)
+    if st is not None and g._features_rest in st.state and "exp_avg" in st.state[g._features_rest]:
+        out["m_f_rest"] = st.state[g._features_rest]["exp_avg"]
+        out["v_opacity"] = st.state[g._opacity]["exp_avg_sq"]
+    return out
 
 
 def main():
@@ -49,14 +55,15 @@ def main():
     stamp("process group up")
     par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
     scene, g, trainer, op = bench.build_state(CFG, torch.device("cuda"), fused=True, lambda_dssim=0.2)
-    par.attach(trainer, rank, world, mode=mode)
+    par.attach(trainer, rank, world, mode="camera" if mode == "camera-sharded" else mode, shard_adam=(mode == "camera-sharded"))
     stamp("state built")
     cams = trainer.cams
     for i in range(3):
-        cam = cams[(i * world + rank) % len(cams)] if mode == "camera" else cams[i % len(cams)]
+        cam = cams[(i * world + rank) % len(cams)] if mode.startswith("camera") else cams[i % len(cams)]
         trainer.step(5001 + i, cams=[cam])
         stamp(f"step {i} enqueued (replayed so far: {trainer.replayed})")
     trainer.drain()
+    trainer.fused.gather_moments()             # (sharded Adam: every rank's moments whole again, as before a checkpoint)
     stamp("drained")
     torch.cuda.synchronize()
     stamp("device idle")
