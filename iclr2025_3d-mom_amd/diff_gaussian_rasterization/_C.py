@@ -214,16 +214,15 @@ def exact_render(lib, a, geom, img, out_color, out_depth, nr_host, P, W, H, dev,
     size), before anything else has been enqueued: what the caller gets back is complete either way, and num_rendered is the
     frame's own count.  The buffer is merely larger than the reference's would be."""
     guess = _state.get("exact_cap", 0)
-    ev = None
     if guess:
-        ev = torch.cuda.Event()
-        ev.record()
         binning = torch.empty((lib.mom_raster_binning_bytes(P, W, H, guess),), dtype=torch.uint8, device=dev)
         N.check(lib.mom_raster_forward_render(C.byref(a), geom.data_ptr(), binning.data_ptr(), guess, img.data_ptr(),
                                               out_color.data_ptr(), out_depth.data_ptr(), None, stream), "mom_raster_forward_render")
-    count = wait_count(nr_host, ev)
-    if count > guess or ev is None:
-        # (ev is None: nothing was enqueued above -- also the case of a frame with NO instances before any guess exists; the
+    # (no event between the two launches any more: the count is polled, and the rare fallback -- the poll timed out -- waits for the
+    # whole stream, i.e. for the compositing too; creating and recording a torch event cost every iteration 20 us of host time)
+    count = wait_count(nr_host, None)
+    if count > guess or not guess:
+        # (not guess: nothing was enqueued above -- also the case of a frame with NO instances before any guess exists; the
         # compositing still has to run, it writes the background image, as the reference does for num_rendered == 0)
         if guess:
             torch.cuda.current_stream().synchronize()      # the truncated pass is out of the way before its buffers are reused

@@ -41,8 +41,32 @@ class grads_through_graph:
         DIRECT_GRADS, ops.PlaneRegFunction.DIRECT_GRADS = self._old
 
 
+# Internal buffers of a render() call (what no caller ever sees: the field's outputs, the rasterizer's geometry and image state, the
+# backward's intermediate gradients and scratch) are handed from one call to the next through a free list per (P, W, H, stream)
+# instead of going back to torch's allocator and being asked for again: twenty torch.empty calls and as many frees per iteration,
+# 40 us of the host time that paces this path.  A call takes a set in its forward and gives it back at the end of its backward; a
+# call that is never back-propagated simply keeps its set (the garbage collector frees it), and several cameras rendered before one
+# backward each hold a set of their own.  The tensors a caller CAN hold -- image, depth, radii, every gradient -- are never pooled.
+_POOL = {}
+_POOL_MAX = 4
+
+
+def _pool_take(key):
+    free = _POOL.get(key)
+    return free.pop() if free else None
+
+
+def _pool_give(key, bufs):
+    free = _POOL.setdefault(key, [])
+    if len(free) < _POOL_MAX:
+        free.append(bufs)
+    if len(_POOL) > 8:                    # the model changed size a few times (densify / prune): forget the old sizes
+        for k in list(_POOL)[:-4]:
+            del _POOL[k]
+
+
 class _State:
-    __slots__ = ("a", "keep", "P", "W", "H", "cam_time", "order", "porders", "feat", "a0", "pts", "sc_d", "rot_d", "sc", "rot", "op",
+    __slots__ = ("pool_key", "bufs", "a", "keep", "P", "W", "H", "cam_time", "order", "porders", "feat", "a0", "pts", "sc_d", "rot_d", "sc", "rot", "op",
                  "color", "depth", "radii", "geom", "img", "binning", "cap", "xyz", "scal", "rotq", "opac", "flow", "coef", "planes",
                  "mlp", "field", "f_dc", "f_rest", "ready", "side")
 
@@ -107,13 +131,20 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
     st.porders = field._plane_orders(xyz)
     f = dict(dtype=torch.float32, device=dev)
     e = lambda *sh: torch.empty(*sh, **f)
-    st.feat, st.a0 = e(P, 64), e(P, 64)
-    st.pts, st.sc_d, st.rot_d = e(P, 3), e(P, 3), e(P, 4)
-    st.sc, st.rot, st.op = e(P, 3), e(P, 4), e(P, 1)
+    st.pool_key = (P, W, H, dev, s)
+    b = st.bufs = _pool_take(st.pool_key)
+    if b is None:
+        b = st.bufs = {"feat": e(P, 64), "a0": e(P, 64), "pts": e(P, 3), "sc_d": e(P, 3), "rot_d": e(P, 4), "sc": e(P, 3),
+                       "rot": e(P, 4), "op": e(P, 1),
+                       "geom": torch.empty(lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev),
+                       "img": torch.empty(lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev),
+                       "nr_dev": torch.empty(1, dtype=torch.int32, device=dev)}
+    st.feat, st.a0 = b["feat"], b["a0"]
+    st.pts, st.sc_d, st.rot_d = b["pts"], b["sc_d"], b["rot_d"]
+    st.sc, st.rot, st.op = b["sc"], b["rot"], b["op"]
     st.color, st.depth = e(3, H, W), e(1, H, W)
     st.radii = torch.empty(P, dtype=torch.int32, device=dev)
-    st.geom = torch.empty(lib.mom_raster_geom_bytes(P), dtype=torch.uint8, device=dev)
-    st.img = torch.empty(lib.mom_raster_image_bytes(W, H), dtype=torch.uint8, device=dev)
+    st.geom, st.img = b["geom"], b["img"]
     hp, keep, md = _forward_desc(pc, field, st.planes, st.mlp)
     ops.field_forward(hp, md, P, xyz, st.cam_time, st.order, scal, rotq, flow, st.coef, st.pts, st.sc_d, st.rot_d, st.feat, st.a0,
                       opac, st.sc, st.rot, st.op, s)
@@ -129,7 +160,7 @@ def _forward(pc, cam, bg, delta_scale, scaling_modifier, debug):
     a.prefiltered, a.debug = 0, int(bool(debug))
     a.keep_all_tiles = int(RC._state["keep_all_tiles"])       # set_keep_all_tiles(): the reference's lists and num_rendered
     st.keep = (bg, view, proj, campos, keep)
-    nr_dev = torch.empty(1, dtype=torch.int32, device=dev)
+    nr_dev = b["nr_dev"]
     nr_host = RC.pinned_word()
     N.check(lib.mom_raster_forward_geometry(C.byref(a), st.geom.data_ptr(), st.img.data_ptr(), st.radii.data_ptr(), nr_dev.data_ptr(),
                                             nr_host.data_ptr(), s), "raster_geometry")
@@ -223,9 +254,13 @@ def _backward(st, dcolor, ddepth, direct=True):
     e = lambda *sh: torch.empty(*sh, **f)
     dcol = dcolor.contiguous().float()
     ddep = None if ddepth is None else ddepth.contiguous().float()
-    g2d, gcol, gop_act, gxyz, gcov = e(P, 3), e(P, 3), e(P, 1), e(P, 3), e(P, 6)
+    b = st.bufs
+    if "gcol" not in b:               # the backward's internal gradients and scratch: made once per pooled set
+        b.update(gcol=e(P, 3), gop_act=e(P, 1), gcov=e(P, 6), gsc_act=e(P, 3), grot_act=e(P, 4), dfeat=e(P, 64),
+                 scratch=torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev))
+    g2d, gcol, gop_act, gxyz, gcov = e(P, 3), b["gcol"], b["gop_act"], e(P, 3), b["gcov"]
     gdc, grest = e(P, 1, 3), e(P, 15, 3)
-    gsc_act, grot_act, gsc, grot, gop = e(P, 3), e(P, 4), e(P, 3), e(P, 4), e(P, 1)
+    gsc_act, grot_act, gsc, grot, gop = b["gsc_act"], b["grot_act"], e(P, 3), e(P, 4), e(P, 1)
     gr = N.MomRasterGrads()
     gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = g2d.data_ptr(), gcol.data_ptr(), gop_act.data_ptr()
     gr.dL_dmeans3D, gr.dL_dcov3D = gxyz.data_ptr(), gcov.data_ptr()
@@ -245,8 +280,7 @@ def _backward(st, dcolor, ddepth, direct=True):
         side = ops.side_stream(dev).cuda_stream
         ready = ops.next_ring_mark(s)
     gplanes, gmlp, hp, md, in_place = _field_grads(st, f, direct)
-    dfeat = e(P, 64)
-    scratch = torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev)
+    dfeat, scratch = b["dfeat"], b["scratch"]
     # pts = xyz + dx(...): d xyz starts as d pts (already in gxyz); scale / rotation residuals likewise
     if overlap:
         # with a second stream the MLP backward leaves an eighth of the chip free (for that Adam launch) and its partial-sum
@@ -260,7 +294,10 @@ def _backward(st, dcolor, ddepth, direct=True):
     porders = st.porders
     hscratch = None
     if porders is not None:
-        hscratch = torch.empty(lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P), dtype=torch.uint8, device=dev)
+        need = lib.mom_hexplane_backward_scratch_bytes(C.byref(hp), P)
+        hscratch = b.get("hscratch")
+        if hscratch is None or hscratch.numel() < need:
+            hscratch = b["hscratch"] = torch.empty(need, dtype=torch.uint8, device=dev)
     N.check(lib.mom_hexplane_backward(C.byref(hp), P, st.xyz.data_ptr(), None, st.cam_time,
                                       None if st.order is None else st.order.data_ptr(), dfeat.data_ptr(), gxyz.data_ptr(),
                                       None if porders is None else porders[0].data_ptr(),
@@ -269,6 +306,11 @@ def _backward(st, dcolor, ddepth, direct=True):
     if overlap:
         ops.stream_wait_stream(s, side)                    # the MLP weight gradients are complete for whoever reads them next
     st.ready, st.side = ready, side
+    # the set goes back to the free list: everything that reads it is enqueued on this stream, and so is whoever takes it next
+    # (the key holds the stream).  With the second-stream overlap a kernel on the OTHER stream may still read it: that call keeps it.
+    if not overlap:
+        _pool_give(st.pool_key, b)
+    st.bufs = None
     return g2d, gxyz, gdc, grest, gsc, grot, gop, gplanes, gmlp, in_place
 
 

@@ -7,6 +7,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 
+import numpy as np
 import torch
 
 from . import _native as N
@@ -626,6 +627,13 @@ def plane_regulation(planes, w_smooth, w_l1):
 
 
 # --------------------------------------------------------------------------- Adam
+# numpy mirror of N.MomAdamTensor (same offsets and size): FusedAdam writes whole columns of its descriptor arrays through it
+_ADAM_DT = np.dtype({"names": [n for n, _ in N.MomAdamTensor._fields_],
+                     "formats": [{C.c_void_p: np.uint64, C.c_size_t: np.uint64, C.c_float: np.float32}[t] for _, t in N.MomAdamTensor._fields_],
+                     "offsets": [getattr(N.MomAdamTensor, n).offset for n, _ in N.MomAdamTensor._fields_],
+                     "itemsize": C.sizeof(N.MomAdamTensor)})
+
+
 def _dense(t):
     """True if t's elements tile its storage span without gaps or overlap (any dim order)."""
     dims = sorted(((st, sz) for st, sz in zip(t.stride(), t.shape) if sz > 1), reverse=True)
@@ -744,6 +752,23 @@ class FusedAdam(torch.optim.Optimizer):
             steps.append(st["step"])
             params.append(p)
         arrs = {cfg: (N.MomAdamTensor * len(ts))(*ts) for cfg, ts in by_cfg.items()}
+        # numpy views of the descriptor arrays (same memory): a step refreshes three float columns and one pointer column of ~32 rows
+        # with four vector assignments instead of ~130 ctypes field stores (0.3 us each: a tenth of the render() path's host time)
+        views = {cfg: np.frombuffer(arr, dtype=_ADAM_DT) for cfg, arr in arrs.items()}
+        cfg_list = list(arrs)
+        rows = {cfg: [] for cfg in cfg_list}            # per configuration: the plan-entry index of every row of its array
+        for j, (_, _, _, cfg, i) in enumerate(entries):
+            rows[cfg].append(j)
+        groups = []
+        gidx = []
+        for group, _ in live:
+            for k, gq in enumerate(groups):
+                if gq is group:
+                    gidx.append(k)
+                    break
+            else:
+                groups.append(group)
+                gidx.append(len(groups) - 1)
         # The step counters of the plan's parameters live in ONE host buffer and every state["step"] is a 0-d view into it (same
         # dtype, same values, still torch.optim.Adam's state layout): advancing and reading thirty-odd separate host tensors cost
         # 65 us per step() (torch._foreach_add_ + torch.stack), a tenth of the API path's host time; one add and one tolist() on the
@@ -752,7 +777,10 @@ class FusedAdam(torch.optim.Optimizer):
         for j, (_, p) in enumerate(live):
             self.state[p]["step"] = buf[j]
         return {"key": self._plan_key(live) + (() if ranges is None else (tuple(ranges[id(p)] for _, p in live),)), "entries": entries,
-                "step_buf": buf, "arrs": arrs, "params": params, "offs": [0 if ranges is None else ranges[id(p)][0] for _, p in live]}
+                "step_buf": buf, "arrs": arrs, "params": params, "offs": [0 if ranges is None else ranges[id(p)][0] for _, p in live],
+                "views": views, "rows": {cfg: np.asarray(r, dtype=np.int64) for cfg, r in rows.items()}, "groups": groups,
+                "gidx": np.asarray(gidx, dtype=np.int64), "offs4": np.asarray([0 if ranges is None else 4 * ranges[id(p)][0] for _, p in live], dtype=np.uint64),
+                "last_grad": [0] * len(params), "betas": [(b1, b2) for _, b1, b2, _, _ in entries]}
 
     def _plan_key(self, live):
         return tuple((p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
@@ -779,24 +807,37 @@ class FusedAdam(torch.optim.Optimizer):
         # torch refuses a .grad assignment whose size, device or dtype differs from the parameter's -- THPVariable_set_grad --
         # but it accepts any strides.)
         arrs = plan["arrs"]
-        for (group, b1, b2, cfg, i), p, off in zip(plan["entries"], plan["params"], plan["offs"]):
+        last, ptrs = plan["last_grad"], []
+        for j, p in enumerate(plan["params"]):
             g = p.grad
-            if g.stride() != p.stride() and not _same_layout(g, p):
-                raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
-            arrs[cfg][i].grad = g.data_ptr() + 4 * off
+            gp = g.data_ptr()
+            if gp != last[j]:           # (the same buffer as last step -- the gradient buffers are cached -- was checked then)
+                if g.stride() != p.stride() and not _same_layout(g, p):
+                    raise N.MomError("FusedAdam: param/grad must be dense with identical strides")
+                last[j] = gp
+            ptrs.append(gp)
         plan["step_buf"] += 1
-        arrs = plan["arrs"]
         # the step counters are host tensors the state surgery and rewind() may have touched: read them all in one go, and form
-        # the two bias corrections once per distinct (betas, step) -- one or two values, not one per tensor
+        # the two bias corrections once per distinct (betas, step) -- one or two values, not one per tensor.  Python float
+        # arithmetic, exactly as torch.optim.Adam forms them (numpy's pow may round differently in the last place)
         step_vals = plan["step_buf"].tolist()
         bias = {}
-        for (group, b1, b2, cfg, i), step in zip(plan["entries"], step_vals):
+        bc1, bc2 = [], []
+        for (b1, b2), step in zip(plan["betas"], step_vals):
             bc = bias.get((b1, b2, step))
             if bc is None:
                 bc = bias[(b1, b2, step)] = (1.0 - b1 ** step, math.sqrt(1.0 - b2 ** step))
-            t = arrs[cfg][i]
-            t.lr = float(group["lr"])
-            t.bias_correction1, t.bias_correction2_sqrt = bc
+            bc1.append(bc[0])
+            bc2.append(bc[1])
+        grad_col = np.asarray(ptrs, dtype=np.uint64) + plan["offs4"]
+        lr_col = np.asarray([float(gq["lr"]) for gq in plan["groups"]], dtype=np.float64)[plan["gidx"]]
+        bc1_col, bc2_col = np.asarray(bc1, dtype=np.float64), np.asarray(bc2, dtype=np.float64)
+        for cfg, view in plan["views"].items():
+            r = plan["rows"][cfg]
+            view["grad"] = grad_col[r]
+            view["lr"] = lr_col[r]                      # (float64 -> float32 on assignment: the rounding a ctypes c_float store makes)
+            view["bias_correction1"] = bc1_col[r]
+            view["bias_correction2_sqrt"] = bc2_col[r]
         for (b1, b2, eps), arr in arrs.items():
             N.check(N.lib().mom_adam_step(arr, len(arr), b1, b2, eps,
                                           None if self.skip_flag is None else self.skip_flag.data_ptr(),
@@ -835,6 +876,28 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        # (torch.optim.Optimizer wraps every subclass's step() in profile_hook_step -- a record_function range, two hook walks and
+        # a functools wrapper: 40 us per call, 4 % of the render() path's host time.  The class is marked `hooked` below so that the
+        # wrapper is not installed; registered step hooks are still honoured, here.)
+        pre = self._optimizer_step_pre_hooks
+        post = self._optimizer_step_post_hooks
+        if pre or post or _TORCH_OPT._global_optimizer_pre_hooks or _TORCH_OPT._global_optimizer_post_hooks:
+            return self._step_with_hooks(closure)
+        return self._step(closure)
+
+    def _step_with_hooks(self, closure):
+        import itertools
+        O = _TORCH_OPT
+        for hook in itertools.chain(O._global_optimizer_pre_hooks.values(), self._optimizer_step_pre_hooks.values()):
+            r = hook(self, (closure,), {})
+            if r is not None:
+                (closure,), _ = r if isinstance(r, tuple) and len(r) == 2 else ((closure,), {})
+        out = self._step(closure)
+        for hook in itertools.chain(self._optimizer_step_post_hooks.values(), O._global_optimizer_post_hooks.values()):
+            hook(self, (closure,), {})
+        return out
+
+    def _step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -875,6 +938,10 @@ class FusedAdam(torch.optim.Optimizer):
                 stream_mark(MARK_PARAMS, cur)
                 _params_ready[planes[0].device] = (cur, frozenset((id(p), p._version) for p in planes))
         return loss
+
+
+_TORCH_OPT = __import__("sys").modules["torch.optim.optimizer"]     # (torch.optim deletes the submodule's name from its namespace)
+FusedAdam.step.hooked = True      # see FusedAdam.step: keeps torch.optim.Optimizer._patch_step_function from wrapping it
 
 
 # --------------------------------------------------------------------------- backend switch

@@ -434,11 +434,20 @@ class GaussianModel:
     def compute_regulation(self, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
         """plane_tv * sum smooth2(space planes) + time_smoothness * sum smooth2(space-time planes)
         + l1_time_planes * sum mean|1 - space-time planes|, as one fused HIP pass over the 12 planes."""
-        planes, ws, wl = [], [], []
-        for g, i in self._reg_terms():
-            planes.append(g[i])
-            ws.append(time_smoothness_weight if i in (2, 4, 5) else plane_tv_weight)
-            wl.append(l1_time_planes_weight if i in (2, 4, 5) else 0.0)
+        # the planes and their weights, remembered until a plane object or a weight changes: walking the nn.ParameterLists costs
+        # 2 us per plane (container.__getitem__), 30 us per iteration of the render() path
+        grid = self._deformation.deformation_net.grid
+        key = (time_smoothness_weight, l1_time_planes_weight, plane_tv_weight)
+        c = getattr(self, "_reg_cache", None)
+        if c is None or c[0] is not grid or c[1] != key or (c[2] and c[2][0] is not grid.grids[0][0]):
+            planes, ws, wl = [], [], []
+            for g, i in self._reg_terms():
+                planes.append(g[i])
+                ws.append(time_smoothness_weight if i in (2, 4, 5) else plane_tv_weight)
+                wl.append(l1_time_planes_weight if i in (2, 4, 5) else 0.0)
+            # (a replaced plane object -- a rebuilt grid; load_state_dict copies into the existing ones -- shows in the first plane)
+            c = self._reg_cache = (grid, key, planes, ws, wl)
+        planes, ws, wl = c[2], c[3], c[4]
         if not planes:
             return 0.0
         return ops.BACKEND.plane_regulation(planes, ws, wl)

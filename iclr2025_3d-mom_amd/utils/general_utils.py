@@ -31,8 +31,8 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
             return 0.0
         warm = 1.0
         if lr_delay_steps > 0:
-            warm = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
-        t = np.clip(step / max_steps, 0, 1)
+            warm = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * min(max(step / lr_delay_steps, 0), 1))
+        t = min(max(step / max_steps, 0), 1)      # (= np.clip(x, 0, 1) of the reference, without its 5 us per call: three schedules per iteration)
         return warm * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
 
     schedule.log_endpoints = (log_a, log_b)
