@@ -11,11 +11,11 @@
 //   round 3's one-kernel f32 form: no dH traffic, but all 640 v_mfma_f32_32x32x2_f32 of a tile on one wave's critical path,
 //                              and that instruction blocks the SIMD's vector ALU: 266 us against 183;
 //   here:  the fp32-exact three-way bf16 split of deform_field.hip's forward (six v_mfma_f32_32x32x16_bf16 per product block,
-//          0.375 of the f32 matrix cycles, vector ALU free meanwhile) and FOUR ROLES.  Two kernels: deform_bwd_b3f_kernel -- one wave per
-//          role and SIMD, described here -- and, the default, deform_bwd_b3g_kernel further down, which cuts every role in two:
+//          0.375 of the f32 matrix cycles, vector ALU free meanwhile) and FOUR ROLES, each cut in two by deform_bwd_b3g_kernel
+//          further down (the roles as such:
 //            waves 0-2, "head k":  a1 = relu(W1_k a0 + b1_k) recomputed, dW2_k / db2_k, dH1_k = relu'(.) W2_k^T dout_k,
 //                                  dA0_k = W1_k^T dH1_k handed to the trunk wave through LDS, dW1_k += dH1_k^T a0, db1_k;
-//            wave 3, "trunk":      dH0 = relu'(a0) (dA0_0 + dA0_1 + dA0_2), dfeat = W0^T dH0, dW0 += dH0^T feat, db0.
+//            wave 3, "trunk":      dH0 = relu'(a0) (dA0_0 + dA0_1 + dA0_2), dfeat = W0^T dH0, dW0 += dH0^T feat, db0.)
 //          A role needs TWO weight-fragment sets, not seven: a head wave keeps W1_k's forward fragments (96 registers) for its
 //          whole share of the Gaussians and reads W1_k^T's from LDS (3 x 24 KB, pre-split once per workgroup); the trunk wave
 //          keeps W0^T's in registers.  Nothing is split per tile except activations.  (The per-tile, on-the-fly split of the
@@ -41,15 +41,6 @@ namespace {
 constexpr int kXS = 36;                                    // staging rows [feature][32 gaussians + 4]: 16-byte aligned
 constexpr int kFragU4 = 3 * 2 * 4 * 64;                    // one matrix orientation, [piece][mt][s][lane] uint4 = 24 KB
 // LDS map (bytes)
-constexpr int kOffFrag = 0;                                // W1_k^T fragments, k = 0..2
-constexpr int kOffXch = kOffFrag + 3 * kFragU4 * 16;       // dA0_k of the tile in flight: [3][8 float4][64 lanes]
-constexpr int kOffStage = kOffXch + 3 * 8 * 64 * 16;       // [4 waves][64][kXS] floats
-constexpr int kOffDout = kOffStage + 4 * 64 * kXS * 4;     // [3 heads][32][4] floats
-constexpr int kOffW2 = kOffDout + 3 * 32 * 4 * 4;          // [3][4][64] floats (rows >= nout zero)
-constexpr int kOffB1 = kOffW2 + 3 * 4 * 64 * 4;            // [3][64] floats
-constexpr int kOffFlag = kOffB1 + 3 * 64 * 4;              // ready[3], done
-constexpr int kLdsBytes = kOffFlag + 64;
-static_assert(kLdsBytes <= 160 * 1024, "the one-kernel MLP backward must fit a CU's LDS");
 
 // A tile's products, smallest terms first (as layer_b3 in deform_field.hip)
 __device__ __forceinline__ f32x16 mfma6(const Frag3& A, const Frag3& B, f32x16 c)
@@ -193,312 +184,15 @@ __device__ __forceinline__ int ld_acquire(const int* p) { return __hip_atomic_lo
 __device__ __forceinline__ void st_release(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wait_ge(const int* p, int v)
 {
-#ifdef B3F_NO_SYNC
-    return;
-#endif
-#ifndef B3_SLEEP
-#define B3_SLEEP 2
-#endif
-    while (__builtin_amdgcn_readfirstlane(ld_acquire(p)) < v) __builtin_amdgcn_s_sleep(B3_SLEEP);
+    // (the polling interval -- s_sleep 0 .. 4 -- does not matter: measured with -DB3G_STAMPS)
+    while (__builtin_amdgcn_readfirstlane(ld_acquire(p)) < v) __builtin_amdgcn_s_sleep(2);
 }
-
-#ifdef B3F_STAMPS
-#define B3F_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph[i] += now_ - last_; last_ = now_; } while (0)
-#else
-#define B3F_STAMP(i) do { } while (0)
-#endif
-// (The wave takes its SIMD's whole register file, so nothing co-runs with this kernel: the early Adam launch on the second stream
-// waits for its workgroups to leave.  Capped at 480 registers -- amdgpu_num_vgpr(240) -- one Adam wave fits beside it on every
-// SIMD and the HexPlane backward no longer shares HBM with Adam (189 -> 170 us at config 2, 3400 -> 2420 at config 5), but this
-// kernel then takes 222 instead of 173-191 us, raised wave priority or not: 1066 -> 1038 steps/s at config 2, equal at config 5.)
-__global__ void __launch_bounds__(256, 1)
-deform_bwd_b3f_kernel(MlpDev m, int P, int tiles, const float* __restrict__ feat, const float* __restrict__ a0g,
-                      const float* __restrict__ dpts, const float* __restrict__ dscales, const float* __restrict__ drots,
-                      float* __restrict__ dfeat, float* __restrict__ parts)
-{
-    float* __restrict__ part = parts + (size_t)blockIdx.x * kPartFloats;
-    extern __shared__ char lds_raw[];
-    uint4* fragT = reinterpret_cast<uint4*>(lds_raw + kOffFrag);
-    float4* xch = reinterpret_cast<float4*>(lds_raw + kOffXch);
-    float* sW2 = reinterpret_cast<float*>(lds_raw + kOffW2);
-    float* sB1 = reinterpret_cast<float*>(lds_raw + kOffB1);
-    int* flags = reinterpret_cast<int*>(lds_raw + kOffFlag);          // [0..2]: tiles published by head k; [3]: tiles consumed by the trunk
-    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    float* sA = reinterpret_cast<float*>(lds_raw + kOffStage) + wv * 64 * kXS;
-
-    // ---- prologue, all four waves: W1_k^T fragments (A[m][k] = W1_k[k][m]: rows = the layer's INPUT features), W2, b1
-    for (int slot = threadIdx.x; slot < 3 * 2 * 4 * 64; slot += 256) {
-        const int k = slot >> 9, mt = (slot >> 8) & 1, s = (slot >> 6) & 3, ln = slot & 63;
-        const int mrow = 32 * mt + (ln & 31), k0 = 16 * s + 4 * (ln >> 5);
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = m.W1[k][(k0 + (j & 3) + 8 * (j >> 2)) * kHid + mrow];
-        const Frag3 f = split8(v);
-#pragma unroll
-        for (int p = 0; p < 3; p++) fragT[k * kFragU4 + ((p * 2 + mt) * 4 + s) * 64 + ln] = f.p[p];
-    }
-    for (int i = threadIdx.x; i < 3 * 4 * kHid; i += 256) {
-        const int head = i >> 8, n = (i >> 6) & 3, f = i & 63;
-        const int nout = head == 2 ? 4 : 3;
-        sW2[i] = n < nout ? m.W2[head][n * kHid + f] : 0.f;
-    }
-    if (threadIdx.x < 3 * kHid) sB1[threadIdx.x] = m.b1[threadIdx.x >> 6][threadIdx.x & 63];
-    if (threadIdx.x < 4) flags[threadIdx.x] = 0;
-    __syncthreads();
-
-    const int t_begin = (int)((long long)tiles * blockIdx.x / gridDim.x), t_end = (int)((long long)tiles * (blockIdx.x + 1) / gridDim.x);
-    f32x16 dW[2][2];                                       // this role's 64x64 weight gradient: [out tile][in tile]
-    float db[2] = {0.f, 0.f};
-    zero_tile(dW[0]);
-    zero_tile(dW[1]);
-
-    if (wv < 3) {
-        // =========================================================================================== head k
-        const int k = wv, nout = k == 2 ? 4 : 3;
-        const float* __restrict__ dsrc = k == 0 ? dpts : (k == 1 ? dscales : drots);
-        float* sD = reinterpret_cast<float*>(lds_raw + kOffDout) + k * 32 * 4;
-        const float* __restrict__ W2l = sW2 + k * 4 * kHid;
-        const uint4* __restrict__ wT = fragT + k * kFragU4;
-        // W1_k's forward fragments stay in registers: A[m][kk] = W1_k[m][kk], kk in the accumulator order of deform_field.hip
-        Frag3 wf[2][4];
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const float* row = m.W1[k] + (32 * mt + col) * kHid + 16 * s + 4 * h;
-                const float4 lo = *reinterpret_cast<const float4*>(row), hi = *reinterpret_cast<const float4*>(row + 8);
-                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                wf[mt][s] = split8(v);
-            }
-        float dW2[4] = {0.f, 0.f, 0.f, 0.f};               // lane = feature
-        float db2[4] = {0.f, 0.f, 0.f, 0.f};               // lane = Gaussian column: summed over the lanes at the end
-        // the next tile's a0 is requested before this tile's weight-gradient phase (a wave is alone on its SIMD: nothing else covers
-        // a memory round trip at the top of a tile).  Not earlier, and not its second layout: with 64 more registers live across
-        // the tile the kernel spilled and went from 188 to 225 us.
-        f32x16 a0n[2];
-        if (t_begin < t_end) load_feat(a0g, t_begin * 32 + col, t_begin * 32 + col < P, h, a0n);
-#ifdef B3F_STAMPS
-        unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-#endif
-        for (int t = t_begin; t < t_end; t++) {
-            const int g = t * 32 + col;
-            const bool ok = g < P;
-            XRows xr;
-#ifndef B3F_NO_DW
-            x_request(a0g, t, P, col, h, xr);              // a0 in the weight gradient's layout: used at the end of the tile
-#endif
-            B3F_STAMP(0);
-            f32x16 a1[2];
-            {
-                f32x16 a0[2];
-                a0[0] = a0n[0];
-                a0[1] = a0n[1];
-                Frag3 Ba0[4];
-                split_tile<false>(a0, Ba0);
-                B3F_STAMP(1);
-                init_bias(sB1 + k * kHid, a1, h);
-                layer_regs(wf, Ba0, a1);
-            }
-            relu_tile(a1);
-            B3F_STAMP(2);
-            float dout[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) dout[q] = (ok && q < nout) ? dsrc[nout * g + q] : 0.f;
-            __builtin_amdgcn_wave_barrier();
-            stage36(sA, a1, col, h);
-            if (h == 0) *reinterpret_cast<float4*>(sD + 4 * col) = make_float4(dout[0], dout[1], dout[2], dout[3]);
-            __builtin_amdgcn_wave_barrier();
-            // dH1 = relu'(h1) * W2^T dout, in place of a1 (whose staged copy the output layer's gradient reads further down)
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 wa = *reinterpret_cast<const float4*>(W2l + 0 * kHid + 32 * mt + 8 * q + 4 * h);
-                    const float4 wb = *reinterpret_cast<const float4*>(W2l + 1 * kHid + 32 * mt + 8 * q + 4 * h);
-                    const float4 wc = *reinterpret_cast<const float4*>(W2l + 2 * kHid + 32 * mt + 8 * q + 4 * h);
-                    const float4 wd = *reinterpret_cast<const float4*>(W2l + 3 * kHid + 32 * mt + 8 * q + 4 * h);
-                    const float v0 = wa.x * dout[0] + wb.x * dout[1] + wc.x * dout[2] + wd.x * dout[3];
-                    const float v1 = wa.y * dout[0] + wb.y * dout[1] + wc.y * dout[2] + wd.y * dout[3];
-                    const float v2 = wa.z * dout[0] + wb.z * dout[1] + wc.z * dout[2] + wd.z * dout[3];
-                    const float v3 = wa.w * dout[0] + wb.w * dout[1] + wc.w * dout[2] + wd.w * dout[3];
-                    a1[mt][4 * q + 0] = a1[mt][4 * q + 0] > 0.f ? v0 : 0.f;
-                    a1[mt][4 * q + 1] = a1[mt][4 * q + 1] > 0.f ? v1 : 0.f;
-                    a1[mt][4 * q + 2] = a1[mt][4 * q + 2] > 0.f ? v2 : 0.f;
-                    a1[mt][4 * q + 3] = a1[mt][4 * q + 3] > 0.f ? v3 : 0.f;
-                }
-            B3F_STAMP(3);
-            {   // dA0_k = W1_k^T dH1 -> the trunk wave.  The 48 MFMAs are ISSUED here; the output layer's gradient below -- vector and
-                // LDS work on the staged a1 -- runs while the matrix pipe works through them (stamps: that phase was 4.4 k of a tile's
-                // 14.4 k cycles with the pipe idle)
-                Frag3 Bd[4];
-                split_tile<false>(a1, Bd);
-                f32x16 dA0[2];
-                zero_tile(dA0);
-                layer_lds(wT, Bd, dA0, lane);
-                __builtin_amdgcn_sched_barrier(0);
-#ifndef B3F_NO_DW2
-                {   // output layer: dW2[n][f] += sum_g dout[n][g] a1[f][g]   (lane = f);  db2[n] += dout[n][this lane's Gaussian]
-#pragma unroll
-                    for (int q = 0; q < 4; q++) db2[q] += dout[q];
-                    float w0 = 0.f, w1 = 0.f, w2 = 0.f, w3 = 0.f;
-#pragma unroll
-                    for (int g4 = 0; g4 < 32; g4 += 4) {
-                        const float4 v4 = *reinterpret_cast<const float4*>(sA + lane * kXS + g4);
-                        const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const float4 d = *reinterpret_cast<const float4*>(sD + 4 * (g4 + u));
-                            w0 += d.x * vv[u]; w1 += d.y * vv[u]; w2 += d.z * vv[u]; w3 += d.w * vv[u];
-                        }
-                    }
-                    dW2[0] += w0; dW2[1] += w1; dW2[2] += w2; dW2[3] += w3;
-                }
-#endif
-                __builtin_amdgcn_wave_barrier();
-                stage36(sA, a1, col, h);                   // dH1^T for the weight gradient (the staged a1 has been consumed)
-                __builtin_amdgcn_wave_barrier();
-                B3F_STAMP(4);
-                wait_ge(flags + 3, t - t_begin);           // the trunk has taken the previous tile out of the slot
-                B3F_STAMP(5);
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        xch[(k * 8 + mt * 4 + q) * 64 + lane] = make_float4(dA0[mt][4 * q], dA0[mt][4 * q + 1], dA0[mt][4 * q + 2], dA0[mt][4 * q + 3]);
-                st_release(flags + k, t - t_begin + 1);
-            }
-            B3F_STAMP(6);
-            if (t + 1 < t_end) load_feat(a0g, (t + 1) * 32 + col, (t + 1) * 32 + col < P, h, a0n);
-            // dW1_k += dH1^T a0, db1_k += sum_g dH1
-#ifndef B3F_NO_DW
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                Frag3 A[2], B[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++) A[mt] = dw_a_frag(sA, mt, ks, col, h, db[mt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) B[nt] = split8(xr.v[nt][ks]);
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++) dW[mt][nt] = mfma6(A[mt], B[nt], dW[mt][nt]);
-            }
-#endif
-            B3F_STAMP(7);
-        }
-#ifdef B3F_STAMPS
-        if (lane == 0) {
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(parts + (size_t)256 * kPartFloats) + ((size_t)blockIdx.x * 4 + wv) * 8;
-            for (int i = 0; i < 8; i++) dbg[i] = ph[i];
-        }
-#endif
-#ifndef B3F_NO_FLUSH
-        flush_dw(part + (1 + k) * kPartLayer, dW, db, col, h);
-#endif
-        float* thin = part + 4 * kPartLayer + k * kPartThin;
-#pragma unroll
-        for (int n = 0; n < 4; n++) thin[n * kHid + lane] = dW2[n];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {                       // both lane halves hold the same Gaussians: the first half's sum
-            float b = db2[q];
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) b += __shfl_xor(b, d);
-            if (lane == 0) thin[4 * kHid + q] = b;
-        }
-    } else {
-        // =========================================================================================== trunk
-        // W0^T's fragments stay in registers: A[mrow][kk] = W0[kk][mrow]
-        Frag3 wf[2][4];
-#pragma unroll
-        for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = m.W0[(16 * s + 4 * h + (j & 3) + 8 * (j >> 2)) * kHid + 32 * mt + col];
-                wf[mt][s] = split8(v);
-            }
-        f32x16 a0n[2];
-        if (t_begin < t_end) load_feat(a0g, t_begin * 32 + col, t_begin * 32 + col < P, h, a0n);
-#ifdef B3F_STAMPS
-        unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
-#endif
-        for (int t = t_begin; t < t_end; t++) {
-            const int g = t * 32 + col;
-            const bool ok = g < P;
-            XRows xr;
-#ifndef B3F_NO_DW
-            x_request(feat, t, P, col, h, xr);
-#endif
-            B3F_STAMP(0);
-            f32x16 a0[2];                                  // only its sign is used: the ReLU between trunk and heads
-            a0[0] = a0n[0];
-            a0[1] = a0n[1];
-            wait_ge(flags + 0, t - t_begin + 1);
-            wait_ge(flags + 1, t - t_begin + 1);
-            wait_ge(flags + 2, t - t_begin + 1);
-            B3F_STAMP(1);
-            f32x16 dH0[2];
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const float4 x0 = xch[(0 * 8 + mt * 4 + q) * 64 + lane], x1 = xch[(1 * 8 + mt * 4 + q) * 64 + lane],
-                                 x2 = xch[(2 * 8 + mt * 4 + q) * 64 + lane];
-                    dH0[mt][4 * q + 0] = a0[mt][4 * q + 0] > 0.f ? (x0.x + x1.x) + x2.x : 0.f;
-                    dH0[mt][4 * q + 1] = a0[mt][4 * q + 1] > 0.f ? (x0.y + x1.y) + x2.y : 0.f;
-                    dH0[mt][4 * q + 2] = a0[mt][4 * q + 2] > 0.f ? (x0.z + x1.z) + x2.z : 0.f;
-                    dH0[mt][4 * q + 3] = a0[mt][4 * q + 3] > 0.f ? (x0.w + x1.w) + x2.w : 0.f;
-                }
-            st_release(flags + 3, t - t_begin + 1);        // the slots are free again
-            B3F_STAMP(2);
-            __builtin_amdgcn_wave_barrier();
-            stage36(sA, dH0, col, h);
-            __builtin_amdgcn_wave_barrier();
-            B3F_STAMP(3);
-            {
-                Frag3 Bd[4];
-                split_tile<false>(dH0, Bd);
-                f32x16 df[2];
-                zero_tile(df);
-                layer_regs(wf, Bd, df);                    // dfeat = W0^T dH0
-                store_feat(dfeat, g, ok, h, df);
-            }
-            B3F_STAMP(4);
-            if (t + 1 < t_end) load_feat(a0g, (t + 1) * 32 + col, (t + 1) * 32 + col < P, h, a0n);
-#ifndef B3F_NO_DW
-#pragma unroll
-            for (int ks = 0; ks < 2; ks++) {
-                Frag3 A[2], B[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++) A[mt] = dw_a_frag(sA, mt, ks, col, h, db[mt]);
-#pragma unroll
-                for (int nt = 0; nt < 2; nt++) B[nt] = split8(xr.v[nt][ks]);
-#pragma unroll
-                for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-                    for (int nt = 0; nt < 2; nt++) dW[mt][nt] = mfma6(A[mt], B[nt], dW[mt][nt]);
-            }
-#endif
-            B3F_STAMP(7);
-        }
-#ifdef B3F_STAMPS
-        if (lane == 0) {
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(parts + (size_t)256 * kPartFloats) + ((size_t)blockIdx.x * 4 + wv) * 8;
-            for (int i = 0; i < 8; i++) dbg[i] = ph[i];
-        }
-#endif
-#ifndef B3F_NO_FLUSH
-        flush_dw(part, dW, db, col, h);
-#endif
-    }
-}
-
 
 // ===========================================================================================================================
-// The default kernel (MOM_B3_EIGHT=0 selects the four-wave one above): EIGHT role waves per workgroup, two per SIMD.  The one-wave-per-SIMD kernel above exposes
-// nearly all of its MFMA time (ablation: 41 of 43 us) and every LDS / memory round trip, because a wave cannot issue its vector
-// instructions under its own dependent MFMAs.  Here every role is cut in two along its data flow, and the two halves -- waves w
+// The kernel: EIGHT role waves per workgroup, two per SIMD.  Its predecessor -- four role waves, one per SIMD, one whole role each:
+// rounds 4-5, in the git history up to round 5 and described in docs/DESIGN_round_5.md 3.2 -- exposed nearly all of its MFMA time
+// (ablation: 41 of 43 us) and every LDS / memory round trip, because a wave cannot issue its vector instructions under its own
+// dependent MFMAs (182-190 us alone against 151 for this one).  Here every role is cut in two along its data flow, and the two halves -- waves w
 // and w + 4, which the hardware places on the same SIMD -- work on consecutive tiles at the same time:
 //   head k, wave A (k):      a1 = relu(W1_k a0 + b1_k) [W1_k fragments in registers], dW2_k / db2_k, dH1_k; stages dH1_k^T for B
 //   head k, wave B (k + 4):  dA0_k = W1_k^T dH1_k [fragments from LDS] -> added into the trunk's slot; dW1_k += dH1_k^T a0, db1_k
@@ -819,8 +513,6 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
     if (forced_blocks < 0) { const char* e = getenv("MOM_B3F_BLOCKS"); forced_blocks = (e && atoi(e) > 0 && atoi(e) <= 256) ? atoi(e) : 0; }
     const int max_blocks = forced_blocks ? forced_blocks : (dw_stream != s ? 224 : 256);
     const int blocks = tiles < max_blocks ? tiles : max_blocks;
-    // the eight-wave kernel (deform_bwd_b3g_kernel) by default; MOM_B3_EIGHT=0: the four-wave one
-    static const int eight = [] { const char* e = getenv("MOM_B3_EIGHT"); return (e && e[0] == '0') ? 0 : 1; }();
     int dev_id = 0;
     if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= kMaxDevices) return MOM_ELAUNCH;
     PerDevice& pd = per_device[dev_id];
@@ -829,20 +521,14 @@ int mom_launch_deform_bwd_b3f(const MomDeformMLP* w, int P, const float* feat, c
         // on): a process may drive several devices, from several threads.  A failed attribute call is retried by the next launch.
         std::lock_guard<std::mutex> lock(per_device_mutex);
         if (!pd.attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    kLdsBytes) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(deform_bwd_b3g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kG_LdsBytes) != hipSuccess)
                 return MOM_ELAUNCH;
             pd.attr_set = true;
         }
     }
     MomProfScope ps(MOM_P_MLP_BWD, s);
-    if (eight)
-        hipLaunchKernelGGL(deform_bwd_b3g_kernel, dim3(blocks), dim3(512), kG_LdsBytes, s, d, P, tiles, feat, a0, dpts, dscales, drots, dfeat,
-                           (float*)scratch);
-    else
-    hipLaunchKernelGGL(deform_bwd_b3f_kernel, dim3(blocks), dim3(256), kLdsBytes, s, d, P, tiles, feat, a0, dpts, dscales, drots, dfeat,
+    hipLaunchKernelGGL(deform_bwd_b3g_kernel, dim3(blocks), dim3(512), kG_LdsBytes, s, d, P, tiles, feat, a0, dpts, dscales, drots, dfeat,
                        (float*)scratch);
     if (hipGetLastError() != hipSuccess) return MOM_ELAUNCH;
     // The sum over the workgroups' partials is all that is left of "the weight gradients are complete on dw_stream": it goes to the
