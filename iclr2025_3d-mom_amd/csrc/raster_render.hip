@@ -30,9 +30,6 @@ __device__ __forceinline__ int remap_tile(int b, int nt, int C)
     return (q * 8 + xcd) * C + (slot - q * C);
 }
 static inline int tile_run(int gx) { return gx >= 8 ? gx / 4 : 1; }
-#ifndef MOM_TILE_ORDER
-#define MOM_TILE_ORDER 1
-#endif
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_add(float v)
@@ -78,10 +75,7 @@ __device__ __forceinline__ float splat_power(const float4 r0, const float4 r1, f
 // (mom_rect_reach, mom_common.h).  Each wave then compacts the indices of its reachable splats (ballot + rank) and loops
 // over those only.  The exact per-pixel tests still run: results are bit-identical.
 // Footprint of a wave inside the 16x16 tile: kFW x kFH pixels, kWX footprints across.  (16x4 strips: 16,4,1; 8x8 blocks: 8,8,2.)
-#ifndef MOM_FOOT_W
-#define MOM_FOOT_W 16
-#endif
-constexpr int kFW = MOM_FOOT_W, kFH = 64 / kFW, kWX = 16 / kFW;
+constexpr int kFW = 16, kFH = 64 / kFW, kWX = 16 / kFW;
 __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const float4 r1, float x0, float y0)
 {
     const float a = r1.x, c = r1.z;
@@ -98,21 +92,8 @@ __device__ __forceinline__ uint32_t strip_reach_mask(const float4 r0, const floa
 // Both compositing kernels gain from occupancy more than they lose to a tighter register budget (forward: 140 us at 8 waves
 // per SIMD against 168 us at 6, same instructions): the budget is pinned instead of left to the allocator, which moved it
 // by a wave or two from one unrelated edit to the next.
-#ifndef MOM_FWD_WAVES
-#define MOM_FWD_WAVES 8
-#endif
-#ifndef MOM_FWD_PREFETCH
-#define MOM_FWD_PREFETCH 1
-#endif
-#ifndef MOM_BWD_CUT
-#define MOM_BWD_CUT 1
-#endif
-#ifndef MOM_BWD_WAVES
+#define MOM_FWD_WAVES 8       // (macros, not constexpr: the launch-bounds attributes below take literals)
 #define MOM_BWD_WAVES 5
-#endif
-#ifndef MOM_BWD_MIN
-#define MOM_BWD_MIN 5
-#endif
 // Optional loss epilogue of the forward kernel (MomRasterArgs.l1_target): target null = none.
 struct L1Epilogue {
     const float* target;
@@ -124,14 +105,8 @@ struct L1Epilogue {
 // Splats staged per round (a multiple of 256; each thread stages kRound / 256 of them).
 // The backward stages 512 (297 against 307 us: fewer rounds, each with two barriers and a list build, for tiles that still hold
 // ~330 splats on average), the forward 256 (139 against 147 us at 512: it stops early and wastes part of its last round).
-#ifndef MOM_ROUND
-#define MOM_ROUND 256
-#endif
-#ifndef MOM_ROUND_BWD
-#define MOM_ROUND_BWD 512
-#endif
-constexpr int kRound = MOM_ROUND, kRoundChunks = kRound / 64;
-constexpr int kRoundB = MOM_ROUND_BWD, kRoundChunksB = kRoundB / 64;
+constexpr int kRound = 256, kRoundChunks = kRound / 64;
+constexpr int kRoundB = 512, kRoundChunksB = kRoundB / 64;
 // Compacts, for wave `wv`, the indices j < kRound whose mask has bit wv: afterwards lane k of list[c] holds entry 64 c + k of
 // the wave's list (in increasing j, so the compositing order is kept); returns the list length.
 template <int CHUNKS>
@@ -191,7 +166,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
     // (the order was made for the rows of the forward's geometry stage, kept in header words 3 and 4; a launch over other rows -- the
     // backward of a tile-row shard that rendered a halo -- falls back to the positional mapping)
-    const bool ordered = MOM_TILE_ORDER && order_hdr[3] == (uint32_t)t0 && order_hdr[4] == (uint32_t)nt;
+    const bool ordered = order_hdr[3] == (uint32_t)t0 && order_hdr[4] == (uint32_t)nt;
     const int tile = ordered ? (int)tile_order[blockIdx.x] : t0 + remap_tile(blockIdx.x, nt, run);
     const int tx = tile % gx, ty = tile / gx;
     const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
@@ -237,7 +212,6 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
     uint64_t live = __builtin_amdgcn_ballot_w64(inside);      // wave-uniform: the lanes still compositing (= !done, as a mask)
 
-#if MOM_FWD_PREFETCH
     // A round's records are asked for one round ahead: the index and the three record loads that depend on it are two memory round
     // trips, and a tile's eight workgroups-per-CU neighbours are all there is to cover them (at the headline size every tile is
     // resident from the start of the launch: nothing new is scheduled onto a SIMD that waits).  The values wait in registers
@@ -256,12 +230,10 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
         }
     };
     fetch(0);
-#endif
     STAMP_WAIT();
     FWD_STAMP(3);                                             // round 0's records are in registers
     for (int i = 0; i < rounds; i++, toDo -= kRound) {
         if (__syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256) { walked_rounds = i; break; }
-#if MOM_FWD_PREFETCH
         {
             uint32_t reach = 0;
             if (pv) {
@@ -276,25 +248,6 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
         }
         __syncthreads();
         fetch(i + 1);
-#else
-#pragma unroll
-        for (int sl = 0; sl < kRound / 256; sl++) {
-            const int slot = threadIdx.x + 256 * sl, progress = i * kRound + slot;
-            uint32_t reach = 0;
-            if (range.x + progress < range.y) {
-                const size_t id = point_list[range.x + progress];
-                float4 q0 = rec[3 * id + 0];
-                const float4 q1 = rec[3 * id + 1];
-                q0.w = power_bound(q1.w);
-                reach = strip_reach_mask(q0, q1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
-                s_rec[slot * 3 + 0] = q0;
-                s_rec[slot * 3 + 1] = q1;
-                s_rec[slot * 3 + 2] = rec[3 * id + 2];
-            }
-            s_mask[slot] = (uint8_t)reach;                  // slots past the end of the list: unreachable
-        }
-        __syncthreads();
-#endif
         int list[kRoundChunks];
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
 #pragma unroll
@@ -506,7 +459,7 @@ __device__ __forceinline__ float swap_add32(float a, float b)
 // those constants once per Gaussian instead of this loop once per (pixel, splat) pair.  The record stays linear in dL/dpixel, so
 // the ranks of a tile-row shard still sum it (mom_raster_backward_render in include/mom4d.h).
 template <bool DEPTH>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_MIN, MOM_BWD_WAVES)))   // LDS (31 KB) allows 5 workgroups per CU
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_BWD_WAVES, MOM_BWD_WAVES)))   // LDS (31 KB) allows 5 workgroups per CU
 render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list, int W, int H, int gx, int nt, int t0, int run,
                   const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_hdr, const float4* __restrict__ rec, const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
@@ -521,7 +474,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
     // (the order was made for the rows of the forward's geometry stage, kept in header words 3 and 4; a launch over other rows -- the
     // backward of a tile-row shard that rendered a halo -- falls back to the positional mapping)
-    const bool ordered = MOM_TILE_ORDER && order_hdr[3] == (uint32_t)t0 && order_hdr[4] == (uint32_t)nt;
+    const bool ordered = order_hdr[3] == (uint32_t)t0 && order_hdr[4] == (uint32_t)nt;
     const int tile = ordered ? (int)tile_order[blockIdx.x] : t0 + remap_tile(blockIdx.x, nt, run);
     const int tx = tile % gx, ty = tile / gx;
     const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
@@ -535,9 +488,6 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
     if (range.y > capacity) range.y = capacity;
     if (range.x > range.y) range.x = range.y;
     int toDo = (int)(range.y - range.x);
-#if !MOM_BWD_CUT
-    const int rounds = (toDo + kRoundB - 1) / kRoundB;
-#endif
 
     const int pix = inside ? py * W + px : 0;
     const size_t HW = (size_t)H * W;
@@ -597,7 +547,6 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);
-#if MOM_BWD_CUT
     // ... and the splats behind the last contributor of the whole TILE are not even staged: the list ends there for this launch
     // (positions are counted from the front, so cutting the tail moves none of them).  A tile the forward left early -- every
     // pixel saturated -- otherwise stages, tests and skips the rest of its list round after round.
@@ -614,7 +563,6 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
         }
     }
     const int rounds = (toDo + kRoundB - 1) / kRoundB;
-#endif
     BWD_STAMP(1);                                             // pixel state loaded, the list cut at the tile's last contributor
     STAMP_LIST(g_bwd_stamps, tile, toDo);
 
@@ -664,7 +612,6 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             if (!__any(!(power < r0.w))) continue;         // no lane of the wave can reach 1/255 (power_bound)
             const float G = mom_exp(power);
             const float alpha = fminf(0.99f, r1.w * G);
-            const bool valid = inside && ((int)contributor < last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
             // wave-uniform skip.  A ballot of each comparison is the comparison's own lane mask, and the masks combine in the
             // scalar unit; a ballot (or __any) of the combined bool made the compiler rebuild a mask with v_cndmask + v_cmp.
             const uint64_t vmask = m_inside & __builtin_amdgcn_ballot_w64((int)contributor < last_contributor) &
@@ -674,11 +621,7 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             // Inside the divergent block: what only the contributing lanes may do (their recurrences) and the two factors every
             // gradient carries, w = alpha T and a = opacity G dL/dalpha.  The products with them are formed outside, by all lanes
             // (an instruction costs the same whatever EXEC is), so that three registers need a zero for the other lanes, not nine.
-#ifndef MOM_BWD_NOBRANCH
-#define MOM_BWD_NOBRANCH 1            // 207 against 211 us (same box, alternating); 0 keeps the divergent block for measurement
-#endif
-#if MOM_BWD_NOBRANCH
-            // no divergent block: with alpha and G forced to zero in the lanes that do not contribute, the recurrences below are
+            // no divergent block (207 against 211 us with one, same box, alternating): with alpha and G forced to zero in the lanes that do not contribute, the recurrences below are
             // identities there (T / (1 - 0), 0 c + 1 accum) and both gradient factors vanish
             const float alpha_in = alpha, G_in = G;
             float w, a, g_op;
@@ -688,10 +631,6 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 // the two forms measured the same, 204.5 against 205 us)
                 float alpha, G;
                 asm("v_cndmask_b32_e64 %0, 0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4" : "=&v"(alpha), "=v"(G) : "v"(alpha_in), "v"(G_in), "s"(vmask));
-#else
-            float w = 0.f, a = 0.f, g_op = 0.f;
-            if (valid) {
-#endif
                 const float4 r2 = *reinterpret_cast<const float4*>(rec_j + 32);
                 // the reference divides (T = T / (1 - alpha), backward.cu:502); the hardware reciprocal is within 1 ulp of that
                 // quotient and costs one instruction instead of ten
