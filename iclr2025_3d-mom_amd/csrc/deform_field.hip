@@ -35,21 +35,9 @@ constexpr int kTileStride = 68;                      // B-operand tile rows: [32
 constexpr int kTileFloats = 32 * kTileStride;
 constexpr int kRecDw = 8;                            // dwords of one (point, level) record
 constexpr int kBufFloats = kTileFloats + 64 * kRecDw;   // one gather wave's buffer: the tile + its records
-#ifndef MOM_FIELD_PRIO
 #define MOM_FIELD_PRIO 2
-#endif
-#ifndef MOM_FIELD_PIPE
-#define MOM_FIELD_PIPE 0
-#endif
-#ifndef MOM_FIELD_NG
 #define MOM_FIELD_NG 2
-#endif
-#ifndef MOM_FIELD_DEPTH
-#define MOM_FIELD_DEPTH 1
-#endif
-#ifndef MOM_FIELD_NM
 #define MOM_FIELD_NM 1
-#endif
 constexpr int kNG = MOM_FIELD_NG;                    // gather waves per SIMD
 constexpr int kNM = MOM_FIELD_NM;                    // MFMA waves per SIMD: they take the SIMD's tiles in turn
 constexpr int kMfmaGroup = (kNM + kNG) >= 4 ? 8 : 16;   // A-fragment prefetch depth (registers)
@@ -238,28 +226,12 @@ __device__ __forceinline__ void gather_tile(const HexArgs& a, const LineTab& lt,
             if (g >= 0) *reinterpret_cast<float4*>(feat_save + (size_t)g * kHid + 32 * lvl + 4 * c) = f;
         }
     };
-#ifdef MOM_FIELD_NOGATHER
-    if (lane >= 0) { __builtin_amdgcn_wave_barrier(); return; }   // probe build: the MLP alone (tiles hold the records' leftovers)
-#endif
-#if MOM_FIELD_DEPTH == 2
-    UnitLoads LA, LB;
-    issue(0, LA);
-    issue(1, LB);
-#pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-        finish(u, LA);
-        if (u + 2 < 8) issue(u + 2, LA);
-        finish(u + 1, LB);
-        if (u + 3 < 8) issue(u + 3, LB);
-    }
-#else
 #pragma unroll 1
     for (int u = 0; u < 8; u++) {        // one pass in flight per wave
         UnitLoads LA;
         issue(u, LA);
         finish(u, LA);
     }
-#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -385,9 +357,6 @@ deform_field_fwd_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float*
             load_tile(tile, col, h, x);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the tile is in registers: its buffer is free again
             flag_set(f_free, n + 1);
-#ifdef MOM_FIELD_NOMLP
-            if (x[0][0] != 12345.678f) continue;     // probe build: the gather alone
-#endif
             init_bias(lds + kLB, a0, h);
             const unsigned long long s1 = STAMP();
             layer64p<false, kMfmaGroup>(lds + kLW, x, a0, col, h);
@@ -395,45 +364,19 @@ deform_field_fwd_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float*
         }
         relu_tile(a0);
         if (a0_save) store_feat(a0_save, g, ok, h, a0);
-        // Heads.  MOM_FIELD_PIPE: software pipelined -- the thin output layer of head k rides between the MFMAs of head k + 1's hidden
-        // layer (for a wave that is ALONE on its SIMD; it needs two hidden tiles in registers).  With two MFMA waves per SIMD the
-        // other wave's MFMAs fill those gaps and the plain order is used.
+        // Heads.  (A software-pipelined form -- the thin output layer of head k riding between the MFMAs of head k + 1's hidden
+        // layer -- pays for a wave that is ALONE on its SIMD and needs two hidden tiles in registers; with two MFMA waves per SIMD the
+        // other wave's MFMAs fill those gaps and the plain order is used: round 3, in the git history.)
         f32x16 hcur[2];
-#if MOM_FIELD_PIPE
-        init_bias(lds + kLB + kHid, hcur, h);
-        const unsigned long long s2 = STAMP();
-        layer64p<false>(lds + kLW + kWFloats, a0, hcur, col, h);
-        relu_tile(hcur);
-        tm += STAMP() - s2;
-#endif
-#if MOM_FIELD_PIPE
-#pragma unroll
-#else
 #pragma nounroll
-#endif
         for (int head = 0; head < 3; head++) {
             float o[4];
             const unsigned long long s3 = STAMP();
-#if MOM_FIELD_PIPE
-            if (head < 2) {
-                f32x16 hn[2];
-                float p[4] = {0.f, 0.f, 0.f, 0.f};
-                init_bias(lds + kLB + (2 + head) * kHid, hn, h);
-                layer64p_fill<false>(lds + kLW + (2 + head) * kWFloats, a0, hn, col, h, lds + kLW2 + head * 4 * kHid, hcur, p);
-                out_finish(lds + kLB2 + head * 4, p, o);
-                relu_tile(hn);
-                hcur[0] = hn[0];
-                hcur[1] = hn[1];
-            } else {
-                out_layer(lds + kLW2 + head * 4 * kHid, lds + kLB2 + head * 4, hcur, h, o);
-            }
-#else
             init_bias(lds + kLB + (1 + head) * kHid, hcur, h);
             layer64p<false, kMfmaGroup>(lds + kLW + (1 + head) * kWFloats, a0, hcur, col, h);
             tm += STAMP() - s3;
             relu_tile(hcur);
             out_layer(lds + kLW2 + head * 4 * kHid, lds + kLB2 + head * 4, hcur, h, o);
-#endif
             to += STAMP() - s3;
             if (h == 0 && ok) {
                 if (!kPrefetchIn) {
@@ -500,9 +443,7 @@ deform_field_fwd_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float*
 // B operand is its predecessor's accumulator, split in place, with no shuffle.  The weight fragments are prepared once per
 // workgroup in that order: wfrag[layer][piece][mt][s][lane] = 16 bytes = a lane's A operand, 96 KB of LDS in all.
 
-#ifndef MOM_B3_WAVES
 #define MOM_B3_WAVES 12
-#endif
 constexpr int kB3Waves = MOM_B3_WAVES;
 constexpr int kL3Frag = 0;                              // uint4 [4 layers][3 pieces][2 mt][4 s][64 lanes]
 constexpr int kL3FragU4 = 4 * 3 * 2 * 4 * 64;
@@ -531,13 +472,6 @@ __device__ __forceinline__ void layer_b3(const uint4* __restrict__ wf /* [3][2][
         }
 }
 
-// -DMOM_B3_PAD_NOPS: 64 wait states behind every burst of MFMAs (tools/probe/pk_hazard_real.py: does the packed-fp32 observation
-// need a vector instruction close behind the wave's OWN MFMAs?  DESIGN.md section 5).  Empty in the shipped build.
-#ifdef MOM_B3_PAD_NOPS
-#define MOM_B3_PAD() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory")
-#else
-#define MOM_B3_PAD() do { } while (0)
-#endif
 __global__ void __launch_bounds__(64 * kB3Waves)
 deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const float* __restrict__ lines, const float* __restrict__ xyz,
                            const float* __restrict__ scaling, const float* __restrict__ rotation, const float* __restrict__ flow,
@@ -618,12 +552,7 @@ deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const flo
         const unsigned long long s2 = STAMP();
         f32x16 acc[2];
         init_bias(lds + kL3B, acc, h);
-#ifndef MOM_B3_NOMFMA
         layer_b3(wfrag, B, acc, lane);
-        MOM_B3_PAD();
-#else
-        acc[0][0] += __uint_as_float(B[0].p[0].x + B[3].p[2].w);
-#endif
         relu_tile(acc);
         if (a0_save) store_feat(a0_save, g, ok, h, acc);
         Frag3 A0[4];
@@ -634,12 +563,7 @@ deform_field_fwd_b3_kernel(HexArgs a, LineTab lt, MlpDev m, int tiles, const flo
             const unsigned long long s3 = STAMP();
             f32x16 h1[2];
             init_bias(lds + kL3B + (1 + head) * kHid, h1, h);
-#ifndef MOM_B3_NOMFMA
             layer_b3(wfrag + (1 + head) * (3 * 2 * 4 * 64), A0, h1, lane);
-            MOM_B3_PAD();
-#else
-            h1[0][0] += __uint_as_float(A0[0].p[0].x + A0[3].p[2].w);
-#endif
             relu_tile(h1);
 #ifdef MOM_FIELD_STAMPS
             asm volatile("" :: "v"(h1[0][0]), "v"(h1[1][15]));
@@ -718,9 +642,7 @@ __device__ __forceinline__ float unit_sum(float v)
     return v;
 }
 
-#ifndef HX6_WAVES
 #define HX6_WAVES 3
-#endif
 template <bool CROWS>
 __global__ void __launch_bounds__(256, HX6_WAVES)
 hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __restrict__ lines, const float* __restrict__ xyz,
