@@ -854,11 +854,12 @@ def main():
                 out["keep_all_tiles"] = side_leg(cfg, dev, "fused", 100, 20, keep_all_tiles=True)
                 out["other_configs"] = {k: side_leg(CONFIGS[k], dev, "fused", 20, 5) for k in ("c1", "c3")}
                 # BASELINE configs[4]: "densify/prune every 100 iters" -- the round at iteration 5100 is inside the window
+                # first as a process's FIRST round finds the allocator (the leg before it ended with empty_cache(), no prewarm): the
+                # boundary then includes whatever the driver takes to hand out ~3 GB of fresh memory on this box; then the leg as
+                # every later round finds it (prewarmed) -- in this order, so that the cold leg IS cold
+                cold = side_leg(CONFIGS["c5"], dev, "fused", 121, 10, with_densify=True, prewarm_allocator=False)
                 out["other_configs"]["c5"] = side_leg(CONFIGS["c5"], dev, "fused", 121, 10, with_densify=True)
-                # ... and the same leg as a process's FIRST round finds the allocator (no prewarm): the boundary then includes
-                # whatever the driver takes to hand out ~3 GB of fresh memory on this box
-                out["other_configs"]["c5_cold_allocator"] = side_leg(CONFIGS["c5"], dev, "fused", 121, 10, with_densify=True,
-                                                                     prewarm_allocator=False)
+                out["other_configs"]["c5_cold_allocator"] = cold
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg)
         sys.stdout.flush()
