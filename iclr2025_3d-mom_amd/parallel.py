@@ -235,12 +235,44 @@ class DistContext:
             return self
         if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
             return self
+        # two phases, each agreed by ALL ranks before anyone goes on (a rank that took the direct path while another fell back to
+        # torch would wait in a collective the other never enters): first "can this rank resolve librccl at all", then "did
+        # ncclCommInitRank succeed here" -- a communicator is only created once every rank has said yes to the first
+        from . import _native as N
+        err = None
         try:
-            self.direct = DirectComm(self.rank, self.world, device)
+            ok = bool(N.lib().mom_comm_available())
+            if not ok:
+                err = N.lib().mom_comm_last_error().decode()
+        except Exception as e:                                   # noqa: BLE001
+            ok, err = False, str(e)
+        if not self._all_ranks(ok, device):
+            self._warn_fallback(err or "another rank cannot resolve librccl")
+            return self
+        comm = None
+        try:
+            comm = DirectComm(self.rank, self.world, device)
         except Exception as e:                                   # noqa: BLE001 -- whatever it was, say so and carry on through torch
-            import warnings
-            warnings.warn(f"parallel: direct RCCL path unavailable ({e}); the step's collectives go through torch.distributed")
+            err = str(e)
+        if self._all_ranks(comm is not None, device):
+            self.direct = comm
+        else:
+            if comm is not None:
+                comm.close()
+            self._warn_fallback(err or "another rank could not create its communicator")
         return self
+
+    def _all_ranks(self, flag, device):
+        """True iff `flag` is true on every rank (one tiny MIN all-reduce through torch.distributed, at set-up time only)."""
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(int(t[0]))
+
+    def _warn_fallback(self, why):
+        import warnings
+        warnings.warn(f"parallel: direct RCCL path unavailable ({why}); the step's collectives go through torch.distributed")
 
     def group(self):
         """Context manager: the collectives started inside are one launch on the direct path (and nothing special elsewhere)."""

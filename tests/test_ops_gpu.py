@@ -717,3 +717,51 @@ def test_hexplane_backward_with_common_factor_rows_equals_the_six_row_form(monke
         for a, b in zip(la, lb):
             assert float(b.abs().max()) > 0
             assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+
+
+def test_mom_comm_entry_points_on_one_rank_leave_in_place_buffers_as_a_world_of_one_must():
+    """include/mom4d.h mom_comm_*: the step's collectives over librccl behind the C ABI (csrc/comm.hip).  A one-GPU box can only
+    form a world of one, where every collective is the identity -- which still exercises the whole path the multi-GPU step takes:
+    librccl resolved at run time (the copy torch has mapped), communicator from a unique id, in-place all-reduce (sum, max, float
+    and int), all-gather, reduce-scatter, a grouped submission, stream ordering through the marks, and parallel.DirectComm on top."""
+    import ctypes as C
+    par = importlib.import_module("iclr2025_3d-mom_amd.parallel")
+    lib = N.lib()
+    assert lib.mom_comm_available() == 1, lib.mom_comm_last_error()
+    idb = (C.c_char * 128)()
+    assert lib.mom_comm_unique_id(idb) == 0
+    comm = C.c_void_p()
+    assert lib.mom_comm_create(C.byref(comm), idb, 1, 0) == 0, lib.mom_comm_last_error()
+    assert lib.mom_comm_world(comm) == 1 and lib.mom_comm_rank(comm) == 0
+    s = N.current_stream()
+    f = torch.arange(4096, dtype=torch.float32, device="cuda") * 0.5
+    i = torch.arange(-100, 924, dtype=torch.int32, device="cuda")
+    want_f, want_i = f.clone(), i.clone()
+    assert lib.mom_comm_all_reduce(comm, f.data_ptr(), f.numel(), N.COMM_F32, N.COMM_SUM, s) == 0
+    assert lib.mom_comm_all_reduce(comm, i.data_ptr(), i.numel(), N.COMM_I32, N.COMM_MAX, s) == 0
+    assert lib.mom_comm_all_gather(comm, f.data_ptr(), f.numel(), N.COMM_F32, s) == 0
+    assert lib.mom_comm_reduce_scatter(comm, f.data_ptr(), f.numel(), N.COMM_F32, N.COMM_SUM, s) == 0
+    assert lib.mom_comm_group_start() == 0
+    assert lib.mom_comm_all_reduce(comm, f.data_ptr(), 1024, N.COMM_F32, N.COMM_SUM, s) == 0
+    assert lib.mom_comm_all_reduce(comm, i.data_ptr(), i.numel(), N.COMM_I32, N.COMM_MAX, s) == 0
+    assert lib.mom_comm_group_end() == 0
+    torch.cuda.synchronize()
+    assert torch.equal(f, want_f) and torch.equal(i, want_i)
+    # bad arguments are refused, not passed on
+    assert lib.mom_comm_all_reduce(comm, f.data_ptr(), 16, 7, N.COMM_SUM, s) == N.MOM_EINVAL
+    assert lib.mom_comm_all_reduce(None, f.data_ptr(), 16, N.COMM_F32, N.COMM_SUM, s) == N.MOM_EINVAL
+    assert lib.mom_comm_create(C.byref(comm), idb, 2, 2) == N.MOM_EINVAL
+    assert lib.mom_comm_destroy(comm) == 0
+    # the Python layer: DirectComm on its own stream, work handles = stream marks
+    dc = par.DirectComm(0, 1, torch.device("cuda", torch.cuda.current_device()))
+    g = torch.full((1000,), 3.0, device="cuda")
+    w1 = dc.all_reduce(g, "sum")
+    with dc.group() as grp:
+        dc.reduce_scatter(g, 1000, "sum")
+        dc.all_reduce(i, "max")
+    dc.wait(w1)
+    dc.wait(grp.work)
+    h = g * 2                                                      # ordered behind the collectives on the current stream
+    torch.cuda.synchronize()
+    assert float(h.sum()) == 6000.0 and torch.equal(i, want_i)
+    dc.close()
