@@ -215,9 +215,14 @@ class FusedStep:
         if getattr(self, "_dg_key", None) != key:
             n = self._dg_n = sum(p.numel() for p in planes + mlp)
             store = getattr(self, "_dg_store", None)
-            if store is None or store.numel() != n + 3 * self._rows_cap or store.device != planes[0].device:
-                store = self._dg_store = torch.zeros(n + 3 * self._rows_cap, dtype=torch.float32, device=planes[0].device)
-            self._dg_flat = store[:n + 3 * self._pad]                                                       # the `late` bucket
+            if store is None or store.numel() != 4 + n + 3 * self._rows_cap or store.device != planes[0].device:
+                store = self._dg_store = torch.zeros(4 + n + 3 * self._rows_cap, dtype=torch.float32, device=planes[0].device)
+            # [loss sums (4) | field gradients (n) | xyz gradients (3 pad)]: the four floats in front carry a tile-row shard's loss
+            # sums (sum |d|, sum d^2, sum of the SSIM map over the rank's own rows) into the SAME all-reduce as the field
+            # gradients -- a collective of their own cost the step ~20 us of stream hand-over and four small launches
+            self._dg_all = store[:4 + n + 3 * self._pad]
+            self._tr_sums = self._dg_all[:4]
+            self._dg_flat = self._dg_all[4:]                                                                # the `late` bucket
             self.gxyz_rows = self._dg_flat[n:].view(self._pad, 3)
             self.gxyz = self.gxyz_rows[:self.P]
             off, self._dg_planes, self._dg_mlp = 0, [], []
@@ -292,7 +297,7 @@ class FusedStep:
         # and at config 1 the host paces the step)
         side = self.side.cuda_stream
         ops.stream_wait_stream(side, s)
-        ops.zero_async(self._dg_flat, side)
+        ops.zero_async(self._dg_all, side)
         # the compositing backward's accumulator record too (MomRasterArgs.accum_cleared): its last reader, the previous
         # step's projection backward, is behind this stream's wait above
         gk = (P, W, H, self.geom.data_ptr())
@@ -332,28 +337,26 @@ class FusedStep:
             g0 = min(P, dc.rank * S)
             g1 = min(P, g0 + S)
             sl = (S, g0, g1)
-            # ONE all-gather for the five tensors of the deformed state, not five: every torch.distributed call costs a rank's host
-            # 40-50 us (and a latency-bound collective its ~20 us on the wire), and the host paces a rank.  The slice's outputs go
-            # straight into this rank's slab of a packed buffer -- [world][pts 3S | scales 3S | rotations 4S | opacity S | raw
-            # rotations 4S], each array contiguous inside its slab, which is all the field kernel needs -- and five strided copies
-            # spread the gathered slabs into the [world * S, k] arrays the replicated projection reads.
-            W_ = dc.world
-            pack = getattr(self, "_tr_pack", None)
-            if pack is None or pack.shape != (W_ * S, 15) or pack.device != dev:
-                pack = self._tr_pack = torch.empty((W_ * S, 15), dtype=torch.float32, device=dev)
-            slabs = pack.view(W_, 15 * S)
-            cuts = ((self.pts, 0, 3), (self.sc, 3, 3), (self.rot, 6, 4), (self.op, 10, 1), (self.rot_d, 11, 4))
+            # The five tensors of the deformed state are gathered IN PLACE, each in its own [world * S, k] array (the slice's
+            # field kernel writes this rank's rows directly), as ONE grouped submission on the direct RCCL transport
+            # (ncclGroupStart / End: one launch).  Round 5 packed them into one slab per rank for a single torch.distributed call
+            # (40-50 us of host each) and paid five strided copies behind the gather at every world size; with the collectives
+            # behind the C ABI a call costs 0.6 us and the copies are gone.  (torch.distributed, the fallback and the CPU tests'
+            # transport, issues the five gathers one after the other.)
             if g1 > g0:
                 v = lambda t: t[g0:g1]
-                own = slabs[dc.rank]
-                loc = [own[S * o:S * (o + k)].view(S, k)[:g1 - g0] for _, o, k in cuts]
                 so = field._slice_order(xyz, g0, g1)
-                lines_kept = ops.field_forward(hp, md, g1 - g0, v(xyz), time, so, v(scal), v(rot), v(flow), coef, loc[0], v(self.sc_d),
-                                  loc[4], v(self.feat), v(self.a0), v(opac), loc[1], loc[2], loc[3], s)
-            dc.start_gather([pack], S)
+                lines_kept = ops.field_forward(hp, md, g1 - g0, v(xyz), time, so, v(scal), v(rot), v(flow), coef, v(self.pts), v(self.sc_d),
+                                  v(self.rot_d), v(self.feat), v(self.a0), v(opac), v(self.sc), v(self.rot), v(self.op), s)
+            grp = None
+            if hasattr(dc, "group"):
+                with dc.group() as grp:
+                    dc.start_gather([self.pts, self.sc, self.rot, self.op, self.rot_d], S)
+            else:
+                dc.start_gather([self.pts, self.sc, self.rot, self.op, self.rot_d], S)
+            if grp is not None and getattr(grp, "work", None) is not None:
+                dc._pending.append(grp.work)
             dc.finish()
-            for t, o, k in cuts:
-                t.view(W_, S, k).copy_(slabs[:, S * o:S * (o + k)].view(W_, S, k))
         else:
             lines_kept = ops.field_forward(hp, md, P, xyz, time, order, scal, rot, flow, coef, self.pts, self.sc_d, self.rot_d, self.feat, self.a0,
                               opac, self.sc, self.rot, self.op, s)
@@ -370,10 +373,13 @@ class FusedStep:
         a.tan_fovx, a.tan_fovy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         a.prefiltered, a.debug = 0, 0
         a.keep_all_tiles = int(self.keep_all_tiles)
-        fuse_l1 = not (self.dist is not None and self.dist.mode == "tile-row")
-        if fuse_l1:      # L1 (its gradient image and its sums) in the compositing kernel's epilogue; a row shard forms it per slab below
+        # L1 (its gradient image and its sums) in the compositing kernel's epilogue.  A tile-row shard too, unless its forward renders a
+        # halo (SSIM term): the kernel runs this rank's tiles only, leaves one pair of sums per tile, and the rank adds up ITS rows
+        tr_rows = dc is not None and dc.mode == "tile-row"
+        fuse_l1 = not tr_rows or (L1_PARTIALS and float(self.opt.lambda_dssim) == 0)
+        if fuse_l1:
             a.l1_target, a.l1_grad = gt.data_ptr(), self.dimg.data_ptr()
-            if L1_PARTIALS:
+            if L1_PARTIALS or tr_rows:
                 a.l1_partials = self.l1_part.data_ptr()
             else:
                 a.l1_sums = self.sums.data_ptr()
@@ -535,6 +541,33 @@ class FusedStep:
                 # backward: on RCCL wait() only makes the waiting stream wait, but gloo (the tests) blocks the host in it, and the
                 # host should block with the GPU's work already queued.
                 early_cam = list(early_works)
+
+        def launch_early_cam():
+            """Camera-batch shard: the second stream waits for the early collectives, then takes the appearance parameters' Adam
+            launch (sharded: this rank's 1/world of it, then the in-place all-gather of the UPDATED parameters behind it -- begun from
+            inside the second stream's context, so it is ordered behind that stream's Adam launch; the caller's DistContext.finish()
+            makes the main stream wait for it before anything reads a parameter)."""
+            app = [g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity]
+            if getattr(dc, "direct", None) is not None and not sharded:
+                # direct RCCL path: a wait is one hipStreamWaitEvent on the second stream's raw handle (no torch stream context: ~10 us)
+                dc.wait_for(early_cam, stream=self.side.cuda_stream)
+                early_adam(app, stream=self.side.cuda_stream)
+                return
+            with torch.cuda.stream(self.side):          # (torch.distributed's wait() orders the CURRENT torch stream)
+                dc.wait_for(early_cam)
+                if sharded:
+                    ranges = {id(p_): r for p_, r in zip(app, dc.shard_ranges(self._cut, self._chunk))}
+                    early_adam(app, stream=self.side.cuda_stream, ranges=ranges)
+                    dc.start_gather_flat(self.pflat, self._chunk)
+            if not sharded:
+                early_adam(app, stream=self.side.cuda_stream)
+
+        if early_cam is not None and not getattr(dc, "host_blocking", False):
+            # On RCCL (either transport) a wait only orders streams: the launch goes to the second stream NOW, ahead of the MLP
+            # backward's reduction kernel that is about to be queued there, and runs underneath that backward as in the unsharded
+            # step.  (Queued behind the reduction it ran beside the HexPlane gather instead, which it slows from 83 to 116 us.)
+            launch_early_cam()
+            early_cam = None
         if sl is None:
             N.check(lib.mom_deform_backward_split(C.byref(md), P, self.feat.data_ptr(), self.a0.data_ptr(), self.gxyz.data_ptr(),
                                                   d_sc.data_ptr(), d_rot.data_ptr(), self.dfeat.data_ptr(),
@@ -572,30 +605,27 @@ class FusedStep:
                                                   None if spo is None else self._hex_scratch.data_ptr(), s), "hexplane_bwd")
             dc.start_gather([self.gxyz_rows], S)
         if early_cam is not None:
-            app = [g._features_dc, g._features_rest, g._scaling, g._rotation, g._opacity]
-            if getattr(dc, "direct", None) is not None and not sharded:
-                # direct RCCL path: a wait is one hipStreamWaitEvent on the second stream's raw handle (no torch stream context: ~10 us)
-                dc.wait_for(early_cam, stream=self.side.cuda_stream)
-                early_adam(app, stream=self.side.cuda_stream)
-                early_cam = None
-        if early_cam is not None:
-            with torch.cuda.stream(self.side):          # (torch.distributed's wait() orders the CURRENT torch stream)
-                dc.wait_for(early_cam)
-                if sharded:
-                    # this rank's 1/world of Adam, then the all-gather of the UPDATED parameters (in place in their flat home) behind
-                    # it -- begun from inside the second stream's context, so it is ordered behind that stream's Adam launch; the
-                    # caller's DistContext.finish() makes the main stream wait for it before anything reads a parameter
-                    ranges = {id(p_): r for p_, r in zip(app, dc.shard_ranges(self._cut, self._chunk))}
-                    early_adam(app, stream=self.side.cuda_stream, ranges=ranges)
-                    dc.start_gather_flat(self.pflat, self._chunk)
-            if not sharded:
-                early_adam(app, stream=self.side.cuda_stream)
+            launch_early_cam()          # (gloo: its wait() blocks the host, so only now, with the deformation backward queued)
         if self.side is not None:
             ops.stream_wait_stream(s, self.side.cuda_stream)
         if dc is not None and dc.mode == "camera":
             dc.start(self._dg_flat, "sum")     # xyz + deformation field; the caller waits (DistContext.finish) before Adam
         elif sl is not None:
-            dc.start(self._dg_flat[:self._dg_n], "sum")     # the deformation field's gradients: the slices' shares (and the regulariser's, once)
+            # this rank's share of the logged loss value -- [sum |d|, sum d^2, sum of the SSIM map] over its OWN rows (the gradient
+            # image is already normalised by the whole image's element count) -- rides in front of the field gradients
+            if rows[1] > rows[0]:
+                if fuse_l1:     # the compositing epilogue left one pair of sums per tile of this rank's rows
+                    gx_ = (W + 15) // 16
+                    torch.sum(self.l1_part[rows[0] * gx_:rows[1] * gx_], dim=0, out=self._tr_sums[:2])
+                else:
+                    y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
+                    for c in range(3):
+                        N.check(lib.mom_l1_loss_acc((y1 - y0) * W, self.color[c, y0:y1].data_ptr(), gt[c, y0:y1].data_ptr(), None,
+                                                    self._tr_sums.data_ptr(), s), "l1_slab")
+                if lam != 0:
+                    self._tr_sums[2:3].copy_(self.ssim_sum[:1])
+            # the deformation field's gradients: the slices' shares (and the regulariser's, once) + the loss sums, one collective
+            dc.start(self._dg_all[:4 + self._dg_n], "sum")
             dc.finish()
         # ---- hand the gradients to the parameters
         for p, gbuf in ((g._xyz, self.gxyz), (g._features_dc, self.gdc), (g._features_rest, self.grest), (g._scaling, self.gsc),
@@ -608,24 +638,12 @@ class FusedStep:
         if rows is None:
             l1 = None                        # formed lazily from self.sums (LazyLoss): no kernels for a value nobody may read
         else:
-            # the image holds this rank's rows only: the logged L1 is the sum of the ranks' row slabs (value only; the
-            # gradient image above is already normalised by the whole image's element count)
-            y0, y1 = rows[0] * 16, min(H, rows[1] * 16)
-            if getattr(self, "_slab_sums", None) is None:
-                self._slab_sums = torch.zeros(3, 2, dtype=torch.float32, device=dev)
-            self._slab_sums.zero_()
-            if y1 > y0:
-                for c in range(3):
-                    N.check(lib.mom_l1_loss((y1 - y0) * W, self.color[c, y0:y1].data_ptr(), gt[c, y0:y1].data_ptr(), None,
-                                            self._slab_sums[c].data_ptr(), s), "l1_slab")
-            tot = torch.cat((self._slab_sums.sum(0), self.ssim_sum[:1].float() if lam != 0 else self._slab_sums.new_zeros(1)))
-            dc.start(tot, "sum")                    # [sum |d|, sum d^2, sum of the SSIM map], over the ranks' own rows
-            dc.finish()
-            self.sums.copy_(tot[:2])
+            # the image holds this rank's rows only: the logged values are the sums over the ranks, reduced above
+            self.sums.copy_(self._tr_sums[:2])
             if lam != 0:
-                self.ssim_sum[0] = tot[2].double()
-            l1 = tot[0] / n
-        sums = _TileSums(self.l1_part) if (fuse_l1 and L1_PARTIALS) else self.sums
+                self.ssim_sum[:1].copy_(self._tr_sums[2:3])
+            l1 = self._tr_sums[0] / n
+        sums = _TileSums(self.l1_part) if (fuse_l1 and L1_PARTIALS and rows is None) else self.sums
         loss = LazyLoss(sums if l1 is None else None, l1, reg, self.ssim_sum if lam != 0 else None, lam, n)
         self.last = {"loss": loss, "mse_sum": _Lazy(sums, 1), "n": n}       # float(last["mse_sum"]): formed when read
         return loss, self.radii, self.g2d

@@ -188,6 +188,9 @@ class DistContext:
         self.exact_scaling = world >= 1 and (world & (world - 1)) == 0
         self.shard_adam = bool(shard_adam) and mode == "camera"
         self.direct = None               # DirectComm on RCCL (connect()); None: torch.distributed carries the collectives
+        # gloo's wait() blocks the HOST until the collective is done (RCCL's only orders streams): the fused step then queues its
+        # own GPU work first and waits afterwards
+        self.host_blocking = dist.is_available() and dist.is_initialized() and dist.get_backend() == "gloo"
         self.verified = world == 1       # first-step replica check (verify_replicas) still to run
         self._flat = None
         self._pending = []

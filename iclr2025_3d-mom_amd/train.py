@@ -278,8 +278,8 @@ class Trainer:
                     fs = self.fused
                     torch.cuda.synchronize()
                     chk = [fs.ibucket, fs._dg_flat] + ([fs.pflat, fs.g2d_flat] if (fs._chunk and early is not None) else [fs.early_bucket])
-                    if self.dist.mode == "tile-row" and getattr(fs, "_tr_pack", None) is not None:
-                        chk.append(fs._tr_pack)
+                    if self.dist.mode == "tile-row":
+                        chk += [fs.pts, fs.rot_d]            # the gathered deformed state (first and last of the five arrays)
                     self.dist.verify_replicas(chk)
             visibility = None          # the statistics kernel derives it from the radii (update_densification_stats)
             if self.sync_every_step:
