@@ -134,6 +134,10 @@ __device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* 
 constexpr int kStampWords = 12, kStampGroups = 16384;
 __device__ unsigned long long g_fwd_stamps[kStampGroups * kStampWords];
 __device__ unsigned long long g_bwd_stamps[kStampGroups * kStampWords];
+// [kernel 0 fwd / 1 bwd][bucket of live (fwd) or valid (bwd) lanes: 0, 1-2, 3-4, 5-8, 9-16, 17-32, 33-64][0: entries walked, 1: entries that pass the wave-level tests]
+__device__ unsigned long long g_lane_hist[2][7][2];
+__device__ __forceinline__ int lane_bucket(uint64_t m) { const int n = __popcll(m); return n == 0 ? 0 : (n <= 2 ? 1 : (n <= 4 ? 2 : (n <= 8 ? 3 : (n <= 16 ? 4 : (n <= 32 ? 5 : 6))))); }
+#define LANE_HIST(kernel, mask, passed) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_lane_hist[kernel][lane_bucket(mask)][passed], 1ull); } while (0)
 #define FWD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) g_fwd_stamps[blockIdx.x * kStampWords + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define BWD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) g_bwd_stamps[blockIdx.x * kStampWords + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMP_ID(arr) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) { \
@@ -149,6 +153,7 @@ __device__ unsigned long long g_bwd_stamps[kStampGroups * kStampWords];
 #define STAMP_LIST(arr, tile, n) do { } while (0)
 #define STAMP_EXIT(arr) do { } while (0)
 #define STAMP_WAIT() do { } while (0)
+#define LANE_HIST(kernel, mask, passed) do { } while (0)
 #endif
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MOM_FWD_WAVES, MOM_FWD_WAVES)))
@@ -268,7 +273,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
                 float dx, dy;
                 const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
                 uint64_t vm = live & __builtin_amdgcn_ballot_w64(!(power < r0.w)) & __builtin_amdgcn_ballot_w64(!(power > 0.0f));
+                LANE_HIST(0, live, 0);
                 if (vm == 0) continue;                      // no lane of the wave can reach 1/255 (power_bound)
+                LANE_HIST(0, live, 1);
                 const float alpha = fminf(0.99f, r1.w * mom_exp(power));
                 const float test_T = T * (1.f - alpha);
                 vm &= __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
@@ -616,7 +623,9 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             // scalar unit; a ballot (or __any) of the combined bool made the compiler rebuild a mask with v_cndmask + v_cmp.
             const uint64_t vmask = m_inside & __builtin_amdgcn_ballot_w64((int)contributor < last_contributor) &
                                    __builtin_amdgcn_ballot_w64(!(power > 0.0f)) & __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f));
+            LANE_HIST(1, vmask, 0);
             if (vmask == 0) continue;
+            LANE_HIST(1, vmask, 1);
 
             // Inside the divergent block: what only the contributing lanes may do (their recurrences) and the two factors every
             // gradient carries, w = alpha T and a = opacity G dL/dalpha.  The products with them are formed outside, by all lanes
@@ -745,6 +754,12 @@ extern "C" int mom_debug_fwd_stamps(unsigned long long* host_dst, int groups)
 {
     if (groups > kStampGroups) groups = kStampGroups;
     return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_fwd_stamps), (size_t)groups * kStampWords * 8) == hipSuccess ? MOM_OK : MOM_ELAUNCH;
+}
+extern "C" int mom_debug_lane_hist(unsigned long long* host_dst, int reset)
+{
+    if (hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_lane_hist), sizeof(g_lane_hist)) != hipSuccess) return MOM_ELAUNCH;
+    if (reset) { static unsigned long long zero[2 * 7 * 2] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lane_hist), zero, sizeof(zero)) != hipSuccess) return MOM_ELAUNCH; }
+    return MOM_OK;
 }
 extern "C" int mom_debug_bwd_stamps(unsigned long long* host_dst, int groups)
 {
