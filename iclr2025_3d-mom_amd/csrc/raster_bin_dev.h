@@ -107,54 +107,104 @@ __device__ __forceinline__ uint64_t decide_instances(int x0, int y0, int x1, int
 }  // namespace
 
 // ---- per-tile sort ------------------------------------------------------------
-// Bitonic network in the "flip then disperse" form: every compare-exchange puts
-// the smaller key at the lower index, so virtual +inf padding above n never moves
-// and is simply skipped.
+// Bitonic network in the "flip then disperse" form: every compare-exchange puts the smaller key at the lower index, so virtual +inf
+// padding above n never moves (it is loaded as UINT64_MAX -- every real key, depth_bits << 32 | index, is smaller -- and never stored).
 //
-// All strides are powers of two: indices come from shifts and masks (a division by a run-time stride costs ~40
-// instructions per compare-exchange).  Thread t works on the compare-exchanges i = t, t + nthreads, ...; a wave's 64
-// consecutive i touch one aligned block of 128 keys whenever the stage's span (kk for a flip, 2j for a disperse step)
-// is at most 128, so two such stages in a row exchange data inside the wave only and need no workgroup barrier --
-// for 1024 keys that leaves 6 of 55.  A barrier is kept wherever either neighbour stage is wider.  With BLOCK_SYNC
-// false (the global-memory path of oversized buckets) every stage keeps its barrier.
+// RADIX 4 (round 6): a pass loads FOUR keys, applies two consecutive stages of the network to them in registers and stores them.
+// The stages of block size kk are  flip(kk), disperse(kk/4), disperse(kk/8), ..., disperse(1):  flip(kk) + disperse(kk/4) close over
+// {a, a + kk/4, kk-1-a-kk/4, kk-1-a} (a in the block's first quarter), disperse(j) + disperse(j/2) over {x, x + j/2, x + j, x + 3j/2}
+// (bits j and j/2 of x clear); a leftover disperse(1) -- and flip(2) -- take two neighbouring pairs.  Same network, same result; the
+// passes drop from 45 to 25 for 512 keys and from 55 to 30 for 1024, and with them the LDS round trips and barriers a lone workgroup's
+// sort is made of (16 us for 1024 keys, which is what the heaviest tiles of render_fwd spent before their first round) and the LDS
+// traffic of eight workgroups per CU sorting at once.
+//
+// All strides are powers of two: indices come from shifts and masks.  Thread t takes the groups g = t, t + nthreads, ...; a wave's 64
+// consecutive groups touch one aligned block of 256 keys whenever the pass's span (kk, or 2j) is at most 256, so consecutive such
+// passes exchange data inside the wave only and need no workgroup barrier.  A barrier is kept wherever either neighbour pass is
+// wider.  With LOCAL_STAGES false (the global-memory path of oversized buckets) every pass keeps its barrier.
 template <bool LOCAL_STAGES, class KeyPtr>
 __device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int nthreads, int tid)
 {
     int lm = 0;
     while ((1 << lm) < n) lm++;
-    const int half_m = (1 << lm) >> 1;
-    bool prev_wide = true;                                   // the loads before the first stage came from all waves
+    if (lm == 0) return;
+    if (lm == 1) {                                           // two keys
+        __syncthreads();
+        if (tid == 0) { const uint64_t ka = k[0], kb = k[1]; if (ka > kb) { k[0] = kb; k[1] = ka; } }
+        __syncthreads();
+        return;
+    }
+    const int quarter_m = (1 << lm) >> 2;
+    constexpr uint64_t kInf = ~0ull;
+    bool prev_wide = true;                                   // the loads before the first pass came from all waves
     auto sync_before = [&](int span) {
-        const bool wide = !LOCAL_STAGES || span > 128;
+        const bool wide = !LOCAL_STAGES || span > 256;
         if (wide || prev_wide) __syncthreads();
         else __builtin_amdgcn_wave_barrier();
         prev_wide = wide;
     };
-    for (int lk = 1; lk <= lm; lk++) {
-        const int kk = 1 << lk, lh = lk - 1, half = kk >> 1;
-        sync_before(kk);
-        for (int i = tid; i < half_m; i += nthreads) {
-            const int blk = i >> lh, off = i & (half - 1);
-            const int a = (blk << lk) + off, b = (blk << lk) + kk - 1 - off;
-            if (b < n) {
-                const uint64_t ka = k[a], kb = k[b];
-                if (ka > kb) { k[a] = kb; k[b] = ka; }
+    auto ld = [&](int i) { return i < n ? (uint64_t)k[i] : kInf; };
+    auto cx = [](uint64_t& a, uint64_t& b) { const uint64_t lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; };
+    // two neighbouring pairs (4g, 4g+1), (4g+2, 4g+3): flip(2), and the disperse(1) an odd number of disperse stages leaves over
+    auto pairs_pass = [&]() {
+        sync_before(2);
+        for (int g = tid; g < quarter_m; g += nthreads) {
+            const int x = 4 * g;
+            if (x + 1 < n) {
+                uint64_t k0 = k[x], k1 = k[x + 1];
+                if (k0 > k1) { k[x] = k1; k[x + 1] = k0; }
+            }
+            if (x + 3 < n) {
+                uint64_t k2 = k[x + 2], k3 = k[x + 3];
+                if (k2 > k3) { k[x + 2] = k3; k[x + 3] = k2; }
             }
         }
-        for (int lj = lk - 2; lj >= 0; lj--) {
-            const int j = 1 << lj;
+    };
+    auto st4 = [&](int i0, int i1, int i2, int i3, uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3) {
+        k[i0] = k0;                                          // i0 < n by construction of the callers' guards
+        if (i1 < n) k[i1] = k1;
+        if (i2 < n) k[i2] = k2;
+        if (i3 < n) k[i3] = k3;
+    };
+    for (int lk = 1; lk <= lm; lk++) {
+        const int kk = 1 << lk;
+        if (lk == 1) { pairs_pass(); continue; }
+        // flip(kk) + disperse(kk / 4)
+        const int q = kk >> 2;
+        sync_before(kk);
+        for (int g = tid; g < quarter_m; g += nthreads) {
+            const int blk = g >> (lk - 2), a = g & (q - 1), base = blk << lk;
+            const int i0 = base + a, i1 = i0 + q, i3 = base + kk - 1 - a, i2 = i3 - q;          // i0 < i1 < i2 < i3
+            if (i0 < n && i1 < n) {                          // (with only i0 below n every partner is +inf: nothing moves)
+                uint64_t k0 = k[i0], k1 = k[i1], k2 = ld(i2), k3 = ld(i3);
+                cx(k0, k3); cx(k1, k2);                      // flip
+                cx(k0, k1); cx(k2, k3);                      // disperse(kk / 4)
+                st4(i0, i1, i2, i3, k0, k1, k2, k3);
+            }
+        }
+        int lj = lk - 3;
+        for (; lj >= 1; lj -= 2) {                           // disperse(2^lj) + disperse(2^(lj-1))
+            const int j = 1 << lj, h = j >> 1;
             sync_before(2 * j);
-            for (int i = tid; i < half_m; i += nthreads) {
-                const int a = ((i >> lj) << (lj + 1)) + (i & (j - 1)), b = a + j;
-                if (b < n) {
-                    const uint64_t ka = k[a], kb = k[b];
-                    if (ka > kb) { k[a] = kb; k[b] = ka; }
+            for (int g = tid; g < quarter_m; g += nthreads) {
+                const int x = ((g >> (lj - 1)) << (lj + 1)) | (g & (h - 1));
+                const int i0 = x, i1 = x + h, i2 = x + j, i3 = x + j + h;
+                if (i1 < n) {                                // (i0 < i1: with i1 >= n the group holds one real key at most)
+                    uint64_t k0 = k[i0], k1 = k[i1], k2 = ld(i2), k3 = ld(i3);
+                    cx(k0, k2); cx(k1, k3);                  // disperse(j)
+                    cx(k0, k1); cx(k2, k3);                  // disperse(j / 2)
+                    st4(i0, i1, i2, i3, k0, k1, k2, k3);
                 }
             }
         }
+        if (lj == 0) pairs_pass();                           // the leftover disperse(1)
     }
     __syncthreads();
 }
 
 
+// Tiles of up to this many keys are sorted inside render_fwd (in the LDS it stages its splats in afterwards); the binning's own sort
+// launch takes the rest.  Measured with the radix-4 network (tile_sort us / render_fwd us / step us, one call, three rounds):
+// cap 1536: 8.7 / 117.5 / 859;  cap 1024: 14.1 / 116.4 / 861;  with the radix-2 network cap 512 read 31.5 / 112 / 895 -- a lone
+// workgroup's sort is latency bound, so what the forward's heavy tiles save by arriving sorted the extra launch pays twice.
 constexpr int kRenderSortCap = 1536;
