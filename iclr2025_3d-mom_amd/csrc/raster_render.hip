@@ -131,13 +131,17 @@ __device__ __forceinline__ int build_wave_list(const uint8_t* s_mask, uint16_t* 
 // Thread 0 of every workgroup leaves s_memtime at its phase boundaries (words 0-7), s_memrealtime at entry and exit (8, 9: one clock
 // for the chip), XCC_ID | HW_ID (10) and tile | list length (11).  Compiled out of the shipped library.
 #ifdef FWD_STAMPS
-constexpr int kStampWords = 12, kStampGroups = 16384;
+constexpr int kStampWords = 16, kStampGroups = 16384;      // words 12-15: cycles each of the four waves spent at the rounds' barriers (render_fwd)
 __device__ unsigned long long g_fwd_stamps[kStampGroups * kStampWords];
 __device__ unsigned long long g_bwd_stamps[kStampGroups * kStampWords];
 // [kernel 0 fwd / 1 bwd][bucket of live (fwd) or valid (bwd) lanes: 0, 1-2, 3-4, 5-8, 9-16, 17-32, 33-64][0: entries walked, 1: entries that pass the wave-level tests]
 __device__ unsigned long long g_lane_hist[2][7][2];
 __device__ __forceinline__ int lane_bucket(uint64_t m) { const int n = __popcll(m); return n == 0 ? 0 : (n <= 2 ? 1 : (n <= 4 ? 2 : (n <= 8 ? 3 : (n <= 16 ? 4 : (n <= 32 ? 5 : 6))))); }
+#ifdef FWD_LANE_HIST      // (with -DFWD_STAMPS: one global atomic per walked entry -- it stretches the launch a hundredfold, so never together with timing stamps)
 #define LANE_HIST(kernel, mask, passed) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_lane_hist[kernel][lane_bucket(mask)][passed], 1ull); } while (0)
+#else
+#define LANE_HIST(kernel, mask, passed) do { } while (0)
+#endif
 #define FWD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) g_fwd_stamps[blockIdx.x * kStampWords + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define BWD_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) g_bwd_stamps[blockIdx.x * kStampWords + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define STAMP_ID(arr) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) { \
@@ -146,7 +150,11 @@ __device__ __forceinline__ int lane_bucket(uint64_t m) { const int n = __popcll(
 #define STAMP_LIST(arr, tile, n) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) arr[blockIdx.x * kStampWords + 11] = ((unsigned long long)(uint32_t)(tile) << 32) | (uint32_t)(n); } while (0)
 #define STAMP_EXIT(arr) do { if (threadIdx.x == 0 && blockIdx.x < kStampGroups) arr[blockIdx.x * kStampWords + 9] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define BARRIER_T0() const unsigned long long bw0_ = __builtin_amdgcn_s_memtime()
+#define BARRIER_T1() bar_wait_ += __builtin_amdgcn_s_memtime() - bw0_
 #else
+#define BARRIER_T0() do { } while (0)
+#define BARRIER_T1() do { } while (0)
 #define FWD_STAMP(k) do { } while (0)
 #define BWD_STAMP(k) do { } while (0)
 #define STAMP_ID(arr) do { } while (0)
@@ -237,8 +245,13 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     fetch(0);
     STAMP_WAIT();
     FWD_STAMP(3);                                             // round 0's records are in registers
+#ifdef FWD_STAMPS
+    unsigned long long bar_wait_ = 0;
+#endif
     for (int i = 0; i < rounds; i++, toDo -= kRound) {
-        if (__syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256) { walked_rounds = i; break; }
+        bool all_done;
+        { BARRIER_T0(); all_done = __syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256; BARRIER_T1(); }
+        if (all_done) { walked_rounds = i; break; }
         {
             uint32_t reach = 0;
             if (pv) {
@@ -251,7 +264,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
             }
             s_mask[threadIdx.x] = (uint8_t)reach;
         }
-        __syncthreads();
+        { BARRIER_T0(); __syncthreads(); BARRIER_T1(); }
         fetch(i + 1);
         int list[kRoundChunks];
         const int n_w = build_wave_list(s_mask, s_lists[wv], wv, lane, list);
@@ -299,6 +312,9 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     // "entries processed before block exit" (SURVEY 8d's Q = 256 x the sum of this over the tiles): the list is walked in rounds of
     // 256 like the reference's (forward.cu:305-327), and a round is entered unless every pixel of the tile is done.  One plain
     // store per tile into the scatter's cursor array, which nothing reads after the binning.
+#ifdef FWD_STAMPS
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < kStampGroups) g_fwd_stamps[blockIdx.x * kStampWords + 12 + (threadIdx.x >> 6)] = bar_wait_;
+#endif
     FWD_STAMP(4);                                             // wave 0 has left the loop
     if (threadIdx.x == 0) tile_walked[tile] = (uint32_t)min(list_len, walked_rounds * kRound);
     // MomRasterArgs.status_post: the frame's status bits (header word 1, final since the binning) go to a pinned host word with the

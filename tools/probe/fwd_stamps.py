@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 real = C.CDLL(N.LIB_PATH)
 gx, gy = (cfg["W"] + 15) // 16, (cfg["H"] + 15) // 16
 nt = gx * gy
-K = 12
+K = 16
 rows, rows_b = [], []
 for rep in range(5):
     trainer.step(5050 + rep, cams=[cams[(17 * (40 + rep)) % len(cams)]])
@@ -62,6 +62,11 @@ for st in rows[-2:]:
     print(f"  start ramp: entries spread over {(r0.max() - r0.min()) / 100.0:.1f} us (p50 {np.percentile(r0 - r0.min(), 50) / 100:.1f}, "
           f"p99 {np.percentile(r0 - r0.min(), 99) / 100:.1f}); exits p1 {np.percentile(r1 - r0.min(), 1) / 100:.1f} p50 "
           f"{np.percentile(r1 - r0.min(), 50) / 100:.1f} p99 {np.percentile(r1 - r0.min(), 99) / 100:.1f} us")
+    bw = st[:, 12:16].astype(np.float64)                      # cycles each wave spent at the rounds' two barriers
+    loop_c = t[:, 4] - t[:, 3]
+    print(f"  rounds' barriers: the four waves wait {100 * bw.mean() / max(loop_c.mean(), 1):.1f} % of the loop's time on average "
+          f"(the least waiting wave {100 * bw.min(axis=1).mean() / max(loop_c.mean(), 1):.1f} %, the most {100 * bw.max(axis=1).mean() / max(loop_c.mean(), 1):.1f} %); "
+          f"median per workgroup {np.median(bw.mean(axis=1)) / clk / 1e3:.1f} us of a {np.median(loop_c) / clk / 1e3:.1f} us loop")
     tot = d.sum()
     print("  share of the workgroups' summed lifetime (wave 0's view): " + " | ".join(f"{n} {100 * d[:, k].sum() / tot:.1f} %" for k, n in enumerate(names)))
     print("  per workgroup, us (median / p90 / max): " + " | ".join(f"{n} {np.median(d[:, k]) / clk / 1e3:.1f}/{np.percentile(d[:, k], 90) / clk / 1e3:.1f}/{d[:, k].max() / clk / 1e3:.1f}"

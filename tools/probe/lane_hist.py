@@ -1,5 +1,5 @@
 """How many lanes are still compositing (render_fwd: `live`) / contribute (render_bwd: all per-lane tests passed) when a wave walks a
-list entry -- csrc/raster_render.hip built with -DFWD_STAMPS (MOM4D_LIB names that build).  Per camera class: entries walked and
+list entry -- csrc/raster_render.hip built with "-DFWD_STAMPS -DFWD_LANE_HIST" (tools/variants.sh; MOM4D_LIB names that build).  Per camera class: entries walked and
 entries that pass the wave-level reject, by lane-count bucket.  Decides whether a "few live pixels" mode for the tail of a list pays."""
 import ctypes as C, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
