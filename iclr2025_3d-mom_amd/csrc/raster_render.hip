@@ -174,6 +174,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     __shared__ float4 s_rec[kRound * 3];
     __shared__ uint8_t s_mask[kRound];
     __shared__ uint16_t s_lists[4][kRound];
+    __shared__ __attribute__((aligned(16))) uint32_t s_live[4];
     FWD_STAMP(0);
     STAMP_ID(g_fwd_stamps);
     // t0: first tile of this launch's rows (tile-row shard); the tiles come heaviest first (tile_scan)
@@ -182,12 +183,6 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     const bool ordered = order_hdr[3] == (uint32_t)t0 && order_hdr[4] == (uint32_t)nt;
     const int tile = ordered ? (int)tile_order[blockIdx.x] : t0 + remap_tile(blockIdx.x, nt, run);
     const int tx = tile % gx, ty = tile / gx;
-    const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
-    const int ly = kFH * ((threadIdx.x >> 6) / kWX) + (threadIdx.x & 63) / kFW;
-    const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
     uint2 range = ranges[tile];
     if (range.y > capacity) range.y = capacity;
@@ -220,6 +215,14 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
     }
 
     FWD_STAMP(2);                                             // sorted (or nothing to sort)
+    // (the pixel's coordinates are formed HERE, behind the sort: the radix-4 passes hold four 64-bit keys per lane, and with the
+    // pixel state live across them the kernel left its 64-register budget -- 24 bytes of scratch, tests/test_isa.py)
+    const int lx = kFW * ((threadIdx.x >> 6) % kWX) + (threadIdx.x & 63) % kFW;       // wave footprint: see strip_reach_mask
+    const int ly = kFH * ((threadIdx.x >> 6) / kWX) + (threadIdx.x & 63) / kFW;
+    const int px = tx * MOM_TILE + lx, py = ty * MOM_TILE + ly;
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float T = 1.0f;
     uint32_t last_contributor = 0;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
@@ -248,16 +251,24 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
 #ifdef FWD_STAMPS
     unsigned long long bar_wait_ = 0;
 #endif
+    // "every pixel of the tile is done" (forward.cu:305-312) from four wave-uniform flags: each wave leaves `live != 0` in LDS at the
+    // end of a round, and the barrier that protects the staging area anyway makes the four flags visible.  (__syncthreads_count
+    // compiled into a DPP reduction, an LDS atomic and THREE barriers per round.)
+    if (lane == 0) s_live[wv] = live != 0;
     for (int i = 0; i < rounds; i++, toDo -= kRound) {
-        bool all_done;
-        { BARRIER_T0(); all_done = __syncthreads_count(!__builtin_amdgcn_inverse_ballot_w64(live)) == 256; BARRIER_T1(); }
-        if (all_done) { walked_rounds = i; break; }
+        { BARRIER_T0(); __syncthreads(); BARRIER_T1(); }
+        const uint4 lv = *reinterpret_cast<const uint4*>(s_live);
+        if (__builtin_amdgcn_readfirstlane((int)(lv.x | lv.y | lv.z | lv.w)) == 0) { walked_rounds = i; break; }
         {
             uint32_t reach = 0;
             if (pv) {
                 float4 q0 = p0;
                 q0.w = power_bound(p1.w);
-                reach = strip_reach_mask(q0, p1, (float)(tx * MOM_TILE), (float)(ty * MOM_TILE));
+                // (the tile's origin goes through an opaque scalar: left alone the compiler hoists the four strips' rectangle bounds --
+                // eight wave-uniform floats -- out of the rounds into vector registers the compositing loop has no room for)
+                int ox = tx * MOM_TILE, oy = ty * MOM_TILE;
+                asm volatile("" : "+s"(ox), "+s"(oy));
+                reach = strip_reach_mask(q0, p1, (float)ox, (float)oy);
                 s_rec[threadIdx.x * 3 + 0] = q0;
                 s_rec[threadIdx.x * 3 + 1] = p1;
                 s_rec[threadIdx.x * 3 + 2] = p2;
@@ -308,6 +319,7 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
                 }
             }
         }
+        if (lane == 0) s_live[wv] = live != 0;                // (read behind the next round's first barrier)
     }
     // "entries processed before block exit" (SURVEY 8d's Q = 256 x the sum of this over the tiles): the list is walked in rounds of
     // 256 like the reference's (forward.cu:305-327), and a round is entered unless every pixel of the tile is done.  One plain
