@@ -294,6 +294,11 @@ render_fwd_kernel(const uint2* __restrict__ ranges, uint32_t* point_list /* read
                 const char* rec_j = reinterpret_cast<const char*>(s_rec) + rec_off;
                 const float4 r0 = *reinterpret_cast<const float4*>(rec_j);
                 const float4 r1 = *reinterpret_cast<const float4*>(rec_j + 16);
+                // the opacity arrives WITH the conic, as one b128: left alone the compiler reads three dwords here and the fourth behind the
+                // reject test -- which 98 % of the walked entries pass (tools/probe/lane_hist.py) -- i.e. a second LDS round trip on every
+                // entry's dependent chain: 121.4 -> 114.2 us.  (The colour record as well: three more live registers, 16 bytes of scratch, 115.0;
+                // with the four list registers packed into one to make room for it: 113.7 against 113.8 -- its round trip is not on the chain.)
+                asm volatile("" :: "v"(r1.w));
                 float dx, dy;
                 const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
                 uint64_t vm = live & __builtin_amdgcn_ballot_w64(!(power < r0.w)) & __builtin_amdgcn_ballot_w64(!(power > 0.0f));
@@ -642,6 +647,12 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
             const char* rec_j = reinterpret_cast<const char*>(s_rec) + rec_off;
             const float4 r0 = *reinterpret_cast<const float4*>(rec_j);
             const float4 r1 = *reinterpret_cast<const float4*>(rec_j + 16);
+            // both records as ONE b128 each, complete before the exponent: left alone the compiler fetches them in four pieces and the
+            // opacity behind the reject test, a second LDS round trip per pair (198.7 -> 197.0 us, one call, three rounds)
+            asm volatile("" :: "v"(r0.x), "v"(r0.y), "v"(r0.z), "v"(r0.w), "v"(r1.x), "v"(r1.y), "v"(r1.z), "v"(r1.w));
+            // ... and the colour record with them (the register budget at five waves per SIMD has room: 193.8 -> 192.5 us)
+            const float4 r2 = *reinterpret_cast<const float4*>(rec_j + 32);
+            asm volatile("" :: "v"(r2.x), "v"(r2.y), "v"(r2.z));
             float dx, dy;
             const float power = splat_power(r0, r1, pxf, pyf, dx, dy);
             if (!__any(!(power < r0.w))) continue;         // no lane of the wave can reach 1/255 (power_bound)
@@ -668,7 +679,6 @@ render_bwd_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__
                 // the two forms measured the same, 204.5 against 205 us)
                 float alpha, G;
                 asm("v_cndmask_b32_e64 %0, 0, %2, %4\n\tv_cndmask_b32_e64 %1, 0, %3, %4" : "=&v"(alpha), "=v"(G) : "v"(alpha_in), "v"(G_in), "s"(vmask));
-                const float4 r2 = *reinterpret_cast<const float4*>(rec_j + 32);
                 // the reference divides (T = T / (1 - alpha), backward.cu:502); the hardware reciprocal is within 1 ulp of that
                 // quotient and costs one instruction instead of ten
                 const float one_m_alpha = 1.f - alpha;
