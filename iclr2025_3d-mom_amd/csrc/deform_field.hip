@@ -129,6 +129,19 @@ __device__ __forceinline__ float4 mul44(float4 a, float4 b) { return make_float4
 //   R0 = {byte offset of texel (y0,x0) of plane (x,y) | hx | hy << 1,  same of (z0,x0) of (x,z) | hz << 1,  same of (z0,y0) of
 //         (y,z),  x0 | y0 << 10 | z0 << 20}      hx / hy / hz: the cell's upper neighbour along that axis is inside
 //   R1 = {bx, by, bz, -}                        fractions; 1 - b is ATen's lower weight bit for bit (Sterbenz)
+// a.res[lvl][k] for a level that differs between the lanes of a wave, picked from the four scalar values: indexed with a vector
+// register the argument block is read from memory, one load per axis, each issued behind the previous axis' clip branches and
+// waited for on the spot (three more round trips on a chain that has two to begin with: order -> position).
+__device__ __forceinline__ int res_of(const HexArgs& a, int lvl, int k)
+{
+    int r0 = a.res[0][k], r1 = a.res[1][k], r2 = a.res[2][k], r3 = a.res[3][k];
+    asm volatile("" : "+s"(r0), "+s"(r1), "+s"(r2), "+s"(r3));       // (opaque: the compiler turns a select of loads into a load of the selected address)
+    int r = r0;
+    r = lvl == 1 ? r1 : r;
+    r = lvl == 2 ? r2 : r;
+    r = lvl == 3 ? r3 : r;
+    return r;
+}
 __device__ __forceinline__ void make_record(const HexArgs& a, const float* __restrict__ xyz, int g, int lvl, uint4& R0, float4& R1)
 {
     float c[4];
@@ -136,15 +149,16 @@ __device__ __forceinline__ void make_record(const HexArgs& a, const float* __res
     int i0[3];
     float b[3];
     bool hn[3];
+    const int res[3] = {res_of(a, lvl, 0), res_of(a, lvl, 1), res_of(a, lvl, 2)};
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         float gm;
-        const float ix = unnorm_clip(c[k], a.res[lvl][k], gm);
+        const float ix = unnorm_clip(c[k], res[k], gm);
         i0[k] = (int)floorf(ix);
         b[k] = ix - (float)i0[k];
-        hn[k] = i0[k] + 1 < a.res[lvl][k];
+        hn[k] = i0[k] + 1 < res[k];
     }
-    const unsigned Wx = (unsigned)a.res[lvl][0], Wy = (unsigned)a.res[lvl][1];
+    const unsigned Wx = (unsigned)res[0], Wy = (unsigned)res[1];
     R0.x = ((unsigned)i0[1] * Wx + (unsigned)i0[0]) * 128u | (hn[0] ? 1u : 0u) | (hn[1] ? 2u : 0u);
     R0.y = ((unsigned)i0[2] * Wx + (unsigned)i0[0]) * 128u | (hn[2] ? 2u : 0u);
     R0.z = ((unsigned)i0[2] * Wy + (unsigned)i0[1]) * 128u;
@@ -180,26 +194,32 @@ __device__ __forceinline__ void gather_tile(const HexArgs& a, const LineTab& lt,
     // phase B: eight lanes per unit; pass u = 4 lvl + i covers the gaussians 8 i .. 8 i + 7 of the tile at level lvl
     const int g8 = lane >> 3, c = lane & 7;
     const unsigned cb = (unsigned)c * 16u;
-    auto issue = [&](int u, UnitLoads& L) {
-        const int lvl = u >> 2, gl = 8 * (u & 3) + g8;
+    // what a pass needs of its level: read from the argument block ONCE per level (indexed by the pass number inside the pass loop,
+    // every pass began with three dependent scalar loads -- level -> plane pointer / line offset -> ... -- ahead of its 18 rows)
+    struct LevelTab {
+        unsigned rowx, rowy;
+        const float *pxy, *pxz, *pyz, *lx, *ly, *lz;
+    };
+    auto issue = [&](int lvl, int i, const LevelTab& T, UnitLoads& L) {
+        const int gl = 8 * i + g8;
         const uint4 R0 = rec[2 * (32 * lvl + gl)];
         const uint4 R1u = rec[2 * (32 * lvl + gl) + 1];
         L.bx = __uint_as_float(R1u.x); L.by = __uint_as_float(R1u.y); L.bz = __uint_as_float(R1u.z);
         L.gl = gl;
-        const unsigned rowx = (unsigned)a.res[lvl][0] * 128u, rowy = (unsigned)a.res[lvl][1] * 128u;
+        const unsigned rowx = T.rowx, rowy = T.rowy;
         const unsigned sx = (R0.x & 1u) ? 128u : 0u, sy = (R0.x & 2u) ? 128u : 0u, sz = (R0.y & 2u) ? 128u : 0u;
         const unsigned ry_x = (R0.x & 2u) ? rowx : 0u, rz_x = (R0.y & 2u) ? rowx : 0u, rz_y = (R0.y & 2u) ? rowy : 0u;
         const unsigned x0 = R0.w & 1023u, y0 = (R0.w >> 10) & 1023u, z0 = R0.w >> 20;
-        const float* __restrict__ pxy = a.planes[lvl][0];
-        const float* __restrict__ pxz = a.planes[lvl][1];
-        const float* __restrict__ pyz = a.planes[lvl][3];
+        const float* __restrict__ pxy = T.pxy;
+        const float* __restrict__ pxz = T.pxz;
+        const float* __restrict__ pyz = T.pyz;
         const unsigned oxy = (R0.x & ~127u) + cb, oxz = (R0.y & ~127u) + cb, oyz = (R0.z & ~127u) + cb;
         L.t[0] = ld4(pxy, oxy); L.t[1] = ld4(pxy, oxy + sx); L.t[2] = ld4(pxy, oxy + ry_x); L.t[3] = ld4(pxy, oxy + sx + ry_x);
         L.t[4] = ld4(pxz, oxz); L.t[5] = ld4(pxz, oxz + sx); L.t[6] = ld4(pxz, oxz + rz_x); L.t[7] = ld4(pxz, oxz + sx + rz_x);
         L.t[8] = ld4(pyz, oyz); L.t[9] = ld4(pyz, oyz + sy); L.t[10] = ld4(pyz, oyz + rz_y); L.t[11] = ld4(pyz, oyz + sy + rz_y);
-        const float* __restrict__ lx = lines + lt.off[lvl][0];
-        const float* __restrict__ ly = lines + lt.off[lvl][1];
-        const float* __restrict__ lz = lines + lt.off[lvl][2];
+        const float* __restrict__ lx = T.lx;
+        const float* __restrict__ ly = T.ly;
+        const float* __restrict__ lz = T.lz;
         L.t[12] = ld4(lx, x0 * 128u + cb); L.t[13] = ld4(lx, x0 * 128u + cb + sx);
         L.t[14] = ld4(ly, y0 * 128u + cb); L.t[15] = ld4(ly, y0 * 128u + cb + sy);
         L.t[16] = ld4(lz, z0 * 128u + cb); L.t[17] = ld4(lz, z0 * 128u + cb + sz);
@@ -211,8 +231,7 @@ __device__ __forceinline__ void gather_tile(const HexArgs& a, const LineTab& lt,
         v = fma4(t[3], b0 * b1, v);
         return v;
     };
-    auto finish = [&](int u, const UnitLoads& L) {
-        const int lvl = u >> 2;
+    auto finish = [&](int lvl, const UnitLoads& L) {
         const float bx = L.bx, by = L.by, bz = L.bz, ax = 1.f - bx, ay = 1.f - by, az = 1.f - bz;
         // reference order of the product: (x,y) (x,z) (x,t) (y,z) (y,t) (z,t)
         float4 f = mul44(space(L.t, ax, bx, ay, by), space(L.t + 4, ax, bx, az, bz));
@@ -227,10 +246,15 @@ __device__ __forceinline__ void gather_tile(const HexArgs& a, const LineTab& lt,
         }
     };
 #pragma unroll 1
-    for (int u = 0; u < 8; u++) {        // one pass in flight per wave
-        UnitLoads LA;
-        issue(u, LA);
-        finish(u, LA);
+    for (int lvl = 0; lvl < 2; lvl++) {
+        const LevelTab T = {(unsigned)a.res[lvl][0] * 128u, (unsigned)a.res[lvl][1] * 128u, a.planes[lvl][0], a.planes[lvl][1], a.planes[lvl][3],
+                            lines + lt.off[lvl][0], lines + lt.off[lvl][1], lines + lt.off[lvl][2]};
+#pragma unroll 1
+        for (int i = 0; i < 4; i++) {    // one pass in flight per wave
+            UnitLoads LA;
+            issue(lvl, i, T, LA);
+            finish(lvl, LA);
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -657,30 +681,44 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
     const unsigned cb = (unsigned)c * 16u;
     const size_t plane_floats = (size_t)a.P * 32;
 
-    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
-        // phase A: lane = unit (point lane & 31 of the chunk, level lane >> 5)
+    auto point_of = [&](int chunk) {
         const int gi = chunk * 32 + (lane & 31);
-        const int g_mine = gi < a.P ? (a.order ? (int)a.order[gi] : gi) : -1;
+        return chunk < nchunks && gi < a.P ? (a.order ? (int)a.order[gi] : gi) : -1;
+    };
+    int g_next = point_of(wave);
+    asm volatile("" :: "v"(g_next));      // (waited for HERE: with it pending at the loop's head the compiler waits for the prefetch below too)
+    for (int chunk = wave; chunk < nchunks; chunk += nwaves) {
+        // phase A: lane = unit (point lane & 31 of the chunk, level lane >> 5).  Its chain of dependent round trips is order ->
+        // {position, order slots} -> 19 rows; the next chunk's first link is asked for here, a chunk ahead.
+        const int g_mine = g_next;
+        g_next = point_of(chunk + nwaves);
         __builtin_amdgcn_wave_barrier();
         {
-            const int lvl = lane >> 5;
+            int lvl = lane >> 5;
+            asm volatile("" : "+v"(lvl));        // (opaque: the per-lane addresses built from it are NOT kept in registers across phase B)
             uint4 R0 = make_uint4(0, 0, 0, 0), R2 = make_uint4(0, 0, 0, 0), R3 = make_uint4(0, 0, 0, 0xffffffffu);
             float4 R1 = make_float4(0.f, 0.f, 0.f, 0.f);
             if (g_mine >= 0) {
+                // the three order slots are asked for together with the position (make_record), not behind its clip branches
+                uint32_t iv[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) iv[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine];
                 make_record(a, xyz, g_mine, lvl, R0, R1);
                 float cc[4];
                 norm_coords(a, xyz, g_mine, cc);
+                asm volatile("" :: "v"(iv[0]), "v"(iv[1]), "v"(iv[2]), "v"(cc[0]), "v"(cc[1]), "v"(cc[2]));
                 float gm[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     float m;
-                    (void)unnorm_clip(cc[k], a.res[lvl][k], m);
+                    const int res = res_of(a, lvl, k);
+                    (void)unnorm_clip(cc[k], res, m);
                     // d(ix)/d(world coordinate): (size-1)/2 * 2/(aabb1 - aabb0), 0 where the coordinate was clipped at the border
-                    gm[k] = m != 0.f ? ((float)(a.res[lvl][k] - 1) / 2.f) * (2.0f / (a.a1[k] - a.a0[k])) : 0.f;
+                    gm[k] = m != 0.f ? ((float)(res - 1) / 2.f) * (2.0f / (a.a1[k] - a.a0[k])) : 0.f;
                 }
                 R2 = make_uint4(__float_as_uint(gm[0]), __float_as_uint(gm[1]), __float_as_uint(gm[2]), 0u);
 #pragma unroll
-                for (int k = 0; k < 3; k++) (&R3.x)[k] = inv[((size_t)k * a.levels + lvl) * a.P + g_mine] * (CROWS ? 128u : 256u);   // CROWS: [slot][level][position][32], else [..][position][space | time][32]
+                for (int k = 0; k < 3; k++) (&R3.x)[k] = iv[k] * (CROWS ? 128u : 256u);   // CROWS: [slot][level][position][32], else [..][position][space | time][32]
                 R3.w = (unsigned)g_mine;
             }
             rec[4 * lane] = R0;
@@ -720,6 +758,14 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
                 t[16] = ld4(lz, z0 * 128u + cb); t[17] = ld4(lz, z0 * 128u + cb + sz);
                 float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (live) go = *reinterpret_cast<const float4*>(dfeat + (size_t)R3.w * (a.levels * 32) + 32 * lvl + 4 * c);
+                // (the row of dxyz this pass adds to, with the same batch: read at the point of the addition it was one more round
+                // trip per pass, waited for on the spot)
+                const bool adds = lvl == 1 && dxyz && live && c == 0;
+                float dold[3] = {0.f, 0.f, 0.f};
+                if (adds) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) dold[k] = dxyz[3 * (size_t)R3.w + k];
+                }
                 // bilinear sample and the two raw derivatives of a space plane (corners nw ne sw se; b0 along the row, b1 across rows)
                 float4 v[6], da[6], db[3];
                 auto space = [&](const float4* q, float b0, float b1, float4& val, float4& d_first, float4& d_second) {
@@ -784,11 +830,11 @@ hexplane_bwd6_gather_kernel(HexArgs a, LineTab lt, int nchunks, const float* __r
                 gy = unit_sum(gy) * __uint_as_float(R2.y);
                 gz = unit_sum(gz) * __uint_as_float(R2.z);
                 if (lvl == 0) { gsum[i][0] = gx; gsum[i][1] = gy; gsum[i][2] = gz; }
-                else if (dxyz && live && c == 0) {
+                else if (adds) {
                     float* d = dxyz + 3 * (size_t)R3.w;
-                    d[0] += gsum[i][0] + gx;
-                    d[1] += gsum[i][1] + gy;
-                    d[2] += gsum[i][2] + gz;
+                    d[0] = dold[0] + (gsum[i][0] + gx);
+                    d[1] = dold[1] + (gsum[i][1] + gy);
+                    d[2] = dold[2] + (gsum[i][2] + gz);
                 }
             }
         }
