@@ -1,3 +1,3 @@
 #!/bin/bash
 V=iclr2025_3d-mom_amd/lib/var
-MOM4D_LIB=$PWD/$V/f1.so python -m pytest tests/test_deform_field_gpu.py tests/test_ops_gpu.py tests/test_fused_step_gpu.py tests/test_golden_gpu.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -5
+for r in 1 2; do for v in h0 h1 h2; do KBENCH_FREEZE=1 MOM4D_LIB=$PWD/$V/$v.so python tools/kbench.py hexplane_bwd 2>/dev/null | tail -1; done; done
