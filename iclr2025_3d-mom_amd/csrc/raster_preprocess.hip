@@ -77,17 +77,61 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
     if (HIST)
         for (int t = threadIdx.x; t < n_tiles; t += 256) s_cnt[t] = 0u;
     const int sh_stride = (a.M - 1) * 3;
+    // Everything this thread reads of its Gaussian, asked for in ONE go and before the SH rows are staged.  Read where it is used,
+    // each item sat behind the cull test before it -- position -> scale + rotation -> DC colour, one channel at a time -> opacity:
+    // seven dependent round trips in a kernel whose workgroups live as long as their longest chain.
+    const bool live = idx < a.P;
+    const int gi = live ? idx : 0;                 // lanes past the end (HIST keeps them for the ballots) read Gaussian 0 and discard
+    float px = a.means3D[3 * gi], py = a.means3D[3 * gi + 1], pz = a.means3D[3 * gi + 2];
+    float in_c3[6], in_s[3], in_q[4], in_col[3];
+    {
+        // (no branch around either form of the covariance's inputs -- the values would be waited for where the branches join:
+        // the form that is absent reads the view matrix, 16 floats that are always there, and is never looked at)
+        const float* __restrict__ p6 = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)gi : a.view;
+        const float* __restrict__ p3 = a.cov3D_precomp ? a.view : a.scales + 3 * (size_t)gi;
+        const float* __restrict__ p4 = a.cov3D_precomp ? a.view : a.rotations + 4 * (size_t)gi;
+#pragma unroll
+        for (int i = 0; i < 6; i++) in_c3[i] = p6[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) in_s[i] = p3[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) in_q[i] = p4[i];
+        // the DC coefficient (one [P,M,3] tensor, or DC and rest stored apart) or the caller's colour
+        const float* __restrict__ col = a.colors_precomp ? a.colors_precomp + 3 * (size_t)gi : a.shs + (size_t)gi * (a.shs_rest ? 1 : a.M) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) in_col[c] = col[c];
+    }
+    float in_opacity = a.opacities[gi];
     if (STAGED) {
         const int block0 = blockIdx.x * 256;
         const int n = min(256, a.P - block0) * sh_stride;
         const float* __restrict__ src = a.shs_rest + (size_t)block0 * sh_stride;
         const int n4 = n >> 2;
-        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(s_sh)[i] = reinterpret_cast<const float4*>(src)[i];
+        // (all of a thread's pieces in flight at once -- at most 12 with rows of 45 floats; as a loop they were taken in three
+        // batches, each waited for before the next was asked for.  The index is clamped, not tested: a load under a test is
+        // waited for where the test ends)
+        float4 piece[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) piece[k] = reinterpret_cast<const float4*>(src)[min((int)threadIdx.x + 256 * k, n4 - 1)];
+        // (and all of them are values of the straight-line code: used only under the tests below, each load is moved into its test)
+        asm("" : "+v"(piece[0].x), "+v"(piece[0].y), "+v"(piece[0].z), "+v"(piece[0].w), "+v"(piece[1].x), "+v"(piece[1].y), "+v"(piece[1].z), "+v"(piece[1].w), "+v"(piece[2].x), "+v"(piece[2].y), "+v"(piece[2].z), "+v"(piece[2].w), "+v"(piece[3].x), "+v"(piece[3].y), "+v"(piece[3].z), "+v"(piece[3].w), "+v"(piece[4].x), "+v"(piece[4].y), "+v"(piece[4].z), "+v"(piece[4].w), "+v"(piece[5].x), "+v"(piece[5].y), "+v"(piece[5].z), "+v"(piece[5].w));
+        asm("" : "+v"(piece[6].x), "+v"(piece[6].y), "+v"(piece[6].z), "+v"(piece[6].w), "+v"(piece[7].x), "+v"(piece[7].y), "+v"(piece[7].z), "+v"(piece[7].w), "+v"(piece[8].x), "+v"(piece[8].y), "+v"(piece[8].z), "+v"(piece[8].w), "+v"(piece[9].x), "+v"(piece[9].y), "+v"(piece[9].z), "+v"(piece[9].w), "+v"(piece[10].x), "+v"(piece[10].y), "+v"(piece[10].z), "+v"(piece[10].w), "+v"(piece[11].x), "+v"(piece[11].y), "+v"(piece[11].z), "+v"(piece[11].w));
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < n4) reinterpret_cast<float4*>(s_sh)[i] = piece[k];
+        }
         for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) s_sh[i] = src[i];
         __syncthreads();
     } else if (HIST) {
         __syncthreads();
     }
+    // All of it complete HERE, not one by one behind the tests below.  (Not `asm volatile`: with no memory operands that still counts
+    // as a possible store, and the uniform loads of the view / projection matrices behind it become vector loads -- three more
+    // round trips; an asm with outputs only makes the values opaque.)
+    asm("" : "+v"(px), "+v"(py), "+v"(pz), "+v"(in_c3[0]), "+v"(in_c3[1]), "+v"(in_c3[2]), "+v"(in_c3[3]), "+v"(in_c3[4]), "+v"(in_c3[5]),
+        "+v"(in_s[0]), "+v"(in_s[1]), "+v"(in_s[2]), "+v"(in_q[0]), "+v"(in_q[1]), "+v"(in_q[2]), "+v"(in_q[3]), "+v"(in_col[0]),
+        "+v"(in_col[1]), "+v"(in_col[2]), "+v"(in_opacity));
     if (!HIST && idx >= a.P) return;
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
@@ -98,10 +142,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
     float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f}, r2 = {0.f, 0.f, 0.f, 0.f};
     uchar4 cl = {0, 0, 0, 0};
     int hx0 = 0, hy0 = 0, hx1 = 0, hy1 = 0;        // the rectangle of tiles (HIST)
-    const bool live = idx < a.P;
-    const int gi = live ? idx : 0;                 // lanes past the end (HIST keeps them for the ballots) read Gaussian 0 and discard
-
-    const float px = a.means3D[3 * gi], py = a.means3D[3 * gi + 1], pz = a.means3D[3 * gi + 2];
     // near cull: keep iff p_view.z > 0.2
     const float vx = view[0] * px + view[4] * py + view[8] * pz + view[12];
     const float vy = view[1] * px + view[5] * py + view[9] * pz + view[13];
@@ -117,15 +157,14 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
         float c3[6];
         if (a.cov3D_precomp != nullptr) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * gi + i];
+            for (int i = 0; i < 6; i++) c3[i] = in_c3[i];
         } else {
             const float mod = a.scale_modifier;
             M3 S = {{{1.f, 0.f, 0.f}, {0.f, 1.f, 0.f}, {0.f, 0.f, 1.f}}};
-            S.m[0][0] = mod * a.scales[3 * gi];
-            S.m[1][1] = mod * a.scales[3 * gi + 1];
-            S.m[2][2] = mod * a.scales[3 * gi + 2];
-            const float r = a.rotations[4 * gi], x = a.rotations[4 * gi + 1], y = a.rotations[4 * gi + 2],
-                        z = a.rotations[4 * gi + 3];
+            S.m[0][0] = mod * in_s[0];
+            S.m[1][1] = mod * in_s[1];
+            S.m[2][2] = mod * in_s[2];
+            const float r = in_q[0], x = in_q[1], y = in_q[2], z = in_q[3];
             M3 Rm = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                       {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
                       {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
@@ -175,14 +214,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             float dx = px - cam[0], dy = py - cam[1], dz = pz - cam[2];
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             dx = dx / len; dy = dy / len; dz = dz / len;
-            // coefficient i of this Gaussian: one [P,M,3] tensor, or DC and rest stored apart
-            const float* sh0 = a.shs + (size_t)gi * (a.shs_rest ? 1 : a.M) * 3;
+            // coefficient i >= 1 of this Gaussian: one [P,M,3] tensor, or DC and rest stored apart
             const float* sh = STAGED ? s_sh + threadIdx.x * sh_stride - 3
-                                     : (a.shs_rest ? a.shs_rest + (size_t)gi * (a.M - 1) * 3 - 3 : sh0);   // sh[3*i+c] valid for i >= 1
+                                     : (a.shs_rest ? a.shs_rest + (size_t)gi * (a.M - 1) * 3 - 3 : a.shs + (size_t)gi * a.M * 3);   // sh[3*i+c] valid for i >= 1
             float res[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                float v = kSH_C0 * sh0[c];
+                float v = kSH_C0 * in_col[c];
                 if (a.D > 0) {
                     const float x = dx, y = dy, z = dz;
                     v = v - kSH_C1 * y * sh[3 + c] + kSH_C1 * z * sh[6 + c] - kSH_C1 * x * sh[9 + c];
@@ -206,13 +244,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreArgs a, int* __r
             cl.x = res[0] < 0; cl.y = res[1] < 0; cl.z = res[2] < 0;
             cr = fmaxf(res[0], 0.0f); cg = fmaxf(res[1], 0.0f); cb = fmaxf(res[2], 0.0f);
         } else {
-            cr = a.colors_precomp[3 * gi]; cg = a.colors_precomp[3 * gi + 1]; cb = a.colors_precomp[3 * gi + 2];
+            cr = in_col[0]; cg = in_col[1]; cb = in_col[2];
         }
         radius = (int)my_radius;
         tiles = cnt;
         hx0 = x0; hy0 = y0; hx1 = x1; hy1 = y1;
         r0 = make_float4(pix, piy, vz, __uint_as_float(tiles));
-        r1 = make_float4(conx, cony, conz, a.opacities[gi]);
+        r1 = make_float4(conx, cony, conz, in_opacity);
         r2 = make_float4(cr, cg, cb, __int_as_float(radius));
     } while (0);
 
