@@ -67,26 +67,65 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     const int sh_stride = (a.M - 1) * 3;
     const int block0 = blockIdx.x * 256;
     const int n_stage = STAGED ? min(256, a.P - block0) * sh_stride : 0;
+    // Everything this thread reads of its Gaussian, asked for in ONE go, before the SH rows are staged and whether or not the frame saw
+    // it (read where used, the items queued behind one another: radius -> accumulator record -> conic -> position + covariance ->
+    // clamp flags -> rotation + scale, behind a staging loop that waited for each of its eleven pieces in turn -- see the same change
+    // in raster_preprocess.hip).  An absent optional input reads the view matrix, 16 floats that are always there.
+    const int gi = min(idx, a.P - 1);
+    int in_radius = a.radii[gi];
+    float ga[10], in_m[3], in_c3[6], in_q[4], in_s[3];
+    float4 in_co = a.rec[3 * (size_t)gi + 1];
+#pragma unroll
+    for (int i = 0; i < 10; i++) ga[i] = a.gacc[(size_t)gi * MOM_GACC_FLOATS + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) in_m[i] = a.means3D[3 * gi + i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) in_c3[i] = a.cov3D[6 * (size_t)gi + i];
+    {
+        const float* __restrict__ p4 = a.scales ? a.rotations + 4 * (size_t)gi : a.view;
+        const float* __restrict__ p3 = a.scales ? a.scales + 3 * (size_t)gi : a.view;
+#pragma unroll
+        for (int i = 0; i < 4; i++) in_q[i] = p4[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) in_s[i] = p3[i];
+    }
+    unsigned in_cl = *reinterpret_cast<const unsigned*>(a.colors_from_sh ? reinterpret_cast<const void*>(a.clamped + gi) : reinterpret_cast<const void*>(a.view));
     if (STAGED) {
         const float* __restrict__ src = a.shs_rest + (size_t)block0 * sh_stride;
         const int n4 = n_stage >> 2;
-        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(s_sh)[i] = reinterpret_cast<const float4*>(src)[i];
+        // all of a thread's pieces in flight at once (at most 12 with rows of 45 floats); the index is clamped, not tested, and the
+        // values are made opaque in the straight-line code: a load under a test, or used only under one, is waited for on the spot
+        // (the first statement names one value of every other group of loads, so that all of them are asked for ahead of it)
+        float4 piece[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) piece[k] = reinterpret_cast<const float4*>(src)[min((int)threadIdx.x + 256 * k, n4 - 1)];
+        asm("" : "+v"(piece[0].x), "+v"(piece[0].y), "+v"(piece[0].z), "+v"(piece[0].w), "+v"(piece[1].x), "+v"(piece[1].y), "+v"(piece[1].z), "+v"(piece[1].w), "+v"(piece[2].x), "+v"(piece[2].y), "+v"(piece[2].z), "+v"(piece[2].w), "+v"(piece[3].x), "+v"(piece[3].y), "+v"(piece[3].z), "+v"(piece[3].w), "+v"(piece[4].x), "+v"(piece[4].y), "+v"(piece[4].z), "+v"(piece[4].w), "+v"(piece[5].x), "+v"(piece[5].y), "+v"(piece[5].z), "+v"(piece[5].w), "+v"(piece[11].w), "+v"(in_cl), "+v"(in_s[2]), "+v"(in_c3[5]), "+v"(ga[9]), "+v"(in_m[2]));
+        asm("" : "+v"(piece[6].x), "+v"(piece[6].y), "+v"(piece[6].z), "+v"(piece[6].w), "+v"(piece[7].x), "+v"(piece[7].y), "+v"(piece[7].z), "+v"(piece[7].w), "+v"(piece[8].x), "+v"(piece[8].y), "+v"(piece[8].z), "+v"(piece[8].w), "+v"(piece[9].x), "+v"(piece[9].y), "+v"(piece[9].z), "+v"(piece[9].w), "+v"(piece[10].x), "+v"(piece[10].y), "+v"(piece[10].z), "+v"(piece[10].w), "+v"(piece[11].x), "+v"(piece[11].y), "+v"(piece[11].z), "+v"(piece[11].w));
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < n4) reinterpret_cast<float4*>(s_sh)[i] = piece[k];
+        }
         for (int i = 4 * n4 + threadIdx.x; i < n_stage; i += 256) s_sh[i] = src[i];
         __syncthreads();
     }
+    // (outputs only, not `asm volatile`: that counts as a possible store and turns the uniform matrix loads below into vector loads)
+    asm("" : "+v"(in_radius), "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]), "+v"(ga[7]), "+v"(ga[8]), "+v"(ga[9]), "+v"(in_co.x), "+v"(in_co.y), "+v"(in_co.z), "+v"(in_co.w));
+    asm("" : "+v"(in_m[0]), "+v"(in_m[1]), "+v"(in_m[2]), "+v"(in_c3[0]), "+v"(in_c3[1]), "+v"(in_c3[2]), "+v"(in_c3[3]), "+v"(in_c3[4]), "+v"(in_c3[5]), "+v"(in_q[0]), "+v"(in_q[1]), "+v"(in_q[2]), "+v"(in_q[3]), "+v"(in_s[0]), "+v"(in_s[1]), "+v"(in_s[2]), "+v"(in_cl));
     if (idx < a.P) {
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
-    const bool vis = a.radii[idx] > 0;
+    const bool vis = in_radius > 0;
 
-    float ga[10];
+    if (!vis) {
 #pragma unroll
-    for (int i = 0; i < 10; i++) ga[i] = vis ? a.gacc[(size_t)idx * MOM_GACC_FLOATS + i] : 0.f;
+        for (int i = 0; i < 10; i++) ga[i] = 0.f;
+    }
     // the compositing backward leaves raw sums (raster_render.hip): for the mean, S_x = sum a dx and S_y = sum a dy -- the conic
     // matrix that turns them into dL/d mean (backward.cu:573-579: a (conic (dx, dy))) is the Gaussian's own, so it is applied here,
     // once per Gaussian, instead of there, once per (pixel, splat) pair -- then d(pixel)/d(ndc) with the sign; -1/2 for the conic
     if (vis) {
-        const float4 co = a.rec[3 * (size_t)idx + 1];
+        const float4 co = in_co;
         const float sx = ga[0], sy = ga[1];
         ga[0] = sx * co.x + sy * co.y;
         ga[1] = sy * co.z + sx * co.y;
@@ -115,8 +154,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     float* dshr = STAGED ? s_sh + threadIdx.x * sh_stride - 3 : (split ? a.dsh_rest + (size_t)idx * (a.M - 1) * 3 - 3 : dsh);
 
     if (vis) {
-        const float mx = a.means3D[3 * idx], my = a.means3D[3 * idx + 1], mz = a.means3D[3 * idx + 2];
-        const float* c3 = a.cov3D + 6 * (size_t)idx;
+        const float mx = in_m[0], my = in_m[1], mz = in_m[2];
+        const float* c3 = in_c3;
         // ---- cov2D backward (backward.cu:144-274) ----
         float tx = view[0] * mx + view[4] * my + view[8] * mz + view[12];
         float ty = view[1] * mx + view[5] * my + view[9] * mz + view[13];
@@ -201,7 +240,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
             const float* sh0 = a.shs + (size_t)idx * (a.shs_rest ? 1 : a.M) * 3;
             const float* sh = STAGED ? s_sh + threadIdx.x * sh_stride - 3
                                      : (a.shs_rest ? a.shs_rest + (size_t)idx * (a.M - 1) * 3 - 3 : sh0);
-            const uchar4 cl = a.clamped[idx];
+            const uchar4 cl = make_uchar4(in_cl & 255u, (in_cl >> 8) & 255u, (in_cl >> 16) & 255u, in_cl >> 24);
             const float dRGB[3] = {cl.x ? 0.f : ga[6], cl.y ? 0.f : ga[7], cl.z ? 0.f : ga[8]};
             float ddir[3] = {0.f, 0.f, 0.f};
 #define SH(i, c) sh[(i) * 3 + (c)]
@@ -272,13 +311,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
 
         // ---- cov3D backward (backward.cu:278-341), no quaternion-normalisation Jacobian ----
         if (a.scales) {
-            const float r = a.rotations[4 * idx], x = a.rotations[4 * idx + 1], y = a.rotations[4 * idx + 2],
-                        z = a.rotations[4 * idx + 3];
+            const float r = in_q[0], x = in_q[1], y = in_q[2], z = in_q[3];
             M3 Rm = {{{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
                       {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
                       {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}}};
-            const float s[3] = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                                a.scale_modifier * a.scales[3 * idx + 2]};
+            const float s[3] = {a.scale_modifier * in_s[0], a.scale_modifier * in_s[1], a.scale_modifier * in_s[2]};
             M3 S = {{{s[0], 0.f, 0.f}, {0.f, s[1], 0.f}, {0.f, 0.f, s[2]}}};
             M3 Mm = mul(S, Rm);
             M3 dSig = {{{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
