@@ -25,7 +25,7 @@ class MomError(RuntimeError):
 
 GACC_FLOATS = int(os.environ.get("MOM_GACC_FLOATS", "12"))         # (the override: only for A/B builds with -DMOM_GACC_FLOATS=16)
 # MOM_GACC_FLOATS: floats per Gaussian of the backward's accumulator record
-ABI_VERSION = 6          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
+ABI_VERSION = 7          # MOM_ABI_VERSION of the include/mom4d.h this mirror was written against
 
 
 class MomRasterArgs(C.Structure):
@@ -52,7 +52,7 @@ class MomRasterArgs(C.Structure):
 
 class MomRasterGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D",
-                                          "dL_dsh", "dL_dsh_rest", "dL_dscales", "dL_drotations")]
+                                          "dL_dsh", "dL_dsh_rest", "dL_dscales", "dL_drotations", "act_rotations_raw")]
 
 
 class MomRasterLayout(C.Structure):

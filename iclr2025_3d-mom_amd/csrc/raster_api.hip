@@ -35,6 +35,7 @@ static int check_grads(const MomRasterArgs* a, const MomRasterGrads* gr)
     if (a->M > 0 && !a->colors_precomp && !gr->dL_dsh) return MOM_EINVAL;
     if (a->shs_rest && !gr->dL_dsh_rest) return MOM_EINVAL;
     if (a->scales && (!gr->dL_dscales || !gr->dL_drotations)) return MOM_EINVAL;
+    if (gr->act_rotations_raw && (!a->scales || !a->rotations || a->cov3D_precomp)) return MOM_EINVAL;   // activations of inputs that are not there
     return MOM_OK;
 }
 

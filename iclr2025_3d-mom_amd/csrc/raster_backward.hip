@@ -50,6 +50,7 @@ struct BwdArgs {
     const uchar4* clamped;
     const float* gacc;
     const float4* rec;           // the forward's per-Gaussian record: rec[3 i + 1] = {conic.x, conic.y, conic.z, opacity}
+    const float* rots_raw;       // MomRasterGrads.act_rotations_raw: scale / rotation / opacity gradients go out through their activations
     float scale_modifier, tan_fovx, tan_fovy, h_x, h_y;
     int colors_from_sh;
     float *dmeans2D, *dcolors, *dopacity, *dmeans3D, *dcov3D, *dsh, *dsh_rest, *dscales, *drot;
@@ -89,6 +90,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
 #pragma unroll
         for (int i = 0; i < 3; i++) in_s[i] = p3[i];
     }
+    float4 in_qraw;
+    {
+        const float* __restrict__ pr = a.rots_raw ? a.rots_raw + 4 * (size_t)gi : a.view;
+        in_qraw = make_float4(pr[0], pr[1], pr[2], pr[3]);
+    }
     unsigned in_cl = *reinterpret_cast<const unsigned*>(a.colors_from_sh ? reinterpret_cast<const void*>(a.clamped + gi) : reinterpret_cast<const void*>(a.view));
     if (STAGED) {
         const float* __restrict__ src = a.shs_rest + (size_t)block0 * sh_stride;
@@ -111,7 +117,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     }
     // (outputs only, not `asm volatile`: that counts as a possible store and turns the uniform matrix loads below into vector loads)
     asm("" : "+v"(in_radius), "+v"(ga[0]), "+v"(ga[1]), "+v"(ga[2]), "+v"(ga[3]), "+v"(ga[4]), "+v"(ga[5]), "+v"(ga[6]), "+v"(ga[7]), "+v"(ga[8]), "+v"(ga[9]), "+v"(in_co.x), "+v"(in_co.y), "+v"(in_co.z), "+v"(in_co.w));
-    asm("" : "+v"(in_m[0]), "+v"(in_m[1]), "+v"(in_m[2]), "+v"(in_c3[0]), "+v"(in_c3[1]), "+v"(in_c3[2]), "+v"(in_c3[3]), "+v"(in_c3[4]), "+v"(in_c3[5]), "+v"(in_q[0]), "+v"(in_q[1]), "+v"(in_q[2]), "+v"(in_q[3]), "+v"(in_s[0]), "+v"(in_s[1]), "+v"(in_s[2]), "+v"(in_cl));
+    asm("" : "+v"(in_m[0]), "+v"(in_m[1]), "+v"(in_m[2]), "+v"(in_c3[0]), "+v"(in_c3[1]), "+v"(in_c3[2]), "+v"(in_c3[3]), "+v"(in_c3[4]), "+v"(in_c3[5]), "+v"(in_q[0]), "+v"(in_q[1]), "+v"(in_q[2]), "+v"(in_q[3]), "+v"(in_s[0]), "+v"(in_s[1]), "+v"(in_s[2]), "+v"(in_cl), "+v"(in_qraw.x), "+v"(in_qraw.y), "+v"(in_qraw.z), "+v"(in_qraw.w));
     if (idx < a.P) {
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
@@ -139,7 +145,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     a.dmeans2D[3 * idx + 0] = ga[0];
     a.dmeans2D[3 * idx + 1] = ga[1];
     a.dmeans2D[3 * idx + 2] = 0.f;
-    a.dopacity[idx] = ga[5];
+    // (act_rotations_raw: through the sigmoid, y (1 - y) of the opacity the forward kept in its record -- optim_loss.hip, act_bwd_kernel)
+    a.dopacity[idx] = a.rots_raw ? ga[5] * ((1.0f - in_co.w) * in_co.w) : ga[5];
     a.dcolors[3 * idx + 0] = ga[6];
     a.dcolors[3 * idx + 1] = ga[7];
     a.dcolors[3 * idx + 2] = ga[8];
@@ -352,6 +359,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
     for (int i = 0; i < 3; i++) a.dmeans3D[3 * idx + i] = dmean[i];
 #pragma unroll
     for (int i = 0; i < 6; i++) a.dcov3D[6 * idx + i] = dcov[i];
+    if (a.rots_raw) {
+        // through exp (d = g * exp(raw) = g * scale) and through q / max(|q|, eps) (zero through the clamp, as ATen does): the
+        // arithmetic of act_bwd_kernel (optim_loss.hip), operation for operation
+#pragma unroll
+        for (int i = 0; i < 3; i++) dscale[i] = dscale[i] * in_s[i];
+        const float4 q = in_qraw;
+        const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        const float n = fmaxf(nrm, 1e-12f);
+        const float4 u = make_float4(q.x / n, q.y / n, q.z / n, q.w / n);
+        const float dot = (nrm >= 1e-12f) ? (u.x * drot[0] + u.y * drot[1] + u.z * drot[2] + u.w * drot[3]) : 0.f;
+        const float g4[4] = {drot[0], drot[1], drot[2], drot[3]};
+        drot[0] = (g4[0] - u.x * dot) / n;
+        drot[1] = (g4[1] - u.y * dot) / n;
+        drot[2] = (g4[2] - u.z * dot) / n;
+        drot[3] = (g4[3] - u.w * dot) / n;
+    }
     if (a.dscales) {
 #pragma unroll
         for (int i = 0; i < 3; i++) a.dscales[3 * idx + i] = dscale[i];
@@ -387,6 +410,7 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
     b.dmeans2D = gr->dL_dmeans2D; b.dcolors = gr->dL_dcolors; b.dopacity = gr->dL_dopacity; b.dmeans3D = gr->dL_dmeans3D;
     b.dcov3D = gr->dL_dcov3D; b.dsh = gr->dL_dsh; b.dsh_rest = a->shs_rest ? gr->dL_dsh_rest : nullptr; b.dscales = a->scales ? gr->dL_dscales : nullptr;
     b.drot = a->scales ? gr->dL_drotations : nullptr;
+    b.rots_raw = gr->act_rotations_raw;                      // (raster_api.hip, check_grads: only with scales and rotations present)
     MomProfScope ps(MOM_P_PRE_BWD, s);
     const int sh_stride = (a->M - 1) * 3;
     const bool staged = b.colors_from_sh && b.shs_rest && b.dsh_rest && (sh_stride & 1) && sh_stride <= 45 &&

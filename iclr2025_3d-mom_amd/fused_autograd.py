@@ -256,22 +256,21 @@ def _backward(st, dcolor, ddepth, direct=True):
     ddep = None if ddepth is None else ddepth.contiguous().float()
     b = st.bufs
     if "gcol" not in b:               # the backward's internal gradients and scratch: made once per pooled set
-        b.update(gcol=e(P, 3), gop_act=e(P, 1), gcov=e(P, 6), gsc_act=e(P, 3), grot_act=e(P, 4), dfeat=e(P, 64),
+        b.update(gcol=e(P, 3), gcov=e(P, 6), dfeat=e(P, 64),
                  scratch=torch.empty(lib.mom_deform_backward_scratch_bytes(P), dtype=torch.uint8, device=dev))
-    g2d, gcol, gop_act, gxyz, gcov = e(P, 3), b["gcol"], b["gop_act"], e(P, 3), b["gcov"]
+    g2d, gcol, gxyz, gcov = e(P, 3), b["gcol"], e(P, 3), b["gcov"]
     gdc, grest = e(P, 1, 3), e(P, 15, 3)
-    gsc_act, grot_act, gsc, grot, gop = b["gsc_act"], b["grot_act"], e(P, 3), e(P, 4), e(P, 1)
+    gsc, grot, gop = e(P, 3), e(P, 4), e(P, 1)
     gr = N.MomRasterGrads()
-    gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = g2d.data_ptr(), gcol.data_ptr(), gop_act.data_ptr()
+    # (scale / rotation / opacity gradients: through their activations inside the projection backward -- act_rotations_raw)
+    gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = g2d.data_ptr(), gcol.data_ptr(), gop.data_ptr()
     gr.dL_dmeans3D, gr.dL_dcov3D = gxyz.data_ptr(), gcov.data_ptr()
     gr.dL_dsh, gr.dL_dsh_rest = gdc.data_ptr(), grest.data_ptr()
-    gr.dL_dscales, gr.dL_drotations = gsc_act.data_ptr(), grot_act.data_ptr()
+    gr.dL_dscales, gr.dL_drotations = gsc.data_ptr(), grot.data_ptr()
+    gr.act_rotations_raw = st.rot_d.data_ptr()
     N.check(lib.mom_raster_backward(C.byref(st.a), st.radii.data_ptr(), st.geom.data_ptr(), st.binning.data_ptr(), st.cap,
                                     st.img.data_ptr(), dcol.data_ptr(), None if ddep is None else ddep.data_ptr(), C.byref(gr), s),
             "raster_bwd")
-    N.check(lib.mom_activations_backward(P, st.sc.data_ptr(), st.rot_d.data_ptr(), st.op.data_ptr(), gsc_act.data_ptr(),
-                                         grot_act.data_ptr(), gop_act.data_ptr(), gsc.data_ptr(), grot.data_ptr(), gop.data_ptr(), s),
-            "act_bwd")
     overlap = ops.API_OVERLAP and direct
     ready = side = None
     if overlap:

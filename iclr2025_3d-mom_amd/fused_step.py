@@ -133,7 +133,7 @@ class FusedStep:
     # per-Gaussian float buffers: (attribute, floats per row, sized for a tile-row shard's padded row count)
     _ROW_BUFFERS = (("feat", 64, False), ("a0", 64, False), ("dfeat", 64, False), ("pts", 3, True), ("sc_d", 3, False),
                     ("rot_d", 4, True), ("sc", 3, True), ("rot", 4, True), ("op", 1, True), ("gcol", 3, False),
-                    ("gop_act", 1, False), ("gcov", 6, False), ("gsc_act", 3, False), ("grot_act", 4, False))
+                    ("gcov", 6, False))
 
     def _world(self):
         return self.dist.world if self.dist is not None else 1
@@ -456,10 +456,13 @@ class FusedStep:
         # ---- rasterizer backward
         ops.stream_wait_mark(s, ops.MARK_BUCKET)      # the gradient bucket is cleared and holds the regulariser's share
         gr = N.MomRasterGrads()
-        gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = self.g2d.data_ptr(), self.gcol.data_ptr(), self.gop_act.data_ptr()
+        # scale / rotation / opacity gradients leave the projection backward already through exp / normalize / sigmoid
+        # (MomRasterGrads.act_rotations_raw): no activation-backward launch behind it
+        gr.dL_dmeans2D, gr.dL_dcolors, gr.dL_dopacity = self.g2d.data_ptr(), self.gcol.data_ptr(), self.gop.data_ptr()
         gr.dL_dmeans3D, gr.dL_dcov3D = self.gxyz.data_ptr(), self.gcov.data_ptr()
         gr.dL_dsh, gr.dL_dsh_rest = self.gdc.data_ptr(), self.grest.data_ptr()
-        gr.dL_dscales, gr.dL_drotations = self.gsc_act.data_ptr(), self.grot_act.data_ptr()
+        gr.dL_dscales, gr.dL_drotations = self.gsc.data_ptr(), self.grot.data_ptr()
+        gr.act_rotations_raw = self.rot_d.data_ptr()
         if rows is None:
             N.check(lib.mom_raster_backward(C.byref(a), self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
                                             self.cap, self.img.data_ptr(), self.dimg.data_ptr(), None, C.byref(gr), s), "raster_bwd")
@@ -493,9 +496,6 @@ class FusedStep:
             # (this rank's backward has read its OWN radii by now; the overflow word rides in the same integer bucket.  Every
             # torch.distributed call costs the host 40-50 us and the host paces a rank: three collectives per step, not five)
             early_works.append(dc.start(self.ibucket, "max"))
-        N.check(lib.mom_activations_backward(P, self.sc.data_ptr(), self.rot_d.data_ptr(), self.op.data_ptr(),
-                                             self.gsc_act.data_ptr(), self.grot_act.data_ptr(), self.gop_act.data_ptr(),
-                                             self.gsc.data_ptr(), self.grot.data_ptr(), self.gop.data_ptr(), s), "act_bwd")
         d_sc, d_rot = self.gsc, self.grot       # also the gradients w.r.t. the MLP's scale / rotation outputs
         if dc is not None and dc.mode == "camera":      # 56 of the 59 floats per Gaussian travel underneath the deformation backward
             # the deformation backward below still reads this rank's own d_sc / d_rot while the bucket is being reduced in

@@ -52,7 +52,7 @@ typedef void* mom_stream_t; /* hipStream_t */
  *   - MomRasterArgs, the struct that changes most often, additionally starts with `struct_size`: every entry point that
  *     takes it returns MOM_EINVAL unless struct_size == sizeof(MomRasterArgs) of the library.
  * (The reference's counterpart is a C++ static-method signature, rasterizer.h:19-87: there the compiler checks it.) */
-#define MOM_ABI_VERSION 6
+#define MOM_ABI_VERSION 7
 /* floats per Gaussian of the compositing backward's accumulator record (mom_raster_layout().geom_gacc); ten are used.  (A build with
  * -DMOM_GACC_FLOATS=16 pads the record to one 64-byte line: a device-scope atomic costs the device by the LINES an instruction
  * touches and 48-byte records straddle 1.5 on average -- but the shipped kernel's atomics hide under its arithmetic, and the larger
@@ -185,6 +185,11 @@ typedef struct MomRasterGrads {
     float* dL_dsh_rest;   /* null, or [P,M-1,3] */
     float* dL_dscales;    /* [P,3] or null when scales absent */
     float* dL_drotations; /* [P,4] or null when rotations absent */
+    /* Optional (null: off).  The RAW rotations [P,4] the caller normalised into MomRasterArgs.rotations, for callers whose scales /
+     * rotations / opacities are exp / normalize / sigmoid of raw parameters (gaussian_renderer/__init__.py:134-137): dL_dscales,
+     * dL_drotations and dL_dopacity are then written THROUGH those activations (w.r.t. the raw values), exactly as
+     * mom_activations_backward would make them from the plain gradients, without its launch and its pass over the arrays. */
+    const float* act_rotations_raw;
 } MomRasterGrads;
 
 /* Backward (Rasterizer::backward, rasterizer_impl.cu:343-444): render backward

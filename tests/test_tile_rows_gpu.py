@@ -62,7 +62,7 @@ def _gacc(run, P):
     return _aligned(run["geom"])[off:off + P * 4 * N.GACC_FLOATS].view(torch.float32).view(P, N.GACC_FLOATS)
 
 
-def _geometry_backward(run, P):
+def _geometry_backward(run, P, act_rotations_raw=None):
     lib = N.lib()
     z = lambda *sh: torch.zeros(*sh, device="cuda")
     bufs = dict(dL_dmeans2D=z(P, 3), dL_dcolors=z(P, 3), dL_dopacity=z(P, 1), dL_dmeans3D=z(P, 3), dL_dcov3D=z(P, 6),
@@ -70,6 +70,8 @@ def _geometry_backward(run, P):
     gr = N.MomRasterGrads()
     for k, v in bufs.items():
         setattr(gr, k, v.data_ptr())
+    if act_rotations_raw is not None:
+        gr.act_rotations_raw = act_rotations_raw.data_ptr()
     N.check(lib.mom_raster_backward_geometry(C.byref(run["a"]), run["radii"].data_ptr(), run["geom"].data_ptr(), C.byref(gr),
                                              N.current_stream()), "backward_geometry")
     torch.cuda.synchronize()
@@ -122,6 +124,52 @@ def test_two_row_shards_reproduce_the_unsharded_pass(W, H, split):
     for k in want:
         sc = max(1e-20, float(np.abs(want[k]).max()))
         assert np.abs(got[k] - want[k]).max() <= 3e-5 * sc, (k, float(np.abs(got[k] - want[k]).max()), sc)
+
+
+def test_activation_backward_inside_the_projection_backward_is_the_separate_launch_bit_for_bit():
+    """MomRasterGrads.act_rotations_raw: dL_dscales / dL_drotations / dL_dopacity leave the projection backward already through
+    exp / normalize / sigmoid (gaussian_renderer/__init__.py:134-137) -- the same numbers mom_activations_backward makes of the plain
+    gradients in its own launch, bit for bit, a clamped quaternion (|q| < eps) included."""
+    lib = N.lib()
+    P, W, H = 9000, 176, 112
+    s = dict(scenes.random_gaussians(P, seed=11, W=W, H=H, scale=(-3.8, -1.8)))
+    g = torch.Generator().manual_seed(3)
+    dev = lambda x: torch.as_tensor(x).float().cuda().contiguous()
+    raw_s = torch.log(dev(s["scales"]))
+    raw_r = dev(s["rotations"]) * (0.25 + 3 * torch.rand(P, 1, generator=g)).cuda()
+    raw_r[5] = 0
+    raw_r[6] *= 1e-14
+    raw_o = torch.logit(dev(s["opacities"]).clamp(1e-4, 1 - 1e-4))
+    sc, rot, op = torch.empty_like(raw_s), torch.empty_like(raw_r), torch.empty_like(raw_o)
+    st = N.current_stream()
+    N.check(lib.mom_activations_forward(P, raw_s.data_ptr(), raw_r.data_ptr(), raw_o.data_ptr(), sc.data_ptr(), rot.data_ptr(),
+                                        op.data_ptr(), st), "act_fwd")
+    torch.cuda.synchronize()
+    s["scales"], s["rotations"], s["opacities"] = (x.cpu().numpy() for x in (sc, rot, op))
+    dcol = torch.randn(3, H, W, generator=g).cuda()
+    ddep = torch.randn(1, H, W, generator=g).cuda()
+    run = _run(s, None, dcol, ddep)
+    plain = _geometry_backward(run, P)
+    fused = _geometry_backward(run, P, act_rotations_raw=raw_r)
+    want = [torch.empty(P, k, device="cuda") for k in (3, 4, 1)]
+    ds, dr, do = (torch.from_numpy(plain[k]).cuda() for k in ("dL_dscales", "dL_drotations", "dL_dopacity"))
+    N.check(lib.mom_activations_backward(P, sc.data_ptr(), raw_r.data_ptr(), op.data_ptr(), ds.data_ptr(), dr.data_ptr(),
+                                         do.data_ptr(), want[0].data_ptr(), want[1].data_ptr(), want[2].data_ptr(), st), "act_bwd")
+    torch.cuda.synchronize()
+    assert np.abs(plain["dL_dscales"]).max() > 0 and np.abs(plain["dL_drotations"]).max() > 0
+    for k, w in zip(("dL_dscales", "dL_drotations", "dL_dopacity"), want):
+        np.testing.assert_array_equal(fused[k], w.cpu().numpy(), err_msg=k)
+    for k in ("dL_dmeans2D", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh"):        # everything else is untouched
+        np.testing.assert_array_equal(fused[k], plain[k], err_msg=k)
+    # the option needs the inputs it differentiates through
+    a = run["a"]
+    gr = N.MomRasterGrads()
+    gr.act_rotations_raw = raw_r.data_ptr()
+    keep_scales = a.scales
+    a.scales = None
+    rc = lib.mom_raster_backward_geometry(C.byref(a), run["radii"].data_ptr(), run["geom"].data_ptr(), C.byref(gr), st)
+    a.scales = keep_scales
+    assert rc == N.MOM_EINVAL
 
 
 def test_row_range_edge_cases():
