@@ -1,5 +1,8 @@
 #!/bin/bash
-V=iclr2025_3d-mom_amd/lib/var
-for r in 1 2 3; do for v in q0 q1; do MOM4D_LIB=$PWD/$V/$v.so python tools/kbench.py render_fwd render_bwd 2>/dev/null | tail -1; done; done
-for v in q0 q1; do KBENCH_CONFIG=c1 MOM4D_LIB=$PWD/$V/$v.so python tools/kbench.py render_fwd render_bwd 2>/dev/null | tail -1; done
-MOM4D_LIB=$PWD/$V/q1.so python -m pytest tests/test_raster_gpu.py tests/test_tile_rows_gpu.py tests/test_golden_gpu.py tests/test_fused_step_gpu.py -m gpu -q 2>&1 | grep -E "passed|failed|rror" | tail -5
+bash tools/collect_profiles.sh r06_c3 c3 > gpurun_out/r06_c3_collect.log 2>&1
+bash tools/collect_profiles.sh r06_c5 c5 > gpurun_out/r06_c5_collect.log 2>&1
+MOM_BENCH_FULL=gpurun_out/r06_bench_full.json python bench.py > gpurun_out/r06_bench_line.json 2> gpurun_out/r06_bench.err
+bash tools/dist_one_rank.sh gpurun_out/r06_dist > gpurun_out/r06_dist.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r06_smoke.log 2>&1
+tail -2 gpurun_out/r06_smoke.log
+tail -c 1500 gpurun_out/r06_bench_line.json
