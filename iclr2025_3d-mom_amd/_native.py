@@ -43,7 +43,8 @@ class MomRasterArgs(C.Structure):
                 ("l1_target", C.c_void_p), ("l1_grad", C.c_void_p), ("l1_sums", C.c_void_p),   # optional L1 epilogue of the forward
                 ("accum_cleared", C.c_int),
                 ("l1_partials", C.c_void_p),                        # per-tile sums of the L1 epilogue instead of two contended atomics
-                ("status_post", C.c_void_p), ("status_serial", C.c_uint)]   # the frame's status bits, posted to pinned host memory
+                ("status_post", C.c_void_p), ("status_serial", C.c_uint),   # the frame's status bits, posted to pinned host memory
+                ("l1_grad_scale", C.c_float)]                       # 0 (= 1) or a factor on the L1 epilogue's gradient (camera-batch shard: 1 / world)
 
     def __init__(self, *args, **kw):
         super().__init__(*args, **kw)
@@ -52,7 +53,8 @@ class MomRasterArgs(C.Structure):
 
 class MomRasterGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D",
-                                          "dL_dsh", "dL_dsh_rest", "dL_dscales", "dL_drotations", "act_rotations_raw")]
+                                          "dL_dsh", "dL_dsh_rest", "dL_dscales", "dL_drotations", "act_rotations_raw",
+                                          "dL_dscales_copy", "dL_drotations_copy")]
 
 
 class MomRasterLayout(C.Structure):

@@ -54,6 +54,7 @@ struct BwdArgs {
     float scale_modifier, tan_fovx, tan_fovy, h_x, h_y;
     int colors_from_sh;
     float *dmeans2D, *dcolors, *dopacity, *dmeans3D, *dcov3D, *dsh, *dsh_rest, *dscales, *drot;
+    float *dscales2, *drot2;     // MomRasterGrads.dL_dscales_copy / dL_drotations_copy: second destinations of the same values (or null)
 };
 
 // STAGED (DC and rest stored apart, an odd row length): the workgroup's higher-order SH rows are copied to LDS with
@@ -383,6 +384,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdArgs a)
 #pragma unroll
         for (int i = 0; i < 4; i++) a.drot[4 * idx + i] = drot[i];
     }
+    if (a.dscales2) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) a.dscales2[3 * idx + i] = dscale[i];
+    }
+    if (a.drot2) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) a.drot2[4 * idx + i] = drot[i];
+    }
     }   // idx < P
     if (STAGED) {
         __syncthreads();
@@ -410,6 +419,8 @@ int mom_launch_preprocess_bwd(const MomRasterArgs* a, const int* radii, const Ge
     b.dmeans2D = gr->dL_dmeans2D; b.dcolors = gr->dL_dcolors; b.dopacity = gr->dL_dopacity; b.dmeans3D = gr->dL_dmeans3D;
     b.dcov3D = gr->dL_dcov3D; b.dsh = gr->dL_dsh; b.dsh_rest = a->shs_rest ? gr->dL_dsh_rest : nullptr; b.dscales = a->scales ? gr->dL_dscales : nullptr;
     b.drot = a->scales ? gr->dL_drotations : nullptr;
+    b.dscales2 = a->scales ? gr->dL_dscales_copy : nullptr;
+    b.drot2 = a->scales ? gr->dL_drotations_copy : nullptr;
     b.rots_raw = gr->act_rotations_raw;                      // (raster_api.hip, check_grads: only with scales and rotations present)
     MomProfScope ps(MOM_P_PRE_BWD, s);
     const int sh_stride = (a->M - 1) * 3;

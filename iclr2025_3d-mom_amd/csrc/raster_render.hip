@@ -761,7 +761,8 @@ int mom_launch_render_fwd(const MomRasterArgs* a, const GeomView& g, const BinVi
         if (a->status_post) hipLaunchKernelGGL(status_post_kernel, dim3(1), dim3(1), 0, s, im.hdr, a->status_post, a->status_serial);
         return hipGetLastError() == hipSuccess ? MOM_OK : MOM_ELAUNCH;
     }
-    L1Epilogue l1 = {a->l1_target, a->l1_grad, a->l1_sums, 1.0f / (3.0f * (float)a->W * (float)a->H), a->l1_partials};
+    const float l1_inv_n = 1.0f / (3.0f * (float)a->W * (float)a->H);
+    L1Epilogue l1 = {a->l1_target, a->l1_grad, a->l1_sums, a->l1_grad_scale != 0.f ? l1_inv_n * a->l1_grad_scale : l1_inv_n, a->l1_partials};
     if (!l1.grad || (!l1.sums && !l1.partials)) l1.target = nullptr;
     hipLaunchKernelGGL(render_fwd_kernel, dim3(nt), dim3(256), 0, s, im.ranges, b.point_list, a->W, a->H, gx, nt, gx * ry0, tile_run(gx), im.tile_order, im.hdr,
                        g.rec, a->background, a->forward_only ? nullptr : im.final_T, a->forward_only ? nullptr : im.n_contrib, out_color,

@@ -376,9 +376,14 @@ class FusedStep:
         # L1 (its gradient image and its sums) in the compositing kernel's epilogue.  A tile-row shard too, unless its forward renders a
         # halo (SSIM term): the kernel runs this rank's tiles only, leaves one pair of sums per tile, and the rank adds up ITS rows
         tr_rows = dc is not None and dc.mode == "tile-row"
+        l1_scaled = False
         fuse_l1 = not tr_rows or (L1_PARTIALS and float(self.opt.lambda_dssim) == 0)
         if fuse_l1:
             a.l1_target, a.l1_grad = gt.data_ptr(), self.dimg.data_ptr()
+            # camera-batch shard: the batch loss is the mean over the ranks' cameras, every gradient carries 1 / world (below)
+            # -- in the epilogue itself when the loss is L1 alone (with the SSIM term the whole gradient image is scaled once, below)
+            l1_scaled = dc is not None and dc.mode == "camera" and float(self.opt.lambda_dssim) == 0
+            a.l1_grad_scale = 1.0 / dc.world if l1_scaled else 0.0
             if L1_PARTIALS or tr_rows:
                 a.l1_partials = self.l1_part.data_ptr()
             else:
@@ -451,8 +456,8 @@ class FusedStep:
                         "ssim_bwd_slab")
             else:
                 self.ssim_sum.zero_()
-        if dc is not None and dc.mode == "camera":
-            self.dimg.mul_(inv_world)
+        if dc is not None and dc.mode == "camera" and not (fuse_l1 and l1_scaled):
+            self.dimg.mul_(inv_world)            # (L1 alone: the forward's epilogue wrote the gradient image with the factor in it)
         # ---- rasterizer backward
         ops.stream_wait_mark(s, ops.MARK_BUCKET)      # the gradient bucket is cleared and holds the regulariser's share
         gr = N.MomRasterGrads()
@@ -463,6 +468,10 @@ class FusedStep:
         gr.dL_dsh, gr.dL_dsh_rest = self.gdc.data_ptr(), self.grest.data_ptr()
         gr.dL_dscales, gr.dL_drotations = self.gsc.data_ptr(), self.grot.data_ptr()
         gr.act_rotations_raw = self.rot_d.data_ptr()
+        if dc is not None and dc.mode == "camera":
+            # the deformation backward still reads this rank's own d_sc / d_rot while the bucket that holds them is being reduced in
+            # place: its private copies (7 floats per Gaussian) come out of the same kernel
+            gr.dL_dscales_copy, gr.dL_drotations_copy = self._loc[0].data_ptr(), self._loc[1].data_ptr()
         if rows is None:
             N.check(lib.mom_raster_backward(C.byref(a), self.radii.data_ptr(), self.geom.data_ptr(), self.binning.data_ptr(),
                                             self.cap, self.img.data_ptr(), self.dimg.data_ptr(), None, C.byref(gr), s), "raster_bwd")
@@ -498,11 +507,7 @@ class FusedStep:
             early_works.append(dc.start(self.ibucket, "max"))
         d_sc, d_rot = self.gsc, self.grot       # also the gradients w.r.t. the MLP's scale / rotation outputs
         if dc is not None and dc.mode == "camera":      # 56 of the 59 floats per Gaussian travel underneath the deformation backward
-            # the deformation backward below still reads this rank's own d_sc / d_rot while the bucket is being reduced in
-            # place: give it private copies (7 floats per Gaussian)
-            d_sc, d_rot = self._loc
-            d_sc.copy_(self.gsc)
-            d_rot.copy_(self.grot)
+            d_sc, d_rot = self._loc            # private copies, written by the projection backward (above)
             if sharded:
                 # reduce-scatter of the appearance gradients (this rank keeps the sum of ITS chunk) + the small all-reduce of the
                 # screen-space gradients every rank's statistics need in full: one launch on the direct path

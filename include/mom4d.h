@@ -140,6 +140,10 @@ typedef struct MomRasterArgs {
      * the stream per frame, 15 us of host time per call of the drop-in's async mode). */
     unsigned long long* status_post;
     uint32_t status_serial;
+    /* 0 (= 1), or a factor on the L1 epilogue's gradient: l1_grad = sign(image - target) * ((1 / (3 H W)) * l1_grad_scale).  A camera-batch
+     * shard's loss is the mean over the ranks' cameras (train_4DGS.py:189-229), so every rank's gradient image carries 1 / world: with
+     * the factor here there is no scaling pass over the gradient image behind the forward.  The sums are not scaled. */
+    float l1_grad_scale;
 } MomRasterArgs;
 
 /* Scratch sizing (bytes).  The three buffers play the roles of the reference's
@@ -190,6 +194,11 @@ typedef struct MomRasterGrads {
      * dL_drotations and dL_dopacity are then written THROUGH those activations (w.r.t. the raw values), exactly as
      * mom_activations_backward would make them from the plain gradients, without its launch and its pass over the arrays. */
     const float* act_rotations_raw;
+    /* Optional second destinations of dL_dscales / dL_drotations (same values): a caller that reduces those two over ranks in place
+     * while another kernel still reads its own copy (the camera-batch shard's deformation backward) gets the copies from the kernel
+     * that makes the values, not from two copy launches behind it. */
+    float* dL_dscales_copy;
+    float* dL_drotations_copy;
 } MomRasterGrads;
 
 /* Backward (Rasterizer::backward, rasterizer_impl.cu:343-444): render backward

@@ -490,6 +490,12 @@ def test_l1_epilogue_of_the_forward_equals_the_l1_kernel():
     np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy(), rtol=2e-6)
     ref = (c0 - gt).double()
     np.testing.assert_allclose(s1.cpu().numpy(), [float(ref.abs().sum()), float((ref * ref).sum())], rtol=2e-6)
+    # l1_grad_scale (a camera-batch shard's 1 / world): the gradient image a scaling pass behind the forward would leave, the sums untouched
+    for w in (2, 3, 8):
+        a.l1_grad_scale = 1.0 / w
+        c4, d4, s4 = forward(True, partials=True)
+        assert torch.equal(c4, c0) and torch.equal(d4, d0 * (1.0 / w)) and torch.equal(s4, s2), w
+    a.l1_grad_scale = 0.0
 
 
 def test_status_post_reports_the_frames_own_overflow_with_its_serial():

@@ -62,7 +62,7 @@ def _gacc(run, P):
     return _aligned(run["geom"])[off:off + P * 4 * N.GACC_FLOATS].view(torch.float32).view(P, N.GACC_FLOATS)
 
 
-def _geometry_backward(run, P, act_rotations_raw=None):
+def _geometry_backward(run, P, act_rotations_raw=None, copies=False):
     lib = N.lib()
     z = lambda *sh: torch.zeros(*sh, device="cuda")
     bufs = dict(dL_dmeans2D=z(P, 3), dL_dcolors=z(P, 3), dL_dopacity=z(P, 1), dL_dmeans3D=z(P, 3), dL_dcov3D=z(P, 6),
@@ -72,6 +72,9 @@ def _geometry_backward(run, P, act_rotations_raw=None):
         setattr(gr, k, v.data_ptr())
     if act_rotations_raw is not None:
         gr.act_rotations_raw = act_rotations_raw.data_ptr()
+    if copies:
+        bufs["dL_dscales_copy"], bufs["dL_drotations_copy"] = z(P, 3) + 7, z(P, 4) + 7
+        gr.dL_dscales_copy, gr.dL_drotations_copy = bufs["dL_dscales_copy"].data_ptr(), bufs["dL_drotations_copy"].data_ptr()
     N.check(lib.mom_raster_backward_geometry(C.byref(run["a"]), run["radii"].data_ptr(), run["geom"].data_ptr(), C.byref(gr),
                                              N.current_stream()), "backward_geometry")
     torch.cuda.synchronize()
@@ -150,7 +153,10 @@ def test_activation_backward_inside_the_projection_backward_is_the_separate_laun
     ddep = torch.randn(1, H, W, generator=g).cuda()
     run = _run(s, None, dcol, ddep)
     plain = _geometry_backward(run, P)
-    fused = _geometry_backward(run, P, act_rotations_raw=raw_r)
+    fused = _geometry_backward(run, P, act_rotations_raw=raw_r, copies=True)
+    # (dL_dscales_copy / dL_drotations_copy: the same values a second time, for a caller that reduces the first pair in place)
+    np.testing.assert_array_equal(fused.pop("dL_dscales_copy"), fused["dL_dscales"])
+    np.testing.assert_array_equal(fused.pop("dL_drotations_copy"), fused["dL_drotations"])
     want = [torch.empty(P, k, device="cuda") for k in (3, 4, 1)]
     ds, dr, do = (torch.from_numpy(plain[k]).cuda() for k in ("dL_dscales", "dL_drotations", "dL_dopacity"))
     N.check(lib.mom_activations_backward(P, sc.data_ptr(), raw_r.data_ptr(), op.data_ptr(), ds.data_ptr(), dr.data_ptr(),
